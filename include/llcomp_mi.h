@@ -1,0 +1,124 @@
+/* llcomp_mi.h -- C ABI of the MI355X-native llcomp coding path (libllcomp_mi.so).
+ *
+ * The reference (vovach777/llcomp) is a header-only C++ library with exactly two entry points and no
+ * FFI of its own; this header is the boundary a maintainer would bind instead of them:
+ *
+ *   llcomp::compressImage(const std::vector<uint8_t>& rgb, int w, int h, int channels)
+ *        -> std::vector<uint8_t>                         /root/reference/llcomp.hpp:358
+ *   llcomp::decompressImage(const std::vector<uint8_t>& data) -> RawImage{pixels,width,height,channels}
+ *                                                        /root/reference/llcomp.hpp:454-461
+ *   callers: llcompc.cpp:33, llcompd.cpp:26
+ *
+ * Everything here is plain C: pointers, sizes, integer status codes.  No torch, no C++ types.
+ * All compute runs in hand-written HIP kernels for gfx950; there is NO CPU code path behind these
+ * calls -- without a HIP device they return LLCOMP_MI_NO_DEVICE.
+ * include/llcomp_mi.hpp layers the reference's own C++ signatures on top; INTEGRATION.md shows the
+ * binding.
+ */
+#ifndef LLCOMP_MI_H
+#define LLCOMP_MI_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LLCOMP_MI_ABI_VERSION 1
+
+/* Wire formats.  LEGACY is the reference's own: [0x79][channels u8][width u16 LE][height u16 LE] + ONE
+ * range-coded stream (llcomp.hpp:375-378); it is a single serial chain (one GPU lane).  SLICED is this
+ * project's container: independent slices, each a bare reference-compatible stream with fresh state:
+ *   [0x9C][ver=1][channels][flags bit0=planar] [w u32][h u32][tile_w u32][tile_h u32][n_slices u32]
+ *   [len u32] x n_slices  [payload bytes ...]                                  (all little-endian) */
+#define LLCOMP_MI_MAGIC_LEGACY 0x79
+#define LLCOMP_MI_MAGIC_SLICED 0x9C
+#define LLCOMP_MI_SLICED_HEADER_BYTES 24
+
+typedef enum llcomp_mi_status {
+    LLCOMP_MI_OK = 0,
+    LLCOMP_MI_BAD_MAGIC = 1,       /* reference throws "Invalid magic number"  (llcomp.hpp:465-467) */
+    LLCOMP_MI_BAD_EXPONENT = 2,    /* reference throws "Invalid exponent"      (llcomp.hpp:232-234) */
+    LLCOMP_MI_TRUNCATED = 3,       /* header or slice table longer than the data (reference: UB, D5) */
+    LLCOMP_MI_BAD_ARGS = 4,        /* null pointers, zero sizes, channels outside 1..4, bad opts */
+    LLCOMP_MI_OUT_OF_RANGE = 5,    /* legacy format with w or h > 65535, or w*h*c >= 2^31 (reference: silent truncation, D4) */
+    LLCOMP_MI_OUTPUT_OVERFLOW = 6, /* caller-provided output capacity too small (reference: heap overflow, D1) */
+    LLCOMP_MI_HIP_ERROR = 7,
+    LLCOMP_MI_NO_DEVICE = 8,
+    LLCOMP_MI_NOMEM = 9
+} llcomp_mi_status;
+
+typedef enum llcomp_mi_format { LLCOMP_MI_FORMAT_LEGACY = 0, LLCOMP_MI_FORMAT_SLICED = 1 } llcomp_mi_format;
+
+typedef struct llcomp_mi_opts {
+    uint32_t struct_size; /* = sizeof(llcomp_mi_opts) */
+    uint32_t format;      /* llcomp_mi_format */
+    uint32_t tile_w;      /* slice width  in pixels, 0 = full width   (SLICED only) */
+    uint32_t tile_h;      /* slice height in pixels, 0 = full height  (SLICED only) */
+    uint32_t planar;      /* 1 = one slice per colour-transformed channel plane, 0 = channels interleaved */
+    int32_t device;       /* HIP device ordinal, -1 = current device */
+} llcomp_mi_opts;
+
+/* ---- host-buffer API: drop-in for compressImage / decompressImage ------------------------------------ */
+/* px: h*w*c bytes, row-major, channels interleaved (exactly the reference's `rgb` vector).  opts==NULL means
+ * LEGACY on the current device.  *out is allocated by the library; release with llcomp_mi_free. */
+int llcomp_mi_encode(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, const llcomp_mi_opts* opts,
+                     uint8_t** out, size_t* out_len);
+/* Accepts either wire format (dispatch on the magic byte).  *px allocated by the library. */
+int llcomp_mi_decode(const uint8_t* data, size_t len, int32_t device, uint8_t** px, uint32_t* w, uint32_t* h,
+                     uint32_t* c);
+void llcomp_mi_free(void* p);
+const char* llcomp_mi_strerror(int status);
+int llcomp_mi_abi_version(void);
+/* Number of usable HIP devices (0 when there is none; never fails). */
+int llcomp_mi_device_count(void);
+
+/* ---- host-side container tools (no GPU involved) ------------------------------------------------------ */
+typedef struct llcomp_mi_info {
+    uint32_t format, channels, width, height, tile_w, tile_h, planar, n_slices;
+    uint64_t table_offset;   /* byte offset of the slice length table (0 for LEGACY) */
+    uint64_t payload_offset; /* byte offset of the first payload byte */
+} llcomp_mi_info;
+int llcomp_mi_probe(const uint8_t* data, size_t len, llcomp_mi_info* info);
+uint32_t llcomp_mi_slice_count(uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar);
+/* Concatenator for multi-GPU sharding: `bands` are SLICED containers of consecutive horizontal bands of one
+ * image (same width/channels/tile/planar; every band but the last a multiple of tile_h rows, because slices
+ * have slice-local borders a band's slices ARE the full image's slices).  Produces the container of the whole
+ * image.  Inverse: llcomp_mi_split_band extracts tile rows [tile_row0, tile_row1). */
+int llcomp_mi_merge_bands(const uint8_t* const* bands, const size_t* band_lens, uint32_t n_bands, uint8_t** out,
+                          size_t* out_len);
+int llcomp_mi_split_band(const uint8_t* data, size_t len, uint32_t tile_row0, uint32_t tile_row1, uint8_t** out,
+                         size_t* out_len);
+
+/* ---- device-resident batch codec: buffers stay in HBM, work is enqueued on the caller's stream --------- */
+/* One codec object = fixed geometry (frames x h x w x c, tiling) + its own workspace on one device.
+ * `frames` images of identical shape are coded per call; every frame gets the slices of the SLICED format
+ * (slice ids run frame-major).  All device pointers are hipMalloc'ed (or torch) memory on that device.  */
+typedef struct llcomp_mi_codec llcomp_mi_codec;
+int llcomp_mi_codec_create(llcomp_mi_codec** codec, int32_t device, uint32_t frames, uint32_t w, uint32_t h,
+                           uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar);
+void llcomp_mi_codec_destroy(llcomp_mi_codec* codec);
+uint32_t llcomp_mi_codec_slices(const llcomp_mi_codec* codec);        /* total = frames * slices per frame */
+uint64_t llcomp_mi_codec_workspace_bytes(const llcomp_mi_codec* codec);
+/* Upper bound on the packed payload bytes the codec can emit for any input (13 B per sample + slack). */
+uint64_t llcomp_mi_codec_max_payload_bytes(const llcomp_mi_codec* codec);
+/* encode: d_px [frames][h][w][c] u8 -> d_payload (slice payloads packed back to back, slice order),
+ * d_slice_len u32[slices], d_total u64[1] (= sum of lengths).  payload_cap = bytes available at d_payload; if
+ * the packed size exceeds it nothing past the capacity is written and the status word reports OVERFLOW.
+ * Asynchronous on `stream` (a hipStream_t, NULL = default stream).  d_status: u32[1], LLCOMP_MI_OK or an error,
+ * valid once the stream has drained. */
+int llcomp_mi_codec_encode(llcomp_mi_codec* codec, const void* d_px, void* d_payload, uint64_t payload_cap,
+                           void* d_slice_len, void* d_total, void* d_status, void* stream);
+/* decode: inverse.  d_payload/d_slice_len as produced by encode (payload_bytes = total), d_px out. */
+int llcomp_mi_codec_decode(llcomp_mi_codec* codec, const void* d_payload, uint64_t payload_bytes,
+                           const void* d_slice_len, void* d_px, void* d_status, void* stream);
+/* Stage-A only (context + prediction model), for tests and profiling: d_sym u32[frames*h*w*c],
+ * low 16 bits = folded context (0..7925), high 16 bits = folded residual (two's complement). */
+int llcomp_mi_codec_model(llcomp_mi_codec* codec, const void* d_px, void* d_sym, void* stream);
+/* Timing probe: runs fn on the codec's own HIP events around the last encode/decode is NOT provided; callers
+ * time with hipEvents on `stream` (bench.py does). */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

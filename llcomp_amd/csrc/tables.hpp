@@ -1,0 +1,36 @@
+// tables.hpp -- bitstream constants of the llcomp coding path, in the form the kernels use.
+//
+// The adaptive binary model (reference: cabac::State + nextStateMps/nextStateLps/stateProbability,
+// /root/reference/llcomp.hpp:252-293) is a 128-state machine, state = 2*level + mps, level 0..63:
+//   P(bit==1)*256 = mps ? 254 - kLpsProb[level] : kLpsProb[level]
+//   bit == mps -> level+1 (saturating at 63);  bit != mps -> level==0 ? flip mps : kLpsFall[level]
+// packed_state(s) folds that into ONE 32-bit word per state so a bin costs a single LDS read:
+//   bits 0..7  P(bit==1)*256      bits 8..15 next state if the coded bit is 0      bits 16..23 next state if 1
+#pragma once
+#include <cstdint>
+
+namespace llcomp_mi {
+
+constexpr int kContexts = 7926;      // reachable folded contexts 0..7925 (hash multipliers 1,11,121,605,3025)
+constexpr int kSlotsPerContext = 8;  // llcomp.hpp:25 substates_nb
+constexpr int kMaxBytesPerSample = 13;  // 19 bins * log2(256/6) bits < 104 bits (DESIGN.md "Output bound")
+
+constexpr uint8_t kLpsProb[64] = {
+    123, 117, 111, 106, 101, 96, 91, 87, 83, 79, 75, 72, 68, 66, 63, 60, 57, 54, 52, 49, 48, 45,
+    43,  41,  40,  38,  36,  35, 33, 32, 30, 30, 28, 27, 26, 25, 24, 23, 22, 21, 21, 20, 19, 18,
+    18,  17,  17,  16,  16,  15, 15, 14, 14, 13, 13, 13, 12, 12, 12, 11, 11, 11, 11, 7};
+constexpr uint8_t kLpsFall[64] = {
+    0,  0,  1,  2,  2,  4,  4,  5,  6,  7,  8,  9,  9,  11, 11, 12, 13, 13, 15, 15, 16, 16,
+    18, 18, 19, 19, 21, 21, 22, 22, 23, 24, 24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30,
+    31, 32, 32, 33, 33, 33, 34, 34, 35, 35, 35, 36, 36, 36, 37, 38, 38, 38, 38, 39};
+
+constexpr uint32_t state_prob(uint32_t s) { return (s & 1) ? 254u - kLpsProb[s >> 1] : kLpsProb[s >> 1]; }
+constexpr uint32_t state_next(uint32_t s, uint32_t bit) {
+    const uint32_t level = s >> 1, mps = s & 1;
+    if (bit == mps) return 2 * (level < 63 ? level + 1 : 63) + mps;
+    if (level == 0) return mps ^ 1;
+    return 2 * kLpsFall[level] + mps;
+}
+constexpr uint32_t packed_state(uint32_t s) { return state_prob(s) | (state_next(s, 0) << 8) | (state_next(s, 1) << 16); }
+
+}  // namespace llcomp_mi
