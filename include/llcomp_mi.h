@@ -115,8 +115,15 @@ int llcomp_mi_codec_decode(llcomp_mi_codec* codec, const void* d_payload, uint64
 /* Stage-A only (context + prediction model), for tests and profiling: d_sym u32[frames*h*w*c],
  * low 16 bits = folded context (0..7925), high 16 bits = folded residual (two's complement). */
 int llcomp_mi_codec_model(llcomp_mi_codec* codec, const void* d_px, void* d_sym, void* stream);
-/* Timing probe: runs fn on the codec's own HIP events around the last encode/decode is NOT provided; callers
- * time with hipEvents on `stream` (bench.py does). */
+/* The u32 status word written by encode/decode holds bit flags (1 overflow, 2 bad exponent, 4 truncated);
+ * this maps it to an llcomp_mi_status. */
+uint32_t llcomp_mi_status_from_bits(uint32_t bits);
+/* Per-kernel timing with hipEvents recorded on the caller's stream around each launch (bench.py's roofline leg).
+ * get_profile drains the stream, adds up the milliseconds since the last call and resets:
+ *   ms[0] state-table clear  ms[1] k_model_fwd  ms[2] k_encode_slices  ms[3] k_scan_lengths+k_pack_payload
+ *   ms[4] k_scan_lengths (decode)  ms[5] k_decode_slices  ms[6] k_model_inv  ms[7] state-table clear (decode) */
+int llcomp_mi_codec_set_profiling(llcomp_mi_codec* codec, int enable);
+int llcomp_mi_codec_get_profile(llcomp_mi_codec* codec, double* ms8, uint32_t* n_encode, uint32_t* n_decode);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,159 @@
+"""llcomp_amd -- host-side mirror (Python, for tests / bench / scripting) of the MI355X-native llcomp coding path.
+
+The product is libllcomp_mi.so (hand-written HIP kernels for gfx950 behind the C ABI of include/llcomp_mi.h);
+include/llcomp_mi.hpp is the C++ drop-in with the reference's own signatures.  This module binds the same C ABI
+with ctypes and keeps the reference's names and error behaviour:
+
+    compress_image(rgb, width, height, channels)  <->  llcomp::compressImage    (/root/reference/llcomp.hpp:358)
+    decompress_image(data) -> RawImage            <->  llcomp::decompressImage  (/root/reference/llcomp.hpp:461)
+    RawImage(pixels, width, height, channels)     <->  llcomp::RawImage         (/root/reference/llcomp.hpp:454-459)
+    EXT = ".llcomp"                               <->  llcomp::ext              (/root/reference/llcomp.hpp:18)
+
+Errors: the reference throws std::runtime_error("Invalid magic number") / ("Invalid exponent"); here LlcompError
+carries the same message text plus the C status code.  There is no CPU fallback anywhere in this package.
+"""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import Info, Opts
+
+EXT = ".llcomp"
+FORMAT_LEGACY, FORMAT_SLICED = 0, 1
+(OK, BAD_MAGIC, BAD_EXPONENT, TRUNCATED, BAD_ARGS, OUT_OF_RANGE, OUTPUT_OVERFLOW, HIP_ERROR, NO_DEVICE, NOMEM) = range(10)
+
+RawImage = namedtuple("RawImage", "pixels width height channels")
+
+
+class LlcompError(RuntimeError):
+    def __init__(self, status):
+        self.status = int(status)
+        super().__init__(_lib.load().llcomp_mi_strerror(int(status)).decode())
+
+
+def _check(rc):
+    if rc != OK:
+        raise LlcompError(rc)
+
+
+def device_count():
+    return _lib.load().llcomp_mi_device_count()
+
+
+def compress_image(rgb, width, height, channels, *, format=FORMAT_LEGACY, tile_w=0, tile_h=0, planar=False, device=-1):
+    """bytes of an llcomp stream.  Default = the reference's own whole-image format (magic 0x79), byte-identical to
+    llcomp::compressImage; format=FORMAT_SLICED produces the parallel container (magic 0x9C)."""
+    L = _lib.load()
+    buf = np.ascontiguousarray(np.frombuffer(rgb, dtype=np.uint8) if isinstance(rgb, (bytes, bytearray, memoryview)) else rgb, dtype=np.uint8).reshape(-1)
+    if buf.size != width * height * channels:  # the reference only asserts this (llcomp.hpp:361)
+        raise LlcompError(BAD_ARGS)
+    o = Opts(C.sizeof(Opts), format, tile_w, tile_h, int(bool(planar)), device)
+    out, n = _lib.u8p(), C.c_size_t()
+    _check(L.llcomp_mi_encode(buf.ctypes.data_as(_lib.u8p), width, height, channels, C.byref(o), C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        L.llcomp_mi_free(out)
+
+
+def decompress_image(data, *, device=-1):
+    """RawImage(pixels: np.uint8[h,w,c], width, height, channels) from either wire format."""
+    L = _lib.load()
+    data = bytes(data)
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data or b"\0")
+    px, w, h, c = _lib.u8p(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    _check(L.llcomp_mi_decode(C.cast(buf, _lib.u8p), len(data), device, C.byref(px), C.byref(w), C.byref(h), C.byref(c)))
+    try:
+        n = w.value * h.value * c.value
+        pixels = np.frombuffer(C.string_at(px, n), dtype=np.uint8).reshape(h.value, w.value, c.value)
+    finally:
+        L.llcomp_mi_free(px)
+    return RawImage(pixels, w.value, h.value, c.value)
+
+
+def probe(data):
+    L = _lib.load()
+    data = bytes(data)
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data or b"\0")
+    info = Info()
+    _check(L.llcomp_mi_probe(C.cast(buf, _lib.u8p), len(data), C.byref(info)))
+    return info
+
+
+def slice_count(w, h, c, tile_w=0, tile_h=0, planar=False):
+    return _lib.load().llcomp_mi_slice_count(w, h, c, tile_w, tile_h, int(bool(planar)))
+
+
+def merge_bands(bands):
+    """Concatenate SLICED containers of consecutive horizontal bands (multi-GPU shards) into one container."""
+    L = _lib.load()
+    n = len(bands)
+    keep = [(C.c_uint8 * max(1, len(b))).from_buffer_copy(bytes(b) or b"\0") for b in bands]
+    ptrs = (_lib.u8p * n)(*[C.cast(k, _lib.u8p) for k in keep])
+    lens = (C.c_size_t * n)(*[len(b) for b in bands])
+    out, m = _lib.u8p(), C.c_size_t()
+    _check(L.llcomp_mi_merge_bands(ptrs, lens, n, C.byref(out), C.byref(m)))
+    try:
+        return C.string_at(out, m.value)
+    finally:
+        L.llcomp_mi_free(out)
+
+
+def split_band(data, tile_row0, tile_row1):
+    L = _lib.load()
+    data = bytes(data)
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data or b"\0")
+    out, m = _lib.u8p(), C.c_size_t()
+    _check(L.llcomp_mi_split_band(C.cast(buf, _lib.u8p), len(data), tile_row0, tile_row1, C.byref(out), C.byref(m)))
+    try:
+        return C.string_at(out, m.value)
+    finally:
+        L.llcomp_mi_free(out)
+
+
+class Codec:
+    """Device-resident batch codec (llcomp_mi_codec_*): `frames` images of one shape per call, buffers stay in HBM.
+    Pointers are raw device addresses (e.g. torch tensor .data_ptr()); `stream` is a hipStream_t handle
+    (torch.cuda.current_stream().cuda_stream) or 0."""
+
+    def __init__(self, frames, w, h, c, tile_w=0, tile_h=0, planar=False, device=-1):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        _check(self._L.llcomp_mi_codec_create(C.byref(self._h), device, frames, w, h, c, tile_w, tile_h, int(bool(planar))))
+        self.frames, self.w, self.h, self.c = frames, w, h, c
+        self.n_slices = self._L.llcomp_mi_codec_slices(self._h)
+        self.max_payload_bytes = self._L.llcomp_mi_codec_max_payload_bytes(self._h)
+        self.workspace_bytes = self._L.llcomp_mi_codec_workspace_bytes(self._h)
+
+    def close(self):
+        if self._h:
+            self._L.llcomp_mi_codec_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def encode(self, d_px, d_payload, payload_cap, d_slice_len, d_total, d_status, stream=0):
+        _check(self._L.llcomp_mi_codec_encode(self._h, d_px, d_payload, payload_cap, d_slice_len, d_total, d_status, stream))
+
+    def decode(self, d_payload, payload_bytes, d_slice_len, d_px, d_status, stream=0):
+        _check(self._L.llcomp_mi_codec_decode(self._h, d_payload, payload_bytes, d_slice_len, d_px, d_status, stream))
+
+    def model(self, d_px, d_sym, stream=0):
+        _check(self._L.llcomp_mi_codec_model(self._h, d_px, d_sym, stream))
+
+    PROFILE_SLOTS = ("clear_states_enc", "k_model_fwd", "k_encode_slices", "scan+pack", "k_scan_lengths_dec", "k_decode_slices", "k_model_inv", "clear_states_dec")
+
+    def set_profiling(self, on=True):
+        _check(self._L.llcomp_mi_codec_set_profiling(self._h, int(on)))
+
+    def get_profile(self):
+        """-> ({slot: total ms since last call}, n_encode, n_decode); drains the stream."""
+        ms = (C.c_double * 8)()
+        ne, nd = C.c_uint32(), C.c_uint32()
+        _check(self._L.llcomp_mi_codec_get_profile(self._h, ms, C.byref(ne), C.byref(nd)))
+        return dict(zip(self.PROFILE_SLOTS, list(ms))), ne.value, nd.value
+
+    def status(self, bits):
+        return self._L.llcomp_mi_status_from_bits(int(bits))

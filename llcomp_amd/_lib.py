@@ -1,0 +1,87 @@
+"""ctypes loader for the product library libllcomp_mi.so (HIP kernels + C ABI, include/llcomp_mi.h).
+
+There is deliberately no fallback: if the library is missing this raises, and if there is no HIP device the
+library's calls return LLCOMP_MI_NO_DEVICE -- nothing in this package can code a single byte on the CPU."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libllcomp_mi.so")
+
+# every symbol include/llcomp_mi.h declares (tests/test_abi.py checks the header against this list and the .so)
+SYMBOLS = [
+    "llcomp_mi_encode", "llcomp_mi_decode", "llcomp_mi_free", "llcomp_mi_strerror", "llcomp_mi_abi_version",
+    "llcomp_mi_device_count", "llcomp_mi_probe", "llcomp_mi_slice_count", "llcomp_mi_merge_bands",
+    "llcomp_mi_split_band", "llcomp_mi_codec_create", "llcomp_mi_codec_destroy", "llcomp_mi_codec_slices",
+    "llcomp_mi_codec_workspace_bytes", "llcomp_mi_codec_max_payload_bytes", "llcomp_mi_codec_encode",
+    "llcomp_mi_codec_decode", "llcomp_mi_codec_model", "llcomp_mi_status_from_bits",
+    "llcomp_mi_codec_set_profiling", "llcomp_mi_codec_get_profile",
+]
+
+u8p = C.POINTER(C.c_uint8)
+
+
+class Opts(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("format", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32),
+                ("planar", C.c_uint32), ("device", C.c_int32)]
+
+
+class Info(C.Structure):
+    _fields_ = [("format", C.c_uint32), ("channels", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("planar", C.c_uint32), ("n_slices", C.c_uint32),
+                ("table_offset", C.c_uint64), ("payload_offset", C.c_uint64)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(or `make -C llcomp_amd/csrc`). llcomp_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.llcomp_mi_encode.restype = C.c_int
+    L.llcomp_mi_encode.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Opts), C.POINTER(u8p), C.POINTER(C.c_size_t)]
+    L.llcomp_mi_decode.restype = C.c_int
+    L.llcomp_mi_decode.argtypes = [u8p, C.c_size_t, C.c_int32, C.POINTER(u8p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.llcomp_mi_free.restype = None
+    L.llcomp_mi_free.argtypes = [C.c_void_p]
+    L.llcomp_mi_strerror.restype = C.c_char_p
+    L.llcomp_mi_strerror.argtypes = [C.c_int]
+    L.llcomp_mi_abi_version.restype = C.c_int
+    L.llcomp_mi_device_count.restype = C.c_int
+    L.llcomp_mi_probe.restype = C.c_int
+    L.llcomp_mi_probe.argtypes = [u8p, C.c_size_t, C.POINTER(Info)]
+    L.llcomp_mi_slice_count.restype = C.c_uint32
+    L.llcomp_mi_slice_count.argtypes = [C.c_uint32] * 6
+    L.llcomp_mi_merge_bands.restype = C.c_int
+    L.llcomp_mi_merge_bands.argtypes = [C.POINTER(u8p), C.POINTER(C.c_size_t), C.c_uint32, C.POINTER(u8p), C.POINTER(C.c_size_t)]
+    L.llcomp_mi_split_band.restype = C.c_int
+    L.llcomp_mi_split_band.argtypes = [u8p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(u8p), C.POINTER(C.c_size_t)]
+    L.llcomp_mi_codec_create.restype = C.c_int
+    L.llcomp_mi_codec_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32] + [C.c_uint32] * 7
+    L.llcomp_mi_codec_destroy.restype = None
+    L.llcomp_mi_codec_destroy.argtypes = [C.c_void_p]
+    L.llcomp_mi_codec_slices.restype = C.c_uint32
+    L.llcomp_mi_codec_slices.argtypes = [C.c_void_p]
+    L.llcomp_mi_codec_workspace_bytes.restype = C.c_uint64
+    L.llcomp_mi_codec_workspace_bytes.argtypes = [C.c_void_p]
+    L.llcomp_mi_codec_max_payload_bytes.restype = C.c_uint64
+    L.llcomp_mi_codec_max_payload_bytes.argtypes = [C.c_void_p]
+    L.llcomp_mi_codec_encode.restype = C.c_int
+    L.llcomp_mi_codec_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.llcomp_mi_codec_decode.restype = C.c_int
+    L.llcomp_mi_codec_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.llcomp_mi_codec_model.restype = C.c_int
+    L.llcomp_mi_codec_model.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.llcomp_mi_status_from_bits.restype = C.c_uint32
+    L.llcomp_mi_status_from_bits.argtypes = [C.c_uint32]
+    L.llcomp_mi_codec_set_profiling.restype = C.c_int
+    L.llcomp_mi_codec_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.llcomp_mi_codec_get_profile.restype = C.c_int
+    L.llcomp_mi_codec_get_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    _lib = L
+    return L

@@ -1,0 +1,38 @@
+// kernels.hpp -- launchers of the gfx950 kernels (kernels.hip).  All launches are asynchronous on `stream`.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "geometry.hpp"
+
+namespace llcomp_mi {
+
+// status word bits written by kernels (atomicOr); mapped to llcomp_mi_status by the host
+enum : uint32_t { kStOverflow = 1u, kStBadExponent = 2u, kStTruncated = 4u };
+
+// Stage A (encode side): pixels u8 [frames][h][w][c] -> per-sample symbols u32 in the same layout:
+// low 16 bits folded context, high 16 bits folded residual.  llcomp.hpp:396-436.
+hipError_t launch_model_fwd(const Geometry& g, const uint8_t* d_px, uint32_t* d_sym, hipStream_t stream);
+// Stage A (decode side): reconstructed colour-transformed samples int16 -> pixels u8.  llcomp.hpp:532-543.
+hipError_t launch_model_inv(const Geometry& g, const int16_t* d_rec, uint8_t* d_px, hipStream_t stream);
+
+// One lane per slice: binarisation + adaptive states + range encoder.  llcomp.hpp:33-89, 166-206, 283-293, 439-449.
+//   d_states  : u64[n_slices][kContexts], zeroed by the caller (8 state bytes per context)
+//   d_scratch : u8[n_slices][slice_cap]  ; d_slice_len : u32[n_slices]
+hipError_t launch_encode_slices(const Geometry& g, const uint32_t* d_sym, uint64_t* d_states, uint8_t* d_scratch,
+                                uint32_t* d_slice_len, uint32_t* d_status, hipStream_t stream);
+// Exclusive prefix sum of slice lengths (u64[n_slices+1]; last = total, also stored to d_total).
+hipError_t launch_scan_lengths(const uint32_t* d_slice_len, uint32_t n, uint64_t* d_offsets, uint64_t* d_total,
+                               hipStream_t stream);
+// Packs the per-slice scratch streams back to back into d_payload (capacity payload_cap).
+hipError_t launch_pack_payload(const Geometry& g, const uint8_t* d_scratch, const uint32_t* d_slice_len,
+                               const uint64_t* d_offsets, uint8_t* d_payload, uint64_t payload_cap,
+                               uint32_t* d_status, hipStream_t stream);
+// One lane per slice: range decoder + adaptive states + context model on reconstructed samples.
+// llcomp.hpp:91-127, 219-247, 486-530.  d_rec int16 [frames][h][w][c].
+hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_payload, uint64_t payload_bytes,
+                                const uint32_t* d_slice_len, const uint64_t* d_offsets, uint64_t* d_states,
+                                int16_t* d_rec, uint32_t* d_status, hipStream_t stream);
+
+}  // namespace llcomp_mi
