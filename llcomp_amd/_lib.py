@@ -35,6 +35,29 @@ class Info(C.Structure):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """libllcomp_mi.so is linked without its own HIP runtime (see csrc/Makefile): exactly one libamdhip64 may live
+    in a process.  PyTorch wheels bundle a private copy, so when torch is installed that copy is the one to share
+    (streams and device pointers handed over from torch then belong to the same runtime); otherwise /opt/rocm's."""
+    import importlib.util
+
+    cands = []
+    spec = importlib.util.find_spec("torch")
+    if spec is not None and spec.origin:
+        cands.append(os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so"))
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cands += [os.path.join(rocm, "lib", "libamdhip64.so.7"), os.path.join(rocm, "lib", "libamdhip64.so"), "libamdhip64.so"]
+    errs = []
+    for c in cands:
+        if os.path.isabs(c) and not os.path.exists(c):
+            continue
+        try:
+            return C.CDLL(c, mode=C.RTLD_GLOBAL)
+        except OSError as e:  # keep looking
+            errs.append(f"{c}: {e}")
+    raise ImportError("no HIP runtime (libamdhip64) found for libllcomp_mi.so: " + "; ".join(errs))
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -42,6 +65,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(or `make -C llcomp_amd/csrc`). llcomp_amd has no CPU fallback.")
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.llcomp_mi_encode.restype = C.c_int
     L.llcomp_mi_encode.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Opts), C.POINTER(u8p), C.POINTER(C.c_size_t)]

@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(mi):
     declared = sorted(set(re.findall(r"\b(llcomp_mi_[a-z_0-9]+)\s*\(", hdr)))
     assert declared, "no declarations found"
     assert sorted(_lib.SYMBOLS) == declared, "llcomp_amd/_lib.py SYMBOLS out of sync with include/llcomp_mi.h"
-    lib = C.CDLL(_lib.LIB_PATH)
+    lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in llcomp_mi.h but not exported by libllcomp_mi.so"
     assert lib.llcomp_mi_abi_version() == 1
