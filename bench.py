@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric: encode+decode MPix/s on 4K RGB8, bit-exact, with achieved HBM GB/s vs peak.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--content g3|g2|mid] [--tile T] [--interleaved]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--content g3|g2|mid] [--tile-w TW --tile-h TH] [--interleaved]
 
 A "step" = one pass of the hot path over one batch: F frames of 3840x2160 RGB8 already resident in HBM are
 encoded into the sliced container payload (k_model_fwd -> k_encode_slices -> scan+pack) and decoded back
@@ -40,7 +40,7 @@ def make_frames(content, frames, rank):
     return out
 
 
-def cpu_baseline(content, tile, planar, budget_s=30.0):
+def cpu_baseline(content, tile_w, tile_h, planar):
     """Time the CPU path on ONE frame of the same workload, single thread.  kind 'reference' = the real
     llcomp.hpp compiled in place (oracle/_ref, whole-image stream: O2 encode + unmodified decompressImage);
     kind 'port' = the plain-C restatement (same sliced container as the GPU produces)."""
@@ -61,7 +61,7 @@ def cpu_baseline(content, tile, planar, budget_s=30.0):
     else:
         orc = orc_mod.Orc()
         t0 = time.perf_counter()
-        s = orc.compress_sliced(img, tile, tile, planar)
+        s = orc.compress_sliced(img, tile_w, tile_h, planar)
         t1 = time.perf_counter()
         rc, px = orc.decompress(s)
         t2 = time.perf_counter()
@@ -77,7 +77,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=8, help="4K frames per step per GPU")
     ap.add_argument("--content", default="g3", choices=["g3", "g2", "mid"])
-    ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--tile-w", type=int, default=64)
+    ap.add_argument("--tile-h", type=int, default=64)
     ap.add_argument("--interleaved", action="store_true", help="channels interleaved in one slice instead of per-channel planes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -103,7 +104,7 @@ def main():
     F = args.frames
     frames_np = make_frames(args.content, F, rank)
     d_px = torch.from_numpy(frames_np).cuda()
-    codec = mi.Codec(F, W4K, H4K, C4K, args.tile, args.tile, planar, device=local_rank)
+    codec = mi.Codec(F, W4K, H4K, C4K, args.tile_w, args.tile_h, planar, device=local_rank)
     raw_bytes = frames_np.size
     cap = min(codec.max_payload_bytes, 2 * raw_bytes + 64 * codec.n_slices + 4096)
     d_pay = torch.empty(cap, dtype=torch.uint8, device="cuda")
@@ -180,9 +181,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"C3 3840x2160 RGB8 {args.content} ({'std::mt19937 noise' if args.content == 'g3' else args.content}), "
-                            f"{F} frames/step/GPU resident in HBM, sliced container: {args.tile}x{args.tile} tiles, "
+                            f"{F} frames/step/GPU resident in HBM, sliced container: {args.tile_w}x{args.tile_h} tiles, "
                             f"{'per-channel planes' if planar else 'channels interleaved'}, {codec.n_slices // F} slices/frame",
-                "frames_per_step_per_gpu": F, "tile": args.tile, "planar": planar, "content": args.content,
+                "frames_per_step_per_gpu": F, "tile_w": args.tile_w, "tile_h": args.tile_h, "planar": planar, "content": args.content,
                 "slices_per_frame": codec.n_slices // F,
                 "compression_ratio": round(world * raw_bytes / (total_all + world * (24 * F + 4 * codec.n_slices)), 4),
                 "parallelism": f"frames sharded over {world} GPU(s), no data-path collective",
@@ -196,7 +197,7 @@ def main():
             "kernel_ms_per_step": {k: round(v / max(1, args.steps), 4) for k, v in prof.items()},
         }
         if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.content, args.tile, planar)
+            res["cpu_baseline"] = cpu_baseline(args.content, args.tile_w, args.tile_h, planar)
             res["speedup_vs_cpu_baseline"] = round(value / res["cpu_baseline"]["value"], 1)
         print(json.dumps(res), flush=True)
     codec.close()

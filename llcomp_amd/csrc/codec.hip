@@ -27,6 +27,7 @@ struct llcomp_mi_codec {
     uint64_t* d_offsets = nullptr;  // u64[n_slices + 1]
     uint64_t* d_total_tmp = nullptr;
     uint64_t workspace_bytes = 0;
+    bool need_states = true;  // false for 1-row slices (states live in registers)
     // optional per-kernel timing (hipEvents on the caller's stream)
     bool profiling = false;
     struct Span { hipEvent_t a, b; int slot; };
@@ -137,7 +138,8 @@ int llcomp_mi_codec_create(llcomp_mi_codec** out, int32_t device, uint32_t frame
     k->g = g;
     k->device = dev;
     const uint64_t samples = uint64_t(frames) * w * h * c;
-    const uint64_t b_sym = samples * 4, b_states = uint64_t(g.n_slices) * kContexts * 8,
+    k->need_states = slices_need_state_tables(g);
+    const uint64_t b_sym = samples * 4, b_states = k->need_states ? uint64_t(g.n_slices) * kContexts * 8 : 8,
                    b_scratch = uint64_t(g.n_slices) * g.slice_cap, b_off = (uint64_t(g.n_slices) + 1) * 8;
     k->workspace_bytes = b_sym + b_states + b_scratch + b_off + 8;
     bool ok = hipMalloc(&k->d_sym_or_rec, b_sym) == hipSuccess &&
@@ -190,7 +192,7 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
     HIP_TRY(hipMemsetAsync(d_status, 0, 4, s));
     {
         Timed t(k, s, 0);
-        HIP_TRY(hipMemsetAsync(k->d_states, 0, uint64_t(g.n_slices) * kContexts * 8, s));
+        if (k->need_states) HIP_TRY(hipMemsetAsync(k->d_states, 0, uint64_t(g.n_slices) * kContexts * 8, s));
     }
     {
         Timed t(k, s, 1);
@@ -222,7 +224,7 @@ int llcomp_mi_codec_decode(llcomp_mi_codec* k, const void* d_payload, uint64_t p
     HIP_TRY(hipMemsetAsync(d_status, 0, 4, s));
     {
         Timed t(k, s, 7);
-        HIP_TRY(hipMemsetAsync(k->d_states, 0, uint64_t(g.n_slices) * kContexts * 8, s));
+        if (k->need_states) HIP_TRY(hipMemsetAsync(k->d_states, 0, uint64_t(g.n_slices) * kContexts * 8, s));
     }
     {
         Timed t(k, s, 4);

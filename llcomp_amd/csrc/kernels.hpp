@@ -1,4 +1,4 @@
-// kernels.hpp -- launchers of the gfx950 kernels (kernels.hip).  All launches are asynchronous on `stream`.
+// kernels.hpp -- launchers of the gfx950 kernels (model_kernels.hip, slice_kernels.hip).  All launches are asynchronous on `stream`.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -11,11 +11,15 @@ namespace llcomp_mi {
 // status word bits written by kernels (atomicOr); mapped to llcomp_mi_status by the host
 enum : uint32_t { kStOverflow = 1u, kStBadExponent = 2u, kStTruncated = 4u };
 
-// Stage A (encode side): pixels u8 [frames][h][w][c] -> per-sample symbols u32 in the same layout:
-// low 16 bits folded context, high 16 bits folded residual.  llcomp.hpp:396-436.
+// Stage A (encode side): pixels u8 [frames][h][w][c] -> per-sample symbols u32, low 16 bits folded context, high
+// 16 bits folded residual (llcomp.hpp:396-436).  Layout [frames][h][w][c] for interleaved slices, plane-major
+// [frames][c][h][w] for planar slices (device_common.hpp), so that a slice row is contiguous.
 hipError_t launch_model_fwd(const Geometry& g, const uint8_t* d_px, uint32_t* d_sym, hipStream_t stream);
 // Stage A (decode side): reconstructed colour-transformed samples int16 -> pixels u8.  llcomp.hpp:532-543.
 hipError_t launch_model_inv(const Geometry& g, const int16_t* d_rec, uint8_t* d_px, hipStream_t stream);
+
+// 1-row slices keep their (three) contexts in registers; only taller slices need the per-slice tables in HBM.
+bool slices_need_state_tables(const Geometry& g);
 
 // One lane per slice: binarisation + adaptive states + range encoder.  llcomp.hpp:33-89, 166-206, 283-293, 439-449.
 //   d_states  : u64[n_slices][kContexts], zeroed by the caller (8 state bytes per context)
@@ -30,7 +34,7 @@ hipError_t launch_pack_payload(const Geometry& g, const uint8_t* d_scratch, cons
                                const uint64_t* d_offsets, uint8_t* d_payload, uint64_t payload_cap,
                                uint32_t* d_status, hipStream_t stream);
 // One lane per slice: range decoder + adaptive states + context model on reconstructed samples.
-// llcomp.hpp:91-127, 219-247, 486-530.  d_rec int16 [frames][h][w][c].
+// llcomp.hpp:91-127, 219-247, 486-530.  d_rec int16, same layout rule as the symbols.
 hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_payload, uint64_t payload_bytes,
                                 const uint32_t* d_slice_len, const uint64_t* d_offsets, uint64_t* d_states,
                                 int16_t* d_rec, uint32_t* d_status, hipStream_t stream);

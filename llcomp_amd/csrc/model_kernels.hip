@@ -1,0 +1,267 @@
+// model_kernels.hip -- the data-parallel kernels of the llcomp coding path (gfx950, wave64).
+//
+//   k_model_fwd   stage A, encode side: colour transform + 6-neighbour context hash + median predictor + residual
+//                 for every sample in parallel.  Coalesced row-major HBM reads, a 4-row LDS ring of
+//                 colour-transformed rows (current + the two above + the row being prefetched).
+//                 Reference: llcomp.hpp:396-436.
+//   k_model_inv   stage A, decode side: inverse colour transform + clamp.  llcomp.hpp:532-543.
+//   k_scan_lengths / k_pack_payload
+//                 wave-prefix-sum of slice lengths and packing of the variable-length streams.
+// None of this is GEMM-shaped; there is no MFMA here on purpose.
+#include <algorithm>
+
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+namespace llcomp_mi {
+
+namespace {
+
+// ---- stage A, encode side -------------------------------------------------------------------------------
+constexpr int kMW = 256;  // pixels per block row segment == threads per block
+constexpr int kMH = 32;   // rows per block (2 halo rows above are re-read: 6% over-fetch)
+
+template <int C>
+__device__ __forceinline__ void rct_forward(const uint8_t* p, int16_t (&o)[C]) {
+    if constexpr (C >= 3) {
+        const int g = p[1], cb = int(p[2]) - g, cr = int(p[0]) - g;
+        o[0] = int16_t(cr);
+        o[1] = int16_t(g + (cb + cr) / 4);  // C++ division truncates toward zero, like llcomp.hpp:402
+        o[2] = int16_t(cb);
+        if constexpr (C == 4) o[3] = p[3];
+    } else {
+#pragma unroll
+        for (int k = 0; k < C; ++k) o[k] = p[k];
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(kMW) void k_model_fwd(const Geometry g, const uint8_t* __restrict__ px,
+                                                   uint32_t* __restrict__ sym) {
+    // ring of 4 colour-transformed rows, planar per channel; column j holds image column bx0 - 2 + j
+    __shared__ int16_t win[4][C][kMW + 4];
+    const uint32_t nbx = (g.w + kMW - 1) / kMW;
+    const uint32_t bx = blockIdx.x % nbx;
+    const uint32_t by = blockIdx.x / nbx;  // strip of kMH rows, never crossing a tile row or frame
+    // row strips are enumerated per (frame, tile row): strips_per_tile_row = ceil(tile_h / kMH)
+    const uint32_t spt = (g.tile_h + kMH - 1) / kMH;
+    const uint32_t trow = by / spt;             // global tile-row index over all frames
+    const uint32_t strip = by - trow * spt;
+    const uint32_t frame = trow / g.nty;
+    const uint32_t ty = trow - frame * g.nty;
+    const uint32_t tile_y0 = ty * g.tile_h;
+    const uint32_t tile_rows = g.h - tile_y0 < g.tile_h ? g.h - tile_y0 : g.tile_h;
+    const uint32_t ly0 = strip * kMH;
+    if (ly0 >= tile_rows) return;  // uniform per block
+    const uint32_t ly1 = ly0 + kMH < tile_rows ? ly0 + kMH : tile_rows;
+
+    const uint32_t t = threadIdx.x;
+    const uint32_t bx0 = bx * kMW;
+    const uint32_t x = bx0 + t;
+    const bool in_x = x < g.w;
+    const uint32_t tx = (in_x ? x : g.w - 1) / g.tile_w;
+    const uint32_t lx = (in_x ? x : g.w - 1) - tx * g.tile_w;
+    const uint32_t sw = g.w - tx * g.tile_w < g.tile_w ? g.w - tx * g.tile_w : g.tile_w;
+
+    const size_t row_bytes = size_t(g.w) * C;
+    const uint8_t* fbase = px + size_t(frame) * g.h * row_bytes;
+
+    // loader: thread t stages column bx0-2+t ... plus 4 extra columns by threads 0..3 (kMW+4 columns total)
+    auto stage_row = [&](int ly, int16_t (&a)[C], int16_t (&b)[C]) {
+        // ly may be negative (rows above the tile are never used by the border rules): stage zeros
+        const bool row_ok = ly >= 0;
+        const uint8_t* rowp = fbase + size_t(tile_y0 + (row_ok ? ly : 0)) * row_bytes;
+        const int xa = int(bx0) - 2 + int(t);
+#pragma unroll
+        for (int k = 0; k < C; ++k) a[k] = b[k] = 0;
+        if (row_ok && xa >= 0 && xa < int(g.w)) rct_forward<C>(rowp + size_t(xa) * C, a);
+        if (t < 4) {
+            const int xb = int(bx0) - 2 + kMW + int(t);
+            if (row_ok && xb < int(g.w)) rct_forward<C>(rowp + size_t(xb) * C, b);
+        }
+    };
+    auto commit_row = [&](int slot, const int16_t (&a)[C], const int16_t (&b)[C]) {
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            win[slot][k][t] = a[k];
+            if (t < 4) win[slot][k][kMW + t] = b[k];
+        }
+    };
+
+    int16_t ra[C], rb[C];
+    // prologue: rows ly0-2, ly0-1, ly0 into slots (ly & 3)
+    for (int ly = int(ly0) - 2; ly <= int(ly0); ++ly) {
+        stage_row(ly, ra, rb);
+        commit_row(ly & 3, ra, rb);
+    }
+    __syncthreads();
+    for (uint32_t ly = ly0; ly < ly1; ++ly) {
+        const bool more = ly + 1 < ly1;
+        if (more) stage_row(int(ly) + 1, ra, rb);  // global loads in flight while this row is modelled
+        if (in_x) {
+            const int s0 = ly & 3, s1 = (ly + 3) & 3, s2 = (ly + 2) & 3;
+            uint32_t out[C];
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const int cur = win[s0][k][t + 2];
+                const Hood n = apply_borders(win[s0][k][t + 1], win[s0][k][t], win[s1][k][t + 2], win[s1][k][t + 1],
+                                             win[s1][k][t + 3], win[s2][k][t + 2], lx, ly, sw);
+                int ctx = context_hash(n);
+                int res = cur - predict(n);
+                if (ctx < 0) {  // llcomp.hpp:433-436
+                    ctx = -ctx;
+                    res = -res;
+                }
+                out[k] = uint32_t(ctx) | (uint32_t(res) << 16);
+            }
+            if (g.planar) {  // plane-major: every plane row is written as full coalesced dword rows
+#pragma unroll
+                for (int k = 0; k < C; ++k) sym[sample_index(g, frame, tile_y0 + ly, x, k)] = out[k];
+            } else {
+                uint32_t* o = sym + sample_index(g, frame, tile_y0 + ly, x, 0);
+#pragma unroll
+                for (int k = 0; k < C; ++k) o[k] = out[k];
+            }
+        }
+        if (more) commit_row((ly + 1) & 3, ra, rb);  // slot (ly+1)&3 == (ly-3)&3: not read this iteration
+        __syncthreads();
+    }
+}
+
+// ---- stage A, decode side -------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void k_model_inv(const Geometry g, const int16_t* __restrict__ rec,
+                                                   uint8_t* __restrict__ px, size_t npix) {
+    const size_t plane = size_t(g.h) * g.w;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < npix; i += size_t(gridDim.x) * blockDim.x) {
+        int16_t s[C];
+        if (g.planar) {
+            const size_t f = i / plane, p = i - f * plane;
+#pragma unroll
+            for (int k = 0; k < C; ++k) s[k] = rec[(f * C + k) * plane + p];
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; ++k) s[k] = rec[i * C + k];
+        }
+        uint8_t* o = px + i * C;
+        if constexpr (C >= 3) {
+            int r = s[0], gg = s[1], b = s[2];
+            gg -= (r + b) / 4;
+            r += gg;
+            b += gg;
+            o[0] = uint8_t(min(max(r, 0), 255));
+            o[1] = uint8_t(min(max(gg, 0), 255));
+            o[2] = uint8_t(min(max(b, 0), 255));
+            if constexpr (C == 4) o[3] = uint8_t(s[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; ++k) o[k] = uint8_t(s[k]);
+        }
+    }
+}
+
+// ---- slice length scan + payload packing -------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_lengths(const uint32_t* __restrict__ len, uint32_t n,
+                                                       uint64_t* __restrict__ off, uint64_t* total) {
+    __shared__ unsigned long long wave_sum[16];
+    __shared__ unsigned long long carry;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const unsigned long long v = i < n ? len[i] : 0;
+        unsigned long long inc = v;  // wave-inclusive prefix sum, 64 lanes
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = __shfl_up(inc, d, 64);
+            if (lane >= uint32_t(d)) inc += o;
+        }
+        if (lane == 63) wave_sum[wv] = inc;
+        __syncthreads();
+        unsigned long long before = carry;
+        for (uint32_t k = 0; k < wv; ++k) before += wave_sum[k];
+        if (i < n) off[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        off[n] = carry;
+        *total = carry;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pack_payload(const Geometry g, const uint8_t* __restrict__ scratch,
+                                                      const uint32_t* __restrict__ slice_len,
+                                                      const uint64_t* __restrict__ off, uint8_t* __restrict__ payload,
+                                                      uint64_t payload_cap, uint32_t* status) {
+    for (uint32_t id = blockIdx.x; id < g.n_slices; id += gridDim.x) {
+        const uint32_t n = slice_len[id];
+        const uint64_t o = off[id];
+        if (o + n > payload_cap) {
+            if (threadIdx.x == 0) atomicOr(status, kStOverflow);
+            continue;
+        }
+        const uint8_t* src = scratch + size_t(id) * g.slice_cap;  // 16-byte aligned
+        uint8_t* dst = payload + o;
+        // head: bytes up to the first 4-byte boundary of dst
+        const uint32_t head = min(n, uint32_t((4 - (uintptr_t(dst) & 3)) & 3));
+        if (threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+        const uint32_t words = (n - head) >> 2;
+        const uint32_t m = head & 3;  // misalignment of src + head
+        const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src + head - m);
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + head);
+        for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) {
+            const uint32_t lo = s32[i];
+            const uint32_t hi = m ? s32[i + 1] : 0;  // stays inside the slice's scratch (cap has 16 B slack)
+            d32[i] = __builtin_amdgcn_alignbyte(hi, lo, m);
+        }
+        const uint32_t done = head + (words << 2);
+        if (threadIdx.x < n - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
+    }
+}
+
+}  // namespace
+
+#define LLMI_DISPATCH_C(c, CALL) \
+    switch (c) {                 \
+        case 1: { constexpr int C = 1; CALL; } break; \
+        case 2: { constexpr int C = 2; CALL; } break; \
+        case 3: { constexpr int C = 3; CALL; } break; \
+        case 4: { constexpr int C = 4; CALL; } break; \
+        default: return hipErrorInvalidValue; \
+    }
+
+hipError_t launch_model_fwd(const Geometry& g, const uint8_t* d_px, uint32_t* d_sym, hipStream_t stream) {
+    const uint32_t nbx = (g.w + kMW - 1) / kMW;
+    const uint32_t spt = (g.tile_h + kMH - 1) / kMH;
+    const uint64_t blocks = uint64_t(nbx) * spt * g.nty * g.frames;
+    if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    LLMI_DISPATCH_C(g.c, (k_model_fwd<C><<<dim3(uint32_t(blocks)), dim3(kMW), 0, stream>>>(g, d_px, d_sym)));
+    return hipGetLastError();
+}
+
+hipError_t launch_model_inv(const Geometry& g, const int16_t* d_rec, uint8_t* d_px, hipStream_t stream) {
+    const size_t npix = size_t(g.frames) * g.h * g.w;
+    const uint32_t blocks = uint32_t(std::min<size_t>((npix + 255) / 256, 256 * 16));
+    LLMI_DISPATCH_C(g.c, (k_model_inv<C><<<dim3(blocks), dim3(256), 0, stream>>>(g, d_rec, d_px, npix)));
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_lengths(const uint32_t* d_slice_len, uint32_t n, uint64_t* d_offsets, uint64_t* d_total,
+                               hipStream_t stream) {
+    k_scan_lengths<<<dim3(1), dim3(1024), 0, stream>>>(d_slice_len, n, d_offsets, d_total);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_payload(const Geometry& g, const uint8_t* d_scratch, const uint32_t* d_slice_len,
+                               const uint64_t* d_offsets, uint8_t* d_payload, uint64_t payload_cap,
+                               uint32_t* d_status, hipStream_t stream) {
+    const uint32_t blocks = std::min<uint32_t>(g.n_slices, 256 * 32);
+    k_pack_payload<<<dim3(blocks), dim3(256), 0, stream>>>(g, d_scratch, d_slice_len, d_offsets, d_payload,
+                                                           payload_cap, d_status);
+    return hipGetLastError();
+}
+
+}  // namespace llcomp_mi

@@ -1,0 +1,588 @@
+// slice_kernels.hip -- the serial part of the llcomp coding path on gfx950: binarisation, the adaptive 128-state
+// binary models and the 16-bit carry-propagating range coder (llcomp.hpp:33-127, 166-247, 283-293, 439-449,
+// 486-530), one LANE per slice, 1..64 independent slices per wavefront, all lanes in lockstep per coding phase.
+//
+// What shapes the code (measured with rocprofv3 SQ counters, profiles/):
+//   * a lone wavefront issues one instruction every ~4.4 cycles, so the cost of a bin is its INSTRUCTION COUNT;
+//     the renormalisation of the decoder is branch-free, its input bytes come from a 64-bit register window that
+//     is topped up once per sample, the encoder's output bytes go to a small per-lane LDS ring that is flushed
+//     16 bytes at a time;
+//   * the model table lives in LDS as 8-byte entries {P, next0, next1, P(next0), P(next1)}: the 8 entries of a
+//     context are requested together when the context is known, and inside a run of bins on one slot (unary
+//     exponent tail, mantissa tail) the next probability is already in registers while the successor's entry is
+//     still on its way, so LDS latency stays off the range-coder recurrence;
+//   * 1-row slices (tile_h == 1) can only ever reach 3 contexts (llcomp.hpp:417-429 with h == 0: hash =
+//     605*quant5(L-l)), so their 24 state bytes stay in registers and the kernel touches no state memory at all;
+//     taller slices keep a private 63 KB table (u64 per context) in HBM, fetched one context per sample.
+#include <algorithm>
+#include <cstdlib>
+
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+namespace llcomp_mi {
+
+namespace {
+
+// ---- model table ------------------------------------------------------------------------------------------------
+// entry = packed_state | packed_successors << 32, always moved as ONE 64-bit LDS access
+using entry_t = unsigned long long;
+struct EntryTable {
+    entry_t v[128];
+};
+constexpr EntryTable make_entries() {
+    EntryTable t{};
+    for (uint32_t s = 0; s < 128; ++s) t.v[s] = entry_t(packed_state(s)) | (entry_t(packed_successors(s)) << 32);
+    return t;
+}
+__constant__ EntryTable c_entries = make_entries();
+
+__device__ __forceinline__ void load_table(entry_t* tab) {
+    for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x) tab[i] = c_entries.v[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ uint32_t byte_of(uint32_t w, int k) { return (w >> (8 * k)) & 0xFF; }
+template <int SLOT>
+__device__ __forceinline__ uint32_t slot_state(const uint32_t (&bank)[2]) {
+    return byte_of(bank[SLOT >> 2], SLOT & 3);
+}
+template <int SLOT>
+__device__ __forceinline__ void set_slot_state(uint32_t (&bank)[2], uint32_t ns) {
+    constexpr int W = SLOT >> 2, SH = (SLOT & 3) * 8;
+    bank[W] = (bank[W] & ~(0xFFu << SH)) | (ns << SH);
+}
+// successor state / successor probability of entry e for the coded bit
+__device__ __forceinline__ uint32_t prob_of(entry_t e) { return uint32_t(e) & 0xFF; }
+__device__ __forceinline__ uint32_t next_state(entry_t e, bool bit) { return bit ? byte_of(uint32_t(e), 2) : byte_of(uint32_t(e), 1); }
+__device__ __forceinline__ uint32_t next_prob(entry_t e, bool bit) { return bit ? byte_of(uint32_t(e >> 32), 1) : byte_of(uint32_t(e >> 32), 0); }
+
+// The 8 entries of one context.  `all` = request slots 1..7 together with slot 0 (worth it when most residuals
+// are non-zero); otherwise they are requested after the zero flag turned out 0.
+struct Entries {
+    entry_t e0, e1, e2, e3, e4, e5, e6, e7;
+    template <int SLOT>
+    __device__ __forceinline__ entry_t get() const {
+        if constexpr (SLOT == 0) return e0;
+        else if constexpr (SLOT == 1) return e1;
+        else if constexpr (SLOT == 2) return e2;
+        else if constexpr (SLOT == 3) return e3;
+        else if constexpr (SLOT == 4) return e4;
+        else if constexpr (SLOT == 5) return e5;
+        else if constexpr (SLOT == 6) return e6;
+        else return e7;
+    }
+};
+__device__ __forceinline__ void fetch_slot0(Entries& E, const uint32_t (&bank)[2], const entry_t* tab) {
+    E.e0 = tab[slot_state<0>(bank)];
+}
+__device__ __forceinline__ void fetch_rest(Entries& E, const uint32_t (&bank)[2], const entry_t* tab) {
+    E.e1 = tab[slot_state<1>(bank)];
+    E.e2 = tab[slot_state<2>(bank)];
+    E.e3 = tab[slot_state<3>(bank)];
+    E.e4 = tab[slot_state<4>(bank)];
+    E.e5 = tab[slot_state<5>(bank)];
+    E.e6 = tab[slot_state<6>(bank)];
+    E.e7 = tab[slot_state<7>(bank)];
+}
+
+// ================================================ ENCODER ========================================================
+// Range encoder of one lane (llcomp.hpp:33-89).  Output bytes are staged in a per-lane LDS ring of 8 dwords laid out
+// [row][lane] (conflict-free) and leave for HBM as aligned 16-byte stores.  `pos` starts at -1: the reference holds
+// its first byte back without emitting (held == -1); here a dummy byte is "emitted" to position -1 instead, which
+// is the same thing without the special case.
+struct RangeEnc {
+    uint32_t low, range, held, pend;
+    int32_t pos;      // bytes produced so far
+    int32_t flushed;  // bytes already stored to HBM (multiple of 16)
+    uint8_t* ring;    // this lane's first ring byte in LDS (row r is at ring + 256 * r)
+    uint8_t* out;     // slice scratch in HBM, 16-byte aligned
+    int32_t cap;
+};
+__device__ __forceinline__ void enc_flush16(RangeEnc& e) {
+    const uint32_t r = (uint32_t(e.flushed) >> 2) & 7;  // 0 or 4
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(e.ring + 256 * r);
+    uint4 v;
+    v.x = row[0]; v.y = row[64]; v.z = row[128]; v.w = row[192];
+    if (e.flushed + 16 <= e.cap) *reinterpret_cast<uint4*>(e.out + e.flushed) = v;
+    e.flushed += 16;
+}
+__device__ __forceinline__ void enc_emit(RangeEnc& e, uint32_t b) {
+    const uint32_t p = uint32_t(e.pos);
+    e.ring[((p >> 2) & 7) * 256 + (p & 3)] = uint8_t(b);
+    ++e.pos;
+}
+// one renormalisation step (body of the reference's `while (range < 0x100)`: one step always suffices because
+// range >= 7 after put() and == 0xFF in finish())
+__device__ __forceinline__ void enc_shift(RangeEnc& e) {
+    const uint32_t carry = e.low >> 16;               // low >= 0x10000
+    if (e.low - 0xFF01u < 0xFFu) {                    // 0xFF00 < low < 0x10000: undecided byte
+        ++e.pend;
+    } else {
+        enc_emit(e, e.held + carry);
+        if (__builtin_expect(e.pend != 0, 0)) {
+            const uint32_t fill = carry ? 0x00u : 0xFFu;
+            for (; e.pend; --e.pend) {
+                if (e.pos - e.flushed >= 16) enc_flush16(e);
+                enc_emit(e, fill);
+            }
+        }
+        e.held = (e.low >> 8) & 0xFF;
+    }
+    e.low = (e.low & 0xFF) << 8;
+    e.range <<= 8;
+}
+__device__ __forceinline__ void enc_core(RangeEnc& e, uint32_t P, bool bit) {  // llcomp.hpp:60-73
+    const uint32_t r1 = __umul24(e.range, P) >> 8;
+    const uint32_t r0 = e.range - r1;
+    e.low += bit ? r0 : 0u;
+    e.range = bit ? r1 : r0;
+    if (e.range < 0x100) enc_shift(e);
+}
+// a slot that is coded at most once per sample
+template <int SLOT>
+__device__ __forceinline__ void enc_once(RangeEnc& e, uint32_t (&bank)[2], const Entries& E, bool bit) {
+    enc_core(e, prob_of(E.get<SLOT>()), bit);
+    set_slot_state<SLOT>(bank, next_state(E.get<SLOT>(), bit));
+}
+
+// putSymbol<true,4,6,7> (llcomp.hpp:166-206).  All lanes walk the phases together, so the slot of every bin is a
+// compile-time constant.
+template <bool ALL>
+__device__ __forceinline__ void enc_residual(RangeEnc& e, uint32_t (&bank)[2], const entry_t* tab, int res) {
+    Entries E;
+    fetch_slot0(E, bank, tab);
+    if (ALL) fetch_rest(E, bank, tab);
+    enc_once<0>(e, bank, E, res == 0);
+    if (res != 0) {
+        if (!ALL) fetch_rest(E, bank, tab);
+        const uint32_t a = uint32_t(res < 0 ? -res : res);
+        const int ex = 31 - __clz(int(a));
+        enc_once<1>(e, bank, E, ex > 0);
+        if (ex > 0) {
+            enc_once<2>(e, bank, E, ex > 1);
+            if (ex > 1) {
+                enc_once<3>(e, bank, E, ex > 2);
+                if (ex > 2) {  // unary tail on slot 4
+                    entry_t cur = E.e4;
+                    uint32_t P = prob_of(cur), ns;
+                    int i = 3;
+                    bool b;
+                    do {
+                        b = ex > i;
+                        enc_core(e, P, b);
+                        ns = next_state(cur, b);
+                        P = next_prob(cur, b);
+                        cur = tab[ns];
+                        ++i;
+                    } while (b);
+                    set_slot_state<4>(bank, ns);
+                }
+            }
+            enc_once<5>(e, bank, E, (a >> (ex - 1)) & 1);
+            if (ex > 1) {  // mantissa tail on slot 6
+                entry_t cur = E.e6;
+                uint32_t P = prob_of(cur), ns;
+                int i = ex - 2;
+                do {
+                    const bool b = (a >> i) & 1;
+                    enc_core(e, P, b);
+                    ns = next_state(cur, b);
+                    P = next_prob(cur, b);
+                    cur = tab[ns];
+                } while (--i >= 0);
+                set_slot_state<6>(bank, ns);
+            }
+        }
+        enc_once<7>(e, bank, E, res < 0);
+    }
+}
+
+__device__ __forceinline__ void enc_finish(RangeEnc& e) {  // llcomp.hpp:75-81
+    e.range = 0xFF; e.low += 0xFF; enc_shift(e);
+    e.range = 0xFF; enc_shift(e);
+    while (e.pos - e.flushed > 0) enc_flush16(e);  // tail: whole 16-byte groups, the slack is scratch
+}
+
+// Lane-per-slice encoder.  ROWS: every slice is one row high (register-resident states).  `lpw` = slices per
+// wavefront (1..64).
+template <int NCH, bool ROWS>
+__global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const uint32_t lpw,
+                                                      const uint32_t* __restrict__ sym, uint64_t* __restrict__ states,
+                                                      uint8_t* __restrict__ scratch, uint32_t* __restrict__ slice_len,
+                                                      uint32_t* status) {
+    __shared__ entry_t tab[128];
+    __shared__ uint32_t ring[8 * 64];
+    load_table(tab);
+    const uint32_t id = blockIdx.x * lpw + threadIdx.x;
+    if (threadIdx.x >= lpw || id >= g.n_slices) return;
+    const SliceRect r = slice_rect(g, id);
+    RangeEnc e;
+    e.low = 0; e.range = 0xFF00; e.held = 0; e.pend = 0;  // llcomp.hpp:35 (held: see RangeEnc)
+    e.pos = -1; e.flushed = 0;
+    e.ring = reinterpret_cast<uint8_t*>(ring + threadIdx.x);
+    e.out = scratch + size_t(id) * g.slice_cap;
+    e.cap = int32_t(g.slice_cap);
+    const size_t row_stride = slice_row_stride(g);
+    const uint32_t n_row = r.sw * NCH;  // samples per slice row (contiguous)
+    const uint32_t* p0 = sym + slice_origin(g, r);
+    const uint32_t total = n_row * r.sh;
+    bool hot = false;  // wave-uniform: most lanes had a non-zero residual last time
+
+    if constexpr (ROWS) {
+        // contexts 0 / 605 / 1210 only: three banks in registers
+        uint32_t B[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+        uint32_t s0 = p0[0];
+        uint32_t s1 = total > 1 ? p0[1] : 0;
+        for (uint32_t i = 0; i < total; ++i) {
+            const uint32_t s2 = i + 2 < total ? p0[i + 2] : 0;
+            const uint32_t ctx = s0 & 0xFFFF;
+            const int res = int(s0) >> 16;
+            const bool c1 = ctx == 605, c2 = ctx > 605;
+            uint32_t bank[2] = {c2 ? B[2][0] : c1 ? B[1][0] : B[0][0], c2 ? B[2][1] : c1 ? B[1][1] : B[0][1]};
+            if (hot) enc_residual<true>(e, bank, tab, res); else enc_residual<false>(e, bank, tab, res);
+            hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(res != 0)) >= __popcll(__ballot(true)));
+            const bool c0 = !(c1 || c2);  // branch-free write-back (six v_cndmask)
+            B[0][0] = c0 ? bank[0] : B[0][0]; B[0][1] = c0 ? bank[1] : B[0][1];
+            B[1][0] = c1 ? bank[0] : B[1][0]; B[1][1] = c1 ? bank[1] : B[1][1];
+            B[2][0] = c2 ? bank[0] : B[2][0]; B[2][1] = c2 ? bank[1] : B[2][1];
+            if (e.pos - e.flushed >= 16) enc_flush16(e);
+            s0 = s1;
+            s1 = s2;
+        }
+    } else {
+        // Everything the coder needs is known up front: the symbol two samples ahead and the state bank one sample
+        // ahead are in flight while a sample is coded (forwarded when consecutive samples share a context).
+        uint64_t* banks = states + size_t(id) * kContexts;
+        uint32_t fx = 0;
+        const uint32_t* frow = p0;
+        auto fetch = [&]() -> uint32_t {
+            const uint32_t v = frow[fx];
+            if (++fx == n_row) { fx = 0; frow += row_stride; }
+            return v;
+        };
+        uint32_t s0 = fetch();
+        uint32_t s1 = total > 1 ? fetch() : 0;
+        uint64_t b0 = banks[s0 & 0xFFFF];
+        for (uint32_t i = 0; i < total; ++i) {
+            const uint32_t s2 = i + 2 < total ? fetch() : 0;
+            const uint32_t ctx0 = s0 & 0xFFFF, ctx1 = s1 & 0xFFFF;
+            const int res = int(s0) >> 16;
+            uint64_t b1 = (i + 1 < total) ? banks[ctx1] : 0;
+            uint32_t bank[2] = {uint32_t(b0), uint32_t(b0 >> 32)};
+            if (hot) enc_residual<true>(e, bank, tab, res); else enc_residual<false>(e, bank, tab, res);
+            hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(res != 0)) >= __popcll(__ballot(true)));
+            b0 = uint64_t(bank[0]) | (uint64_t(bank[1]) << 32);
+            banks[ctx0] = b0;
+            if (ctx1 == ctx0) b1 = b0;  // the prefetched copy is stale: forward
+            b0 = b1;
+            if (e.pos - e.flushed >= 16) enc_flush16(e);
+            s0 = s1;
+            s1 = s2;
+        }
+    }
+    enc_finish(e);
+    if (e.pos > e.cap) {
+        atomicOr(status, kStOverflow);
+        e.pos = e.cap;
+    }
+    slice_len[id] = uint32_t(e.pos);
+}
+
+// ================================================ DECODER ========================================================
+// Range decoder of one lane (llcomp.hpp:91-127).  The stream is consumed through a 64-bit register window (next byte
+// = window & 0xFF) that is topped up with aligned dword loads, one dword prefetched ahead; bytes past the end of the
+// slice read as 0 (llcomp.hpp:475-479).
+struct RangeDec {
+    uint32_t low, range;
+    uint32_t wlo, whi;      // window, LSB first; bits above `nb` bytes are zero
+    int32_t nb;             // valid bytes in the window
+    uint32_t nxt;           // prefetched dword that follows the window
+    const uint32_t* words;  // aligned base: word k holds stream bytes [4k - skew, 4k - skew + 4)
+    uint32_t end;           // len + skew (0 when the slice is empty)
+    uint32_t kn;            // next word to prefetch
+};
+__device__ __forceinline__ uint32_t dec_word(const RangeDec& d, uint32_t k) {
+    const uint32_t first = k * 4;
+    if (first >= d.end) return 0;
+    uint32_t w = d.words[k];
+    const uint32_t nvalid = d.end - first;  // >= 1
+    if (nvalid < 4) w &= (1u << (8 * nvalid)) - 1;
+    return w;
+}
+__device__ __forceinline__ void dec_append(RangeDec& d) {  // requires nb <= 4
+    const uint64_t w = (uint64_t(d.nxt) << (8 * d.nb)) | (uint64_t(d.whi) << 32) | d.wlo;
+    d.wlo = uint32_t(w);
+    d.whi = uint32_t(w >> 32);
+    d.nb += 4;
+    d.nxt = dec_word(d, d.kn++);
+}
+__device__ __forceinline__ void dec_open(RangeDec& d, const uint8_t* p, uint32_t len) {
+    const uint32_t skew = uint32_t(uintptr_t(p) & 3);
+    d.words = reinterpret_cast<const uint32_t*>(p - skew);
+    d.end = len ? len + skew : 0;
+    d.wlo = dec_word(d, 0) >> (8 * skew);
+    d.whi = 0;
+    d.nb = int32_t(4 - skew);
+    d.nxt = dec_word(d, 1);
+    d.kn = 2;
+    dec_append(d);
+    d.range = 0xFF00;  // llcomp.hpp:93-96: low = first two bytes
+    d.low = ((d.wlo & 0xFF) << 8) | ((d.wlo >> 8) & 0xFF);
+    d.wlo = __builtin_amdgcn_alignbit(d.whi, d.wlo, 16);
+    d.whi >>= 16;
+    d.nb -= 2;
+}
+__device__ __forceinline__ bool dec_core(RangeDec& d, uint32_t P) {  // llcomp.hpp:98-121, branch-free refill
+    if (__builtin_expect(d.nb <= 0, 0)) dec_append(d);
+    const uint32_t r1 = __umul24(d.range, P) >> 8;
+    const uint32_t r0 = d.range - r1;
+    const bool bit = d.low >= r0;
+    d.low = min(d.low, d.low - r0);  // unsigned: low - r0 wraps above low exactly when low < r0
+    d.range = bit ? r1 : r0;
+    const bool need = d.range < 0x100;
+    const uint32_t sh = need ? 8u : 0u;
+    d.range <<= sh;
+    d.low = (d.low << sh) | (d.wlo & (need ? 0xFFu : 0u));
+    d.wlo = __builtin_amdgcn_alignbit(d.whi, d.wlo, sh);
+    d.whi >>= sh;
+    d.nb -= need ? 1 : 0;
+    return bit;
+}
+template <int SLOT>
+__device__ __forceinline__ bool dec_once(RangeDec& d, uint32_t (&bank)[2], const Entries& E) {
+    const bool bit = dec_core(d, prob_of(E.get<SLOT>()));
+    set_slot_state<SLOT>(bank, next_state(E.get<SLOT>(), bit));
+    return bit;
+}
+// getSymbol<true,4,6,7> (llcomp.hpp:219-247).  Returns false on "Invalid exponent".  Arithmetic modulo 2^32.
+template <bool ALL>
+__device__ __forceinline__ bool dec_residual(RangeDec& d, uint32_t (&bank)[2], const entry_t* tab, uint32_t& out) {
+    Entries E;
+    fetch_slot0(E, bank, tab);
+    if (ALL) fetch_rest(E, bank, tab);
+    if (dec_once<0>(d, bank, E)) {
+        out = 0;
+        return true;
+    }
+    if (!ALL) fetch_rest(E, bank, tab);
+    int ex = 0;
+    bool ok = true;
+    if (dec_once<1>(d, bank, E)) {
+        ex = 1;
+        if (dec_once<2>(d, bank, E)) {
+            ex = 2;
+            if (dec_once<3>(d, bank, E)) {
+                ex = 3;
+                entry_t cur = E.e4;
+                uint32_t P = prob_of(cur), ns;
+                bool b;
+                do {
+                    b = dec_core(d, P);
+                    ns = next_state(cur, b);
+                    P = next_prob(cur, b);
+                    cur = tab[ns];
+                    ex += b ? 1 : 0;
+                    if (ex > 31) { ok = false; b = false; }
+                } while (b);
+                set_slot_state<4>(bank, ns);
+            }
+        }
+    }
+    if (!ok) return false;
+    uint32_t v = 1;
+    if (ex > 0) {
+        v += v + uint32_t(dec_once<5>(d, bank, E));
+        if (ex > 1) {
+            entry_t cur = E.e6;
+            uint32_t P = prob_of(cur), ns;
+            int j = ex - 1;
+            do {
+                const bool b = dec_core(d, P);
+                ns = next_state(cur, b);
+                P = next_prob(cur, b);
+                cur = tab[ns];
+                v += v + uint32_t(b);
+            } while (--j > 0);
+            set_slot_state<6>(bank, ns);
+        }
+    }
+    if (dec_once<7>(d, bank, E)) v = 0u - v;
+    out = v;
+    return true;
+}
+
+template <int NCH, bool ROWS>
+__global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const uint32_t lpw,
+                                                      const uint8_t* __restrict__ payload,
+                                                      const uint64_t payload_bytes,
+                                                      const uint32_t* __restrict__ slice_len,
+                                                      const uint64_t* __restrict__ offsets,
+                                                      uint64_t* __restrict__ states, int16_t* __restrict__ rec,
+                                                      uint32_t* status) {
+    __shared__ entry_t tab[128];
+    load_table(tab);
+    const uint32_t id = blockIdx.x * lpw + threadIdx.x;
+    if (threadIdx.x >= lpw || id >= g.n_slices) return;
+    const SliceRect r = slice_rect(g, id);
+    RangeDec d;
+    const uint64_t off = offsets[id];
+    uint64_t len = slice_len[id];
+    if (off + len > payload_bytes) {  // slice table promises more than the data holds
+        atomicOr(status, kStTruncated);
+        len = off < payload_bytes ? payload_bytes - off : 0;
+    }
+    dec_open(d, payload + (off < payload_bytes ? off : 0), uint32_t(len));
+
+    const ptrdiff_t rs = ptrdiff_t(slice_row_stride(g));  // row stride in samples; samples of a row are contiguous
+    int16_t* p0 = rec + slice_origin(g, r);
+    bool hot = false;
+
+    if constexpr (ROWS) {
+        // one-row slice (llcomp.hpp:494-509 with h == 0): l = left (128 at the start), everything above = l, so
+        // hash = 605*quant5(L - l), prediction = l.  Three banks in registers, no state memory.
+        uint32_t B[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+        int l[NCH], L[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) l[k] = L[k] = 128;
+        for (uint32_t x = 0; x < r.sw; ++x) {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                if (d.nb <= 4) dec_append(d);
+                const int lv = l[k];                 // x == 0: 128
+                const int Lv = x > 1 ? L[k] : lv;    // llcomp.hpp:496
+                const int dq = Lv - lv;
+                const uint32_t aq = uint32_t(dq < 0 ? -dq : dq);
+                const bool neg = dq < 0;               // hash = 605*quant5(L-l) < 0
+                const bool c2 = aq > 3, c1 = aq > 0 && !c2;  // |quant5| == 2 / == 1
+                uint32_t bank[2] = {c2 ? B[2][0] : c1 ? B[1][0] : B[0][0], c2 ? B[2][1] : c1 ? B[1][1] : B[0][1]};
+                uint32_t v;
+                const bool ok = hot ? dec_residual<true>(d, bank, tab, v) : dec_residual<false>(d, bank, tab, v);
+                if (!ok) {
+                    atomicOr(status, kStBadExponent);
+                    return;
+                }
+                hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true)));
+                const bool c0 = !(c1 || c2);  // branch-free write-back (six v_cndmask)
+                B[0][0] = c0 ? bank[0] : B[0][0]; B[0][1] = c0 ? bank[1] : B[0][1];
+                B[1][0] = c1 ? bank[0] : B[1][0]; B[1][1] = c1 ? bank[1] : B[1][1];
+                B[2][0] = c2 ? bank[0] : B[2][0]; B[2][1] = c2 ? bank[1] : B[2][1];
+                if (neg) v = 0u - v;
+                const int val = int(int16_t(uint32_t(lv) + v));
+                p0[ptrdiff_t(x) * NCH + k] = int16_t(val);
+                L[k] = lv;
+                l[k] = val;
+            }
+        }
+    } else {
+        // Neighbours of the row above rotate through registers (tl <- t <- tr); the two values the NEXT pixel needs
+        // from memory (top-right, top-top) are loaded while the current one decodes.
+        uint64_t* banks = states + size_t(id) * kContexts;
+        for (uint32_t y = 0; y < r.sh; ++y) {
+            int16_t* row = p0 + ptrdiff_t(y) * rs;
+            int l[NCH], L[NCH], t[NCH], tl[NCH], tr[NCH], T[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                l[k] = L[k] = tl[k] = 0;
+                t[k] = y > 0 ? row[k - rs] : 0;
+                tr[k] = (y > 0 && r.sw > 1) ? row[k - rs + NCH] : 0;
+                T[k] = y > 1 ? row[k - 2 * rs] : 0;
+            }
+            for (uint32_t x = 0; x < r.sw; ++x) {
+                int16_t* q = row + ptrdiff_t(x) * NCH;
+                int tr_n[NCH], T_n[NCH];
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    tr_n[k] = (y > 0 && x + 2 < r.sw) ? q[k - rs + 2 * NCH] : 0;
+                    T_n[k] = (y > 1 && x + 1 < r.sw) ? q[k - 2 * rs + NCH] : 0;
+                }
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    if (d.nb <= 4) dec_append(d);
+                    const Hood n = apply_borders(l[k], L[k], t[k], tl[k], tr[k], T[k], x, y, r.sw);
+                    int ctx = context_hash(n);
+                    const bool neg = ctx < 0;  // llcomp.hpp:511-515
+                    if (neg) ctx = -ctx;
+                    const uint64_t b64 = banks[ctx];
+                    uint32_t bank[2] = {uint32_t(b64), uint32_t(b64 >> 32)};
+                    uint32_t v;
+                    const bool ok = hot ? dec_residual<true>(d, bank, tab, v) : dec_residual<false>(d, bank, tab, v);
+                    if (!ok) {
+                        atomicOr(status, kStBadExponent);
+                        return;  // this lane's slice is unusable; the whole call reports the error
+                    }
+                    hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true)));
+                    banks[ctx] = uint64_t(bank[0]) | (uint64_t(bank[1]) << 32);
+                    if (neg) v = 0u - v;
+                    const int val = int(int16_t(uint32_t(predict(n)) + v));
+                    q[k] = int16_t(val);
+                    L[k] = l[k];
+                    l[k] = val;
+                    tl[k] = t[k];
+                    t[k] = tr[k];
+                    tr[k] = tr_n[k];
+                    T[k] = T_n[k];
+                }
+            }
+        }
+    }
+}
+
+// Slices per wavefront.  A slice is one serial chain, so with few slices the best use of the chip is one chain per
+// SIMD (256 CUs x 4 SIMDs): spread them over ~kTargetWaves wavefronts with few active lanes each; only once there
+// are more slices than that do wavefronts fill up to 64 lanes.  LLCOMP_MI_LPW overrides (tuning / tests).
+uint32_t lanes_per_wave(uint32_t n_slices) {
+    if (const char* e = std::getenv("LLCOMP_MI_LPW")) {
+        const long v = std::strtol(e, nullptr, 10);
+        if (v >= 1 && v <= 64) return uint32_t(v);
+    }
+    constexpr uint32_t kTargetWaves = 256 * 4 * 2;
+    uint32_t lpw = (n_slices + kTargetWaves - 1) / kTargetWaves;
+    return lpw < 1 ? 1 : (lpw > 64 ? 64 : lpw);
+}
+
+}  // namespace
+
+#define LLMI_DISPATCH_SLICE(nch, rows, CALL)                                      \
+    switch ((nch) * 2 + ((rows) ? 1 : 0)) {                                       \
+        case 2: { constexpr int C = 1; constexpr bool R = false; CALL; } break;   \
+        case 3: { constexpr int C = 1; constexpr bool R = true; CALL; } break;    \
+        case 4: { constexpr int C = 2; constexpr bool R = false; CALL; } break;   \
+        case 5: { constexpr int C = 2; constexpr bool R = true; CALL; } break;    \
+        case 6: { constexpr int C = 3; constexpr bool R = false; CALL; } break;   \
+        case 7: { constexpr int C = 3; constexpr bool R = true; CALL; } break;    \
+        case 8: { constexpr int C = 4; constexpr bool R = false; CALL; } break;   \
+        case 9: { constexpr int C = 4; constexpr bool R = true; CALL; } break;    \
+        default: return hipErrorInvalidValue;                                     \
+    }
+
+// LLCOMP_MI_NOROWS=1 (tests / debugging) sends 1-row slices through the general table-in-HBM kernels as well.
+static bool rows_mode(const Geometry& g) {
+    if (g.tile_h != 1) return false;
+    const char* e = std::getenv("LLCOMP_MI_NOROWS");
+    return !(e && e[0] == '1');
+}
+bool slices_need_state_tables(const Geometry& g) { return !rows_mode(g); }
+
+hipError_t launch_encode_slices(const Geometry& g, const uint32_t* d_sym, uint64_t* d_states, uint8_t* d_scratch,
+                                uint32_t* d_slice_len, uint32_t* d_status, hipStream_t stream) {
+    const uint32_t lpw = lanes_per_wave(g.n_slices);
+    const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
+    LLMI_DISPATCH_SLICE(g.nch, rows_mode(g),
+                        (k_encode_slices<C, R><<<dim3(blocks), dim3(64), 0, stream>>>(g, lpw, d_sym, d_states, d_scratch,
+                                                                                     d_slice_len, d_status)));
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_payload, uint64_t payload_bytes,
+                                const uint32_t* d_slice_len, const uint64_t* d_offsets, uint64_t* d_states,
+                                int16_t* d_rec, uint32_t* d_status, hipStream_t stream) {
+    const uint32_t lpw = lanes_per_wave(g.n_slices);
+    const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
+    LLMI_DISPATCH_SLICE(g.nch, rows_mode(g),
+                        (k_decode_slices<C, R><<<dim3(blocks), dim3(64), 0, stream>>>(
+                            g, lpw, d_payload, payload_bytes, d_slice_len, d_offsets, d_states, d_rec, d_status)));
+    return hipGetLastError();
+}
+
+}  // namespace llcomp_mi

@@ -233,3 +233,15 @@ def test_c4_8k_roundtrip_and_band_merge_property(mi, orc):
     assert mi.merge_bands([top, bot]) == whole
     assert mi.split_band(whole, 0, 32) == top and mi.split_band(whole, 32, 64) == bot
     assert np.array_equal(mi.decompress_image(whole).pixels, img)
+
+
+@pytest.mark.parametrize("lpw", ["64", "7", "1"])
+def test_lanes_per_wave_does_not_change_bytes(mi, orc, lpw, monkeypatch):
+    """The launcher spreads slices over wavefronts (1..64 slices per wave); the bytes must not depend on it."""
+    monkeypatch.setenv("LLCOMP_MI_LPW", lpw)
+    img = make_image("g3", 200, 150, 3)
+    img[:, 100:] = make_image("mid", 100, 150, 3)
+    for planar in (False, True):
+        s = mi.compress_image(img, 200, 150, 3, format=mi.FORMAT_SLICED, tile_w=16, tile_h=16, planar=planar)
+        assert s == orc.compress_sliced(img, 16, 16, planar)
+        assert np.array_equal(mi.decompress_image(s).pixels, img)
