@@ -26,6 +26,7 @@ struct llcomp_mi_codec {
     uint8_t* d_scratch = nullptr;   // u8[n_slices][slice_cap]
     uint64_t* d_offsets = nullptr;  // u64[n_slices + 1]
     uint64_t* d_total_tmp = nullptr;
+    uint64_t* d_block_sums = nullptr;  // scan scratch
     uint64_t workspace_bytes = 0;
     bool need_states = true;  // false for 1-row slices (states live in registers)
     // optional per-kernel timing (hipEvents on the caller's stream)
@@ -146,7 +147,8 @@ int llcomp_mi_codec_create(llcomp_mi_codec** out, int32_t device, uint32_t frame
               hipMalloc(reinterpret_cast<void**>(&k->d_states), b_states) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&k->d_scratch), b_scratch) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&k->d_offsets), b_off) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void**>(&k->d_total_tmp), 8) == hipSuccess;
+              hipMalloc(reinterpret_cast<void**>(&k->d_total_tmp), 8) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&k->d_block_sums), 8ull * (scan_block_count(g.n_slices) + 1)) == hipSuccess;
     if (!ok) {
         llcomp_mi_codec_destroy(k);
         return LLCOMP_MI_NOMEM;
@@ -163,6 +165,7 @@ void llcomp_mi_codec_destroy(llcomp_mi_codec* k) {
     (void)hipFree(k->d_scratch);
     (void)hipFree(k->d_offsets);
     (void)hipFree(k->d_total_tmp);
+    (void)hipFree(k->d_block_sums);
     for (auto& sp : k->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     delete k;
 }
@@ -206,7 +209,7 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
     {
         Timed t(k, s, 3);
         HIP_TRY(launch_scan_lengths(static_cast<const uint32_t*>(d_slice_len), g.n_slices, k->d_offsets,
-                                    static_cast<uint64_t*>(d_total), s));
+                                    static_cast<uint64_t*>(d_total), k->d_block_sums, s));
         HIP_TRY(launch_pack_payload(g, k->d_scratch, static_cast<const uint32_t*>(d_slice_len), k->d_offsets,
                                     static_cast<uint8_t*>(d_payload), payload_cap, static_cast<uint32_t*>(d_status), s));
     }
@@ -228,7 +231,7 @@ int llcomp_mi_codec_decode(llcomp_mi_codec* k, const void* d_payload, uint64_t p
     }
     {
         Timed t(k, s, 4);
-        HIP_TRY(launch_scan_lengths(static_cast<const uint32_t*>(d_slice_len), g.n_slices, k->d_offsets, k->d_total_tmp, s));
+        HIP_TRY(launch_scan_lengths(static_cast<const uint32_t*>(d_slice_len), g.n_slices, k->d_offsets, k->d_total_tmp, k->d_block_sums, s));
     }
     {
         Timed t(k, s, 5);

@@ -27,8 +27,10 @@ bool slices_need_state_tables(const Geometry& g);
 hipError_t launch_encode_slices(const Geometry& g, const uint32_t* d_sym, uint64_t* d_states, uint8_t* d_scratch,
                                 uint32_t* d_slice_len, uint32_t* d_status, hipStream_t stream);
 // Exclusive prefix sum of slice lengths (u64[n_slices+1]; last = total, also stored to d_total).
+// d_block_sums: scratch of scan_block_count(n) u64.
+uint32_t scan_block_count(uint32_t n);
 hipError_t launch_scan_lengths(const uint32_t* d_slice_len, uint32_t n, uint64_t* d_offsets, uint64_t* d_total,
-                               hipStream_t stream);
+                               uint64_t* d_block_sums, hipStream_t stream);
 // Packs the per-slice scratch streams back to back into d_payload (capacity payload_cap).
 hipError_t launch_pack_payload(const Geometry& g, const uint8_t* d_scratch, const uint32_t* d_slice_len,
                                const uint64_t* d_offsets, uint8_t* d_payload, uint64_t payload_cap,

@@ -5,7 +5,7 @@
 //                 colour-transformed rows (current + the two above + the row being prefetched).
 //                 Reference: llcomp.hpp:396-436.
 //   k_model_inv   stage A, decode side: inverse colour transform + clamp.  llcomp.hpp:532-543.
-//   k_scan_lengths / k_pack_payload
+//   k_scan_local / k_scan_blocks / k_scan_add / k_pack_payload
 //                 wave-prefix-sum of slice lengths and packing of the variable-length streams.
 // None of this is GEMM-shaped; there is no MFMA here on purpose.
 #include <algorithm>
@@ -161,35 +161,75 @@ __global__ __launch_bounds__(256) void k_model_inv(const Geometry g, const int16
 }
 
 // ---- slice length scan + payload packing -------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan_lengths(const uint32_t* __restrict__ len, uint32_t n,
-                                                       uint64_t* __restrict__ off, uint64_t* total) {
+// Exclusive prefix sum of the slice lengths in three small launches (slices can number in the millions):
+//   k_scan_local  : every block of 256 threads scans kScanChunk = 4096 lengths (16 per thread, wave prefix via DPP
+//                   shuffles, 4 wave totals through LDS) -> block-local offsets + one total per block
+//   k_scan_blocks : one block scans the block totals (exclusive, in place) and writes the grand total
+//   k_scan_add    : offsets += their block's base; off[n] = total
+constexpr uint32_t kScanPerThread = 16, kScanThreads = 256, kScanChunk = kScanPerThread * kScanThreads;
+
+__device__ __forceinline__ unsigned long long wave_inclusive_scan(unsigned long long v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(v, d, 64);
+        if (lane >= uint32_t(d)) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_local(const uint32_t* __restrict__ len, uint32_t n,
+                                                             uint64_t* __restrict__ off,
+                                                             uint64_t* __restrict__ block_sum) {
+    __shared__ unsigned long long wave_sum[kScanThreads / 64];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
+    uint32_t v[kScanPerThread];
+    unsigned long long mine = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kScanPerThread; ++j) {
+        v[j] = base + j < n ? len[base + j] : 0;
+        mine += v[j];
+    }
+    const unsigned long long inc = wave_inclusive_scan(mine, lane);
+    if (lane == 63) wave_sum[wv] = inc;
+    __syncthreads();
+    unsigned long long run = inc - mine;
+    for (uint32_t k = 0; k < wv; ++k) run += wave_sum[k];
+#pragma unroll
+    for (uint32_t j = 0; j < kScanPerThread; ++j) {
+        if (base + j < n) off[base + j] = run;
+        run += v[j];
+    }
+    if (threadIdx.x == kScanThreads - 1) block_sum[blockIdx.x] = run;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_blocks(uint64_t* __restrict__ block_sum, uint32_t nb, uint64_t* total) {
     __shared__ unsigned long long wave_sum[16];
     __shared__ unsigned long long carry;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
+    for (uint32_t base = 0; base < nb; base += 1024) {
         const uint32_t i = base + threadIdx.x;
-        const unsigned long long v = i < n ? len[i] : 0;
-        unsigned long long inc = v;  // wave-inclusive prefix sum, 64 lanes
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long o = __shfl_up(inc, d, 64);
-            if (lane >= uint32_t(d)) inc += o;
-        }
+        const unsigned long long v = i < nb ? block_sum[i] : 0;
+        const unsigned long long inc = wave_inclusive_scan(v, lane);
         if (lane == 63) wave_sum[wv] = inc;
         __syncthreads();
         unsigned long long before = carry;
         for (uint32_t k = 0; k < wv; ++k) before += wave_sum[k];
-        if (i < n) off[i] = before + inc - v;
+        if (i < nb) block_sum[i] = before + inc - v;
         __syncthreads();
         if (threadIdx.x == 1023) carry = before + inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        off[n] = carry;
-        *total = carry;
-    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_add(uint64_t* __restrict__ off, uint32_t n,
+                                                  const uint64_t* __restrict__ block_sum, const uint64_t* total) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) off[i] += block_sum[i / kScanChunk];
+    if (i == n) off[n] = *total;
 }
 
 __global__ __launch_bounds__(256) void k_pack_payload(const Geometry g, const uint8_t* __restrict__ scratch,
@@ -249,9 +289,14 @@ hipError_t launch_model_inv(const Geometry& g, const int16_t* d_rec, uint8_t* d_
     return hipGetLastError();
 }
 
+uint32_t scan_block_count(uint32_t n) { return (n + kScanChunk - 1) / kScanChunk; }
+
 hipError_t launch_scan_lengths(const uint32_t* d_slice_len, uint32_t n, uint64_t* d_offsets, uint64_t* d_total,
-                               hipStream_t stream) {
-    k_scan_lengths<<<dim3(1), dim3(1024), 0, stream>>>(d_slice_len, n, d_offsets, d_total);
+                               uint64_t* d_block_sums, hipStream_t stream) {
+    const uint32_t nb = scan_block_count(n);
+    k_scan_local<<<dim3(nb), dim3(kScanThreads), 0, stream>>>(d_slice_len, n, d_offsets, d_block_sums);
+    k_scan_blocks<<<dim3(1), dim3(1024), 0, stream>>>(d_block_sums, nb, d_total);
+    k_scan_add<<<dim3(n / 256 + 1), dim3(256), 0, stream>>>(d_offsets, n, d_block_sums, d_total);
     return hipGetLastError();
 }
 

@@ -43,6 +43,7 @@ __device__ __forceinline__ void load_table(entry_t* tab) {
 }
 
 __device__ __forceinline__ uint32_t byte_of(uint32_t w, int k) { return (w >> (8 * k)) & 0xFF; }
+__device__ __forceinline__ uint32_t consume_here(uint32_t v);
 template <int SLOT>
 __device__ __forceinline__ uint32_t slot_state(const uint32_t (&bank)[2]) {
     return byte_of(bank[SLOT >> 2], SLOT & 3);
@@ -235,7 +236,13 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
         uint32_t s0 = p0[0];
         uint32_t s1 = total > 1 ? p0[1] : 0;
         for (uint32_t i = 0; i < total; ++i) {
+            // Memory operations of one wave retire in order and s_waitcnt counts loads and stores together, so the
+            // order inside an iteration is: consume what was requested a sample ago (long back, no stall) -> issue the
+            // next prefetch -> issue the stores of the previous sample's output.  Nothing is ever waited for right
+            // after it was issued.
+            s0 = consume_here(s0);  // loaded two samples ago
             const uint32_t s2 = i + 2 < total ? p0[i + 2] : 0;
+            if (e.pos - e.flushed >= 16) enc_flush16(e);
             const uint32_t ctx = s0 & 0xFFFF;
             const int res = int(s0) >> 16;
             const bool c1 = ctx == 605, c2 = ctx > 605;
@@ -246,7 +253,6 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
             B[0][0] = c0 ? bank[0] : B[0][0]; B[0][1] = c0 ? bank[1] : B[0][1];
             B[1][0] = c1 ? bank[0] : B[1][0]; B[1][1] = c1 ? bank[1] : B[1][1];
             B[2][0] = c2 ? bank[0] : B[2][0]; B[2][1] = c2 ? bank[1] : B[2][1];
-            if (e.pos - e.flushed >= 16) enc_flush16(e);
             s0 = s1;
             s1 = s2;
         }
@@ -297,34 +303,46 @@ struct RangeDec {
     uint32_t low, range;
     uint32_t wlo, whi;      // window, LSB first; bits above `nb` bytes are zero
     int32_t nb;             // valid bytes in the window
-    uint32_t nxt;           // prefetched dword that follows the window
+    uint32_t nxt;           // prefetched dword that follows the window, RAW (masked only when it is appended, so the
+    uint32_t nxt_mask;      //   load's latency is never waited for at the point of issue)
     const uint32_t* words;  // aligned base: word k holds stream bytes [4k - skew, 4k - skew + 4)
     uint32_t end;           // len + skew (0 when the slice is empty)
+    uint32_t kmax;          // last word that holds stream bytes
     uint32_t kn;            // next word to prefetch
 };
-__device__ __forceinline__ uint32_t dec_word(const RangeDec& d, uint32_t k) {
-    const uint32_t first = k * 4;
-    if (first >= d.end) return 0;
-    uint32_t w = d.words[k];
-    const uint32_t nvalid = d.end - first;  // >= 1
-    if (nvalid < 4) w &= (1u << (8 * nvalid)) - 1;
-    return w;
+// issues the load of word k and records the mask of its valid stream bytes.  The load is UNCONDITIONAL (index clamped
+// to the last word that holds stream bytes) so that its result lands directly in the loop-carried register; a
+// conditional load ends in a register copy, and hipcc waits vmcnt(0) for that copy right after the issue.
+__device__ __forceinline__ void dec_prefetch(RangeDec& d, uint32_t k) {
+    d.nxt = d.words[min(k, d.kmax)];
+    const int32_t nvalid = int32_t(d.end) - int32_t(k * 4);
+    d.nxt_mask = nvalid >= 4 ? 0xFFFFFFFFu : (nvalid <= 0 ? 0u : (1u << (8 * nvalid)) - 1);
+}
+// Pins the point where a value that was loaded earlier is consumed: the compiler's s_waitcnt for it lands HERE (the
+// load was issued a whole sample ago, so it has long returned) and no later load may be hoisted above it -- otherwise
+// hipcc issues the next prefetch first and then waits vmcnt(0) for both.
+__device__ __forceinline__ uint32_t consume_here(uint32_t v) {
+    asm volatile("" : "+v"(v) : : "memory");
+    return v;
 }
 __device__ __forceinline__ void dec_append(RangeDec& d) {  // requires nb <= 4
-    const uint64_t w = (uint64_t(d.nxt) << (8 * d.nb)) | (uint64_t(d.whi) << 32) | d.wlo;
+    const uint32_t ready = consume_here(d.nxt);
+    const uint64_t w = (uint64_t(ready & d.nxt_mask) << (8 * d.nb)) | (uint64_t(d.whi) << 32) | d.wlo;
     d.wlo = uint32_t(w);
     d.whi = uint32_t(w >> 32);
     d.nb += 4;
-    d.nxt = dec_word(d, d.kn++);
+    dec_prefetch(d, d.kn++);
 }
 __device__ __forceinline__ void dec_open(RangeDec& d, const uint8_t* p, uint32_t len) {
     const uint32_t skew = uint32_t(uintptr_t(p) & 3);
     d.words = reinterpret_cast<const uint32_t*>(p - skew);
     d.end = len ? len + skew : 0;
-    d.wlo = dec_word(d, 0) >> (8 * skew);
+    d.kmax = d.end ? (d.end - 1) >> 2 : 0;
+    dec_prefetch(d, 0);
+    d.wlo = (d.nxt & d.nxt_mask) >> (8 * skew);
     d.whi = 0;
     d.nb = int32_t(4 - skew);
-    d.nxt = dec_word(d, 1);
+    dec_prefetch(d, 1);
     d.kn = 2;
     dec_append(d);
     d.range = 0xFF00;  // llcomp.hpp:93-96: low = first two bytes
@@ -432,7 +450,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
         atomicOr(status, kStTruncated);
         len = off < payload_bytes ? payload_bytes - off : 0;
     }
-    dec_open(d, payload + (off < payload_bytes ? off : 0), uint32_t(len));
+    dec_open(d, payload + ((len && off < payload_bytes) ? off : 0), uint32_t(len));  // empty slice: any readable word
 
     const ptrdiff_t rs = ptrdiff_t(slice_row_stride(g));  // row stride in samples; samples of a row are contiguous
     int16_t* p0 = rec + slice_origin(g, r);
@@ -445,10 +463,13 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
         int l[NCH], L[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) l[k] = L[k] = 128;
+        int held_val = 0;           // the previous sample: stored only AFTER the window top-up of the next one, so the
+        int16_t* held_at = nullptr; // top-up never waits for a store that was issued a moment ago (see the encoder)
         for (uint32_t x = 0; x < r.sw; ++x) {
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 if (d.nb <= 4) dec_append(d);
+                if (held_at) *held_at = int16_t(held_val);
                 const int lv = l[k];                 // x == 0: 128
                 const int Lv = x > 1 ? L[k] : lv;    // llcomp.hpp:496
                 const int dq = Lv - lv;
@@ -469,11 +490,13 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 B[2][0] = c2 ? bank[0] : B[2][0]; B[2][1] = c2 ? bank[1] : B[2][1];
                 if (neg) v = 0u - v;
                 const int val = int(int16_t(uint32_t(lv) + v));
-                p0[ptrdiff_t(x) * NCH + k] = int16_t(val);
+                held_val = val;
+                held_at = p0 + ptrdiff_t(x) * NCH + k;
                 L[k] = lv;
                 l[k] = val;
             }
         }
+        if (held_at) *held_at = int16_t(held_val);
     } else {
         // Neighbours of the row above rotate through registers (tl <- t <- tr); the two values the NEXT pixel needs
         // from memory (top-right, top-top) are loaded while the current one decodes.
