@@ -77,8 +77,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=8, help="4K frames per step per GPU")
     ap.add_argument("--content", default="g3", choices=["g3", "g2", "mid"])
-    ap.add_argument("--tile-w", type=int, default=64)
-    ap.add_argument("--tile-h", type=int, default=64)
+    ap.add_argument("--tile-w", type=int, default=960)
+    ap.add_argument("--tile-h", type=int, default=1)
     ap.add_argument("--interleaved", action="store_true", help="channels interleaved in one slice instead of per-channel planes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -21,7 +21,8 @@ struct llcomp_mi_codec {
     Geometry g{};
     int device = 0;
     // workspace (all on `device`)
-    void* d_sym_or_rec = nullptr;   // encode: u32 symbols per sample; decode: int16 reconstructed samples
+    void* d_sym_or_rec = nullptr;   // image order: encode u32 symbols per sample / decode int16 reconstructed samples
+    void* d_lane_order = nullptr;   // the same data in lane order [group][k][64] for the serial kernels
     uint64_t* d_states = nullptr;   // u64[n_slices][kContexts]
     uint8_t* d_scratch = nullptr;   // u8[n_slices][slice_cap]
     uint64_t* d_offsets = nullptr;  // u64[n_slices + 1]
@@ -142,8 +143,9 @@ int llcomp_mi_codec_create(llcomp_mi_codec** out, int32_t device, uint32_t frame
     k->need_states = slices_need_state_tables(g);
     const uint64_t b_sym = samples * 4, b_states = k->need_states ? uint64_t(g.n_slices) * kContexts * 8 : 8,
                    b_scratch = uint64_t(g.n_slices) * g.slice_cap, b_off = (uint64_t(g.n_slices) + 1) * 8;
-    k->workspace_bytes = b_sym + b_states + b_scratch + b_off + 8;
-    bool ok = hipMalloc(&k->d_sym_or_rec, b_sym) == hipSuccess &&
+    const uint64_t b_lanes = (uint64_t(lane_groups(g)) * slice_capacity_samples(g) << g.lane_shift) * 4;
+    k->workspace_bytes = b_sym + b_lanes + b_states + b_scratch + b_off + 8;
+    bool ok = hipMalloc(&k->d_sym_or_rec, b_sym) == hipSuccess && hipMalloc(&k->d_lane_order, b_lanes) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&k->d_states), b_states) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&k->d_scratch), b_scratch) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&k->d_offsets), b_off) == hipSuccess &&
@@ -161,6 +163,7 @@ void llcomp_mi_codec_destroy(llcomp_mi_codec* k) {
     if (!k) return;
     DeviceGuard guard(k->device);
     (void)hipFree(k->d_sym_or_rec);
+    (void)hipFree(k->d_lane_order);
     (void)hipFree(k->d_states);
     (void)hipFree(k->d_scratch);
     (void)hipFree(k->d_offsets);
@@ -200,10 +203,12 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
     {
         Timed t(k, s, 1);
         HIP_TRY(launch_model_fwd(g, static_cast<const uint8_t*>(d_px), static_cast<uint32_t*>(k->d_sym_or_rec), s));
+        HIP_TRY(launch_to_lane_order_u32(g, static_cast<const uint32_t*>(k->d_sym_or_rec),
+                                         static_cast<uint32_t*>(k->d_lane_order), s));
     }
     {
         Timed t(k, s, 2);
-        HIP_TRY(launch_encode_slices(g, static_cast<const uint32_t*>(k->d_sym_or_rec), k->d_states, k->d_scratch,
+        HIP_TRY(launch_encode_slices(g, static_cast<const uint32_t*>(k->d_lane_order), k->d_states, k->d_scratch,
                                      static_cast<uint32_t*>(d_slice_len), static_cast<uint32_t*>(d_status), s));
     }
     {
@@ -237,10 +242,12 @@ int llcomp_mi_codec_decode(llcomp_mi_codec* k, const void* d_payload, uint64_t p
         Timed t(k, s, 5);
         HIP_TRY(launch_decode_slices(g, static_cast<const uint8_t*>(d_payload), payload_bytes,
                                      static_cast<const uint32_t*>(d_slice_len), k->d_offsets, k->d_states,
-                                     static_cast<int16_t*>(k->d_sym_or_rec), static_cast<uint32_t*>(d_status), s));
+                                     static_cast<int16_t*>(k->d_lane_order), static_cast<uint32_t*>(d_status), s));
     }
     {
         Timed t(k, s, 6);
+        HIP_TRY(launch_from_lane_order_i16(g, static_cast<const int16_t*>(k->d_lane_order),
+                                           static_cast<int16_t*>(k->d_sym_or_rec), s));
         HIP_TRY(launch_model_inv(g, static_cast<const int16_t*>(k->d_sym_or_rec), static_cast<uint8_t*>(d_px), s));
     }
     ++k->n_decode;

@@ -23,7 +23,15 @@ struct Geometry {
     uint32_t n_slices;          // frames * slices_per_frame
     uint32_t slice_cap;         // scratch bytes reserved per slice (worst case, multiple of 16)
     uint32_t nch;               // channels coded inside one slice: planar ? 1 : c
+    uint32_t lane_shift;        // log2 of the lane-group width (64 lanes, fewer when there are fewer slices)
+    uint32_t slice_samples;     // sample capacity of one slice: tile_w * tile_h * nch
 };
+
+// lane order: element k of slice `id` inside an array laid out [group][k][group width]
+LLMI_HD inline size_t lane_order_index(const Geometry& g, uint32_t id, uint32_t k) {
+    const uint32_t gw = 1u << g.lane_shift;
+    return ((size_t(id >> g.lane_shift) * g.slice_samples + k) << g.lane_shift) + (id & (gw - 1));
+}
 
 struct SliceRect {
     uint32_t frame, x0, y0, sw, sh, ch;  // ch = first channel of the slice (planar) or 0
@@ -66,6 +74,9 @@ inline bool make_geometry(Geometry& g, uint32_t frames, uint32_t w, uint32_t h, 
     const uint64_t cap = (uint64_t(tile_w) * tile_h * g.nch * 13 + 16 + 15) & ~15ull;
     if (cap >= (1ull << 32)) return false;
     g.slice_cap = uint32_t(cap);
+    g.slice_samples = tile_w * tile_h * g.nch;
+    g.lane_shift = 0;
+    while (g.lane_shift < 6 && (1u << g.lane_shift) < g.n_slices) ++g.lane_shift;
     return true;
 }
 

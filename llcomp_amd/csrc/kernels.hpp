@@ -18,10 +18,17 @@ hipError_t launch_model_fwd(const Geometry& g, const uint8_t* d_px, uint32_t* d_
 // Stage A (decode side): reconstructed colour-transformed samples int16 -> pixels u8.  llcomp.hpp:532-543.
 hipError_t launch_model_inv(const Geometry& g, const int16_t* d_rec, uint8_t* d_px, hipStream_t stream);
 
+// Lane order: [lane_groups][slice_capacity_samples][64]; see model_kernels.hip.
+uint32_t lane_groups(const Geometry& g);
+uint32_t slice_capacity_samples(const Geometry& g);
+hipError_t launch_to_lane_order_u32(const Geometry& g, const uint32_t* d_img, uint32_t* d_lanes, hipStream_t stream);
+hipError_t launch_from_lane_order_i16(const Geometry& g, const int16_t* d_lanes, int16_t* d_img, hipStream_t stream);
+
 // 1-row slices keep their (three) contexts in registers; only taller slices need the per-slice tables in HBM.
 bool slices_need_state_tables(const Geometry& g);
 
 // One lane per slice: binarisation + adaptive states + range encoder.  llcomp.hpp:33-89, 166-206, 283-293, 439-449.
+//   d_sym     : symbols in LANE ORDER
 //   d_states  : u64[n_slices][kContexts], zeroed by the caller (8 state bytes per context)
 //   d_scratch : u8[n_slices][slice_cap]  ; d_slice_len : u32[n_slices]
 hipError_t launch_encode_slices(const Geometry& g, const uint32_t* d_sym, uint64_t* d_states, uint8_t* d_scratch,
@@ -36,7 +43,7 @@ hipError_t launch_pack_payload(const Geometry& g, const uint8_t* d_scratch, cons
                                const uint64_t* d_offsets, uint8_t* d_payload, uint64_t payload_cap,
                                uint32_t* d_status, hipStream_t stream);
 // One lane per slice: range decoder + adaptive states + context model on reconstructed samples.
-// llcomp.hpp:91-127, 219-247, 486-530.  d_rec int16, same layout rule as the symbols.
+// llcomp.hpp:91-127, 219-247, 486-530.  d_rec int16 in LANE ORDER.
 hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_payload, uint64_t payload_bytes,
                                 const uint32_t* d_slice_len, const uint64_t* d_offsets, uint64_t* d_states,
                                 int16_t* d_rec, uint32_t* d_status, hipStream_t stream);

@@ -224,9 +224,10 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     e.ring = reinterpret_cast<uint8_t*>(ring + threadIdx.x);
     e.out = scratch + size_t(id) * g.slice_cap;
     e.cap = int32_t(g.slice_cap);
-    const size_t row_stride = slice_row_stride(g);
-    const uint32_t n_row = r.sw * NCH;  // samples per slice row (contiguous)
-    const uint32_t* p0 = sym + slice_origin(g, r);
+    const uint32_t n_row = r.sw * NCH;  // samples per slice row
+    // symbols in lane order: sample k of this slice is p0[k * GW]; the lanes of a group read one contiguous piece
+    const uint32_t* p0 = sym + lane_order_index(g, id, 0);
+    const size_t GW = size_t(1) << g.lane_shift;  // distance between consecutive samples of this slice
     const uint32_t total = n_row * r.sh;
     bool hot = false;  // wave-uniform: most lanes had a non-zero residual last time
 
@@ -234,14 +235,14 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
         // contexts 0 / 605 / 1210 only: three banks in registers
         uint32_t B[3][2] = {{0, 0}, {0, 0}, {0, 0}};
         uint32_t s0 = p0[0];
-        uint32_t s1 = total > 1 ? p0[1] : 0;
+        uint32_t s1 = total > 1 ? p0[GW] : 0;
         for (uint32_t i = 0; i < total; ++i) {
             // Memory operations of one wave retire in order and s_waitcnt counts loads and stores together, so the
             // order inside an iteration is: consume what was requested a sample ago (long back, no stall) -> issue the
             // next prefetch -> issue the stores of the previous sample's output.  Nothing is ever waited for right
             // after it was issued.
             s0 = consume_here(s0);  // loaded two samples ago
-            const uint32_t s2 = i + 2 < total ? p0[i + 2] : 0;
+            const uint32_t s2 = i + 2 < total ? p0[size_t(i + 2) * GW] : 0;
             if (e.pos - e.flushed >= 16) enc_flush16(e);
             const uint32_t ctx = s0 & 0xFFFF;
             const int res = int(s0) >> 16;
@@ -260,13 +261,8 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
         // Everything the coder needs is known up front: the symbol two samples ahead and the state bank one sample
         // ahead are in flight while a sample is coded (forwarded when consecutive samples share a context).
         uint64_t* banks = states + size_t(id) * kContexts;
-        uint32_t fx = 0;
-        const uint32_t* frow = p0;
-        auto fetch = [&]() -> uint32_t {
-            const uint32_t v = frow[fx];
-            if (++fx == n_row) { fx = 0; frow += row_stride; }
-            return v;
-        };
+        uint32_t fk = 0;
+        auto fetch = [&]() -> uint32_t { return p0[size_t(fk++) * GW]; };
         uint32_t s0 = fetch();
         uint32_t s1 = total > 1 ? fetch() : 0;
         uint64_t b0 = banks[s0 & 0xFFFF];
@@ -452,8 +448,9 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
     }
     dec_open(d, payload + ((len && off < payload_bytes) ? off : 0), uint32_t(len));  // empty slice: any readable word
 
-    const ptrdiff_t rs = ptrdiff_t(slice_row_stride(g));  // row stride in samples; samples of a row are contiguous
-    int16_t* p0 = rec + slice_origin(g, r);
+    // reconstructed samples in lane order: sample k of this slice is p0[k * GW]
+    int16_t* p0 = rec + lane_order_index(g, id, 0);
+    const ptrdiff_t GW = ptrdiff_t(1) << g.lane_shift;  // distance between consecutive samples of this slice
     bool hot = false;
 
     if constexpr (ROWS) {
@@ -491,7 +488,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 if (neg) v = 0u - v;
                 const int val = int(int16_t(uint32_t(lv) + v));
                 held_val = val;
-                held_at = p0 + ptrdiff_t(x) * NCH + k;
+                held_at = p0 + (ptrdiff_t(x) * NCH + k) * GW;
                 L[k] = lv;
                 l[k] = val;
             }
@@ -501,23 +498,24 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
         // Neighbours of the row above rotate through registers (tl <- t <- tr); the two values the NEXT pixel needs
         // from memory (top-right, top-top) are loaded while the current one decodes.
         uint64_t* banks = states + size_t(id) * kContexts;
+        const ptrdiff_t up = ptrdiff_t(r.sw) * NCH * GW;  // one slice row back, in lane-order elements
         for (uint32_t y = 0; y < r.sh; ++y) {
-            int16_t* row = p0 + ptrdiff_t(y) * rs;
+            int16_t* row = p0 + ptrdiff_t(y) * up;
             int l[NCH], L[NCH], t[NCH], tl[NCH], tr[NCH], T[NCH];
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 l[k] = L[k] = tl[k] = 0;
-                t[k] = y > 0 ? row[k - rs] : 0;
-                tr[k] = (y > 0 && r.sw > 1) ? row[k - rs + NCH] : 0;
-                T[k] = y > 1 ? row[k - 2 * rs] : 0;
+                t[k] = y > 0 ? row[k * GW - up] : 0;
+                tr[k] = (y > 0 && r.sw > 1) ? row[(k + NCH) * GW - up] : 0;
+                T[k] = y > 1 ? row[k * GW - 2 * up] : 0;
             }
             for (uint32_t x = 0; x < r.sw; ++x) {
-                int16_t* q = row + ptrdiff_t(x) * NCH;
+                int16_t* q = row + ptrdiff_t(x) * NCH * GW;
                 int tr_n[NCH], T_n[NCH];
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
-                    tr_n[k] = (y > 0 && x + 2 < r.sw) ? q[k - rs + 2 * NCH] : 0;
-                    T_n[k] = (y > 1 && x + 1 < r.sw) ? q[k - 2 * rs + NCH] : 0;
+                    tr_n[k] = (y > 0 && x + 2 < r.sw) ? q[(k + 2 * NCH) * GW - up] : 0;
+                    T_n[k] = (y > 1 && x + 1 < r.sw) ? q[(k + NCH) * GW - 2 * up] : 0;
                 }
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
@@ -538,7 +536,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                     banks[ctx] = uint64_t(bank[0]) | (uint64_t(bank[1]) << 32);
                     if (neg) v = 0u - v;
                     const int val = int(int16_t(uint32_t(predict(n)) + v));
-                    q[k] = int16_t(val);
+                    q[k * GW] = int16_t(val);
                     L[k] = l[k];
                     l[k] = val;
                     tl[k] = t[k];
