@@ -245,3 +245,49 @@ def test_lanes_per_wave_does_not_change_bytes(mi, orc, lpw, monkeypatch):
         s = mi.compress_image(img, 200, 150, 3, format=mi.FORMAT_SLICED, tile_w=16, tile_h=16, planar=planar)
         assert s == orc.compress_sliced(img, 16, 16, planar)
         assert np.array_equal(mi.decompress_image(s).pixels, img)
+
+
+# ---- the reference-compatible CLIs (tools/llcompc, tools/llcompd) --------------------------------------------------
+def test_cli_roundtrip_matches_reference_behaviour(mi, orc, tmp_path):
+    import os
+    import struct
+    import subprocess
+    import zlib
+
+    from conftest import ROOT
+
+    exe_c, exe_d = os.path.join(ROOT, "tools", "llcompc"), os.path.join(ROOT, "tools", "llcompd")
+    if not (os.path.exists(exe_c) and os.path.exists(exe_d)):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")])
+    img = make_image("mid", 61, 47, 3)
+    ppm = tmp_path / "a.ppm"
+    ppm.write_bytes(b"P6\n# comment\n61 47\n255\n" + img.tobytes())
+    assert subprocess.run([exe_c]).returncode == 1                      # usage
+    assert subprocess.run([exe_c, str(tmp_path / "missing.ppm")]).returncode == 1
+    assert subprocess.run([exe_c, str(ppm)]).returncode == 0
+    stream = (tmp_path / "a.ppm.llcomp").read_bytes()                   # llcompc.cpp:34: <path> + ".llcomp"
+    assert stream == orc.compress_image(img)                            # == reference stream
+    assert subprocess.run([exe_d, str(tmp_path / "a.ppm.llcomp")]).returncode == 0
+    png = (tmp_path / "a.ppm.llcomp.png").read_bytes()                  # llcompd.cpp:28: <path> + ".png"
+    assert png[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr = 8, b"", None
+    while pos < len(png):
+        n, typ = struct.unpack(">I4s", png[pos:pos + 8])
+        body = png[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", png[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + body)
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        if typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    assert ihdr == (61, 47, 8, 2, 0, 0, 0)
+    raw = zlib.decompress(idat)
+    rows = np.frombuffer(raw, np.uint8).reshape(47, 1 + 61 * 3)
+    assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:].reshape(47, 61, 3), img)
+    # sliced container through the CLI, damaged input -> exit code 1 with the reference's message
+    assert subprocess.run([exe_c, str(ppm), "--sliced", "16x1"]).returncode == 0
+    assert (tmp_path / "a.ppm.llcomp").read_bytes() == orc.compress_sliced(img, 16, 1, True)
+    bad = tmp_path / "bad.llcomp"
+    bad.write_bytes(bytes([0x42]) + stream[1:])
+    r = subprocess.run([exe_d, str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and "Invalid magic number" in r.stderr
