@@ -202,9 +202,13 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
     }
     {
         Timed t(k, s, 1);
-        HIP_TRY(launch_model_fwd(g, static_cast<const uint8_t*>(d_px), static_cast<uint32_t*>(k->d_sym_or_rec), s));
-        HIP_TRY(launch_to_lane_order_u32(g, static_cast<const uint32_t*>(k->d_sym_or_rec),
-                                         static_cast<uint32_t*>(k->d_lane_order), s));
+        if (model_is_fused(g)) {
+            HIP_TRY(launch_model_rows_fwd(g, static_cast<const uint8_t*>(d_px), static_cast<uint32_t*>(k->d_lane_order), s));
+        } else {
+            HIP_TRY(launch_model_fwd(g, static_cast<const uint8_t*>(d_px), static_cast<uint32_t*>(k->d_sym_or_rec), s));
+            HIP_TRY(launch_to_lane_order_u32(g, static_cast<const uint32_t*>(k->d_sym_or_rec),
+                                             static_cast<uint32_t*>(k->d_lane_order), s));
+        }
     }
     {
         Timed t(k, s, 2);
@@ -246,9 +250,13 @@ int llcomp_mi_codec_decode(llcomp_mi_codec* k, const void* d_payload, uint64_t p
     }
     {
         Timed t(k, s, 6);
-        HIP_TRY(launch_from_lane_order_i16(g, static_cast<const int16_t*>(k->d_lane_order),
-                                           static_cast<int16_t*>(k->d_sym_or_rec), s));
-        HIP_TRY(launch_model_inv(g, static_cast<const int16_t*>(k->d_sym_or_rec), static_cast<uint8_t*>(d_px), s));
+        if (model_is_fused(g)) {
+            HIP_TRY(launch_model_rows_inv(g, static_cast<const int16_t*>(k->d_lane_order), static_cast<uint8_t*>(d_px), s));
+        } else {
+            HIP_TRY(launch_from_lane_order_i16(g, static_cast<const int16_t*>(k->d_lane_order),
+                                               static_cast<int16_t*>(k->d_sym_or_rec), s));
+            HIP_TRY(launch_model_inv(g, static_cast<const int16_t*>(k->d_sym_or_rec), static_cast<uint8_t*>(d_px), s));
+        }
     }
     ++k->n_decode;
     return LLCOMP_MI_OK;

@@ -24,6 +24,11 @@ uint32_t slice_capacity_samples(const Geometry& g);
 hipError_t launch_to_lane_order_u32(const Geometry& g, const uint32_t* d_img, uint32_t* d_lanes, hipStream_t stream);
 hipError_t launch_from_lane_order_i16(const Geometry& g, const int16_t* d_lanes, int16_t* d_img, hipStream_t stream);
 
+// Planar 1-row slices: stage A fused with the lane-order transpose (pixels <-> lane-order arrays directly).
+bool model_is_fused(const Geometry& g);
+hipError_t launch_model_rows_fwd(const Geometry& g, const uint8_t* d_px, uint32_t* d_lanes, hipStream_t stream);
+hipError_t launch_model_rows_inv(const Geometry& g, const int16_t* d_lanes, uint8_t* d_px, hipStream_t stream);
+
 // 1-row slices keep their (three) contexts in registers; only taller slices need the per-slice tables in HBM.
 bool slices_need_state_tables(const Geometry& g);
 

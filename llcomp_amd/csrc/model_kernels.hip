@@ -5,6 +5,8 @@
 //                 colour-transformed rows (current + the two above + the row being prefetched).
 //                 Reference: llcomp.hpp:396-436.
 //   k_model_inv   stage A, decode side: inverse colour transform + clamp.  llcomp.hpp:532-543.
+//   k_model_rows_fwd / k_model_rows_inv
+//                 the same two stages fused with the lane-order transpose for planar 1-row slices.
 //   k_to_lane_order / k_from_lane_order
 //                 64x64 LDS transposes between image order and the [group][k][lane] order of the serial kernels.
 //   k_scan_local / k_scan_blocks / k_scan_add / k_pack_payload
@@ -341,6 +343,127 @@ __global__ __launch_bounds__(256) void k_from_lane_order(const Geometry g, const
     }
 }
 
+// ---- fused stage A for planar 1-row slices (tile_h == 1, planar) -------------------------------------------------------
+// The headline configuration.  One block = one lane group (64 consecutive slice ids = ~64/C tiles x C channel planes)
+// x 64 consecutive samples: the pixel runs of those tiles are staged raw in LDS (coalesced reads of 66*C bytes each),
+// every thread then models samples of its lane and the block writes symbols straight in lane order (256-byte pieces),
+// so the image-order symbol array and the transpose pass disappear.  With h == 0 in llcomp.hpp:417-429 the context is
+// 605*quant5(L - l) and the prediction is l.
+template <int C>
+__device__ __forceinline__ int rct_channel(const uint8_t* p, int ch) {  // one colour-transformed channel of a pixel
+    if constexpr (C >= 3) {
+        const int g = p[1], cb = int(p[2]) - g, cr = int(p[0]) - g;
+        if (ch == 0) return cr;
+        if (ch == 2) return cb;
+        if (ch == 1) return g + (cb + cr) / 4;  // truncating division, llcomp.hpp:402
+        return p[3];
+    } else {
+        return p[ch];
+    }
+}
+struct RowTile {
+    unsigned long long base;  // byte offset of the tile's first pixel in the frame batch
+    uint32_t sw;              // pixels in this tile
+};
+template <int C>
+__device__ __forceinline__ void load_row_tiles(const Geometry& g, uint32_t first_tile, uint32_t ntiles, RowTile* tiles) {
+    if (threadIdx.x < ntiles) {
+        const uint32_t tile = first_tile + threadIdx.x;  // global tile index: (frame, row, column tile)
+        const uint32_t per_frame = g.ntx * g.nty;        // nty == h because tile_h == 1
+        const uint32_t frame = tile / per_frame, rem = tile - frame * per_frame;
+        const uint32_t y = rem / g.ntx, tx = rem - y * g.ntx;
+        const uint32_t x0 = tx * g.tile_w;
+        tiles[threadIdx.x].base = ((size_t(frame) * g.h + y) * g.w + x0) * C;
+        tiles[threadIdx.x].sw = g.w - x0 < g.tile_w ? g.w - x0 : g.tile_w;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_model_rows_fwd(const Geometry g, const uint8_t* __restrict__ px,
+                                                        uint32_t* __restrict__ lanes) {
+    constexpr int K = 64, RUN = (K + 2) * C, TPG = 64 / C + 2;
+    __shared__ uint8_t raw[TPG][RUN + 2];
+    __shared__ RowTile tiles[TPG];
+    const uint32_t chunks = (g.tile_w + K - 1) / K;
+    const uint32_t group = blockIdx.x / chunks, k0 = (blockIdx.x - group * chunks) * K;
+    const uint32_t gw = 1u << g.lane_shift;
+    const uint32_t first_id = group << g.lane_shift;
+    const uint32_t end_id = first_id + gw < g.n_slices ? first_id + gw : g.n_slices;
+    const uint32_t first_tile = first_id / C, ntiles = (end_id - 1) / C - first_tile + 1;
+    load_row_tiles<C>(g, first_tile, ntiles, tiles);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < ntiles * RUN; i += 256) {
+        const uint32_t tt = i / RUN, b = i - tt * RUN;
+        const int off = (int(k0) - 2) * C + int(b);  // byte offset from the tile's first pixel
+        raw[tt][b] = (off >= 0 && off < int(tiles[tt].sw) * C) ? px[tiles[tt].base + off] : uint8_t(0);
+    }
+    __syncthreads();
+    const uint32_t j = threadIdx.x & 63;
+    const uint32_t id = first_id + j;
+    if (j >= gw || id >= end_id) return;
+    const uint32_t tt = id / C - first_tile, ch = id - (id / C) * C;
+    const uint32_t sw = tiles[tt].sw;
+    for (uint32_t kk = threadIdx.x >> 6; kk < uint32_t(K); kk += 4) {
+        const uint32_t k = k0 + kk;
+        if (k >= sw) break;
+        const uint8_t* p = &raw[tt][(kk + 2) * C];
+        const int cur = rct_channel<C>(p, ch);
+        const int l = k > 0 ? rct_channel<C>(p - C, ch) : 128;  // llcomp.hpp:417
+        const int L = k > 1 ? rct_channel<C>(p - 2 * C, ch) : l;  // llcomp.hpp:419
+        const int q = quant5(L - l);
+        int res = cur - l;
+        if (q < 0) res = -res;  // llcomp.hpp:433-436
+        lanes[lane_order_index(g, id, k)] = uint32_t(605 * (q < 0 ? -q : q)) | (uint32_t(res) << 16);
+    }
+}
+
+// Decode side: lane-order reconstructed samples -> pixels.  One block = the tiles whose FIRST channel plane lies in one
+// lane group x 64 samples; the other planes of the last tile may sit in the next group, hence 64 + C - 1 lanes.
+template <int C>
+__global__ __launch_bounds__(256) void k_model_rows_inv(const Geometry g, const int16_t* __restrict__ lanes,
+                                                        uint8_t* __restrict__ px) {
+    constexpr int K = 64, TPG = 64 / C + 2;
+    __shared__ int16_t tile[K][64 + C + 1];
+    __shared__ RowTile tiles[TPG];
+    const uint32_t chunks = (g.tile_w + K - 1) / K;
+    const uint32_t group = blockIdx.x / chunks, k0 = (blockIdx.x - group * chunks) * K;
+    const uint32_t gw = 1u << g.lane_shift;
+    const uint32_t first_id = group << g.lane_shift;
+    const uint32_t end_id = first_id + gw < g.n_slices ? first_id + gw : g.n_slices;
+    const uint32_t first_tile = (first_id + C - 1) / C;          // first tile whose channel 0 is in this group
+    const uint32_t end_tile = (end_id + C - 1) / C;              // one past the last such tile
+    if (first_tile >= end_tile) return;
+    const uint32_t ntiles = end_tile - first_tile;
+    load_row_tiles<C>(g, first_tile, ntiles, tiles);
+    const uint32_t lane0 = first_tile * C;                       // slice id held in LDS column 0
+    const uint32_t ncols = ntiles * C;
+    for (uint32_t i = threadIdx.x; i < uint32_t(K) * (64 + C - 1); i += 256) {
+        const uint32_t kk = i / (64 + C - 1), col = i - kk * (64 + C - 1);
+        const uint32_t id = lane0 + col, k = k0 + kk;
+        tile[kk][col] = (col < ncols && id < g.n_slices && k < g.tile_w) ? lanes[lane_order_index(g, id, k)] : int16_t(0);
+    }
+    __syncthreads();
+    const uint32_t kk = threadIdx.x & 63, k = k0 + kk;
+    for (uint32_t tt = threadIdx.x >> 6; tt < ntiles; tt += 4) {
+        if (k >= tiles[tt].sw) continue;
+        const int16_t* s = &tile[kk][tt * C];
+        uint8_t* o = px + tiles[tt].base + size_t(k) * C;
+        if constexpr (C >= 3) {  // llcomp.hpp:532-543
+            int r = s[0], gg = s[1], b = s[2];
+            gg -= (r + b) / 4;
+            r += gg;
+            b += gg;
+            o[0] = uint8_t(min(max(r, 0), 255));
+            o[1] = uint8_t(min(max(gg, 0), 255));
+            o[2] = uint8_t(min(max(b, 0), 255));
+            if constexpr (C == 4) o[3] = uint8_t(s[3]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) o[c] = uint8_t(s[c]);
+        }
+    }
+}
+
 }  // namespace
 
 #define LLMI_DISPATCH_C(c, CALL) \
@@ -377,6 +500,22 @@ hipError_t launch_from_lane_order_i16(const Geometry& g, const int16_t* d_lanes,
     const uint64_t blocks = uint64_t(lane_groups(g)) * ((max_n + 63) / 64);
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     k_from_lane_order<int16_t><<<dim3(uint32_t(blocks)), dim3(256), 0, stream>>>(g, max_n, d_lanes, d_img);
+    return hipGetLastError();
+}
+
+bool model_is_fused(const Geometry& g) { return g.planar && g.tile_h == 1; }
+
+hipError_t launch_model_rows_fwd(const Geometry& g, const uint8_t* d_px, uint32_t* d_lanes, hipStream_t stream) {
+    const uint64_t blocks = uint64_t(lane_groups(g)) * ((g.tile_w + 63) / 64);
+    if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    LLMI_DISPATCH_C(g.c, (k_model_rows_fwd<C><<<dim3(uint32_t(blocks)), dim3(256), 0, stream>>>(g, d_px, d_lanes)));
+    return hipGetLastError();
+}
+
+hipError_t launch_model_rows_inv(const Geometry& g, const int16_t* d_lanes, uint8_t* d_px, hipStream_t stream) {
+    const uint64_t blocks = uint64_t(lane_groups(g)) * ((g.tile_w + 63) / 64);
+    if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    LLMI_DISPATCH_C(g.c, (k_model_rows_inv<C><<<dim3(uint32_t(blocks)), dim3(256), 0, stream>>>(g, d_lanes, d_px)));
     return hipGetLastError();
 }
 
