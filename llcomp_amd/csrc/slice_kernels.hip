@@ -25,14 +25,14 @@ namespace llcomp_mi {
 namespace {
 
 // ---- model table ------------------------------------------------------------------------------------------------
-// entry = packed_state | packed_successors << 32, always moved as ONE 64-bit LDS access
+// entry = entry_lo | entry_hi << 32 (tables.hpp), always moved as ONE 64-bit LDS access
 using entry_t = unsigned long long;
 struct EntryTable {
     entry_t v[128];
 };
 constexpr EntryTable make_entries() {
     EntryTable t{};
-    for (uint32_t s = 0; s < 128; ++s) t.v[s] = entry_t(packed_state(s)) | (entry_t(packed_successors(s)) << 32);
+    for (uint32_t s = 0; s < 128; ++s) t.v[s] = entry_t(entry_lo(s)) | (entry_t(entry_hi(s)) << 32);
     return t;
 }
 __constant__ EntryTable c_entries = make_entries();
@@ -54,9 +54,10 @@ __device__ __forceinline__ void set_slot_state(uint32_t (&bank)[2], uint32_t ns)
     bank[W] = (bank[W] & ~(0xFFu << SH)) | (ns << SH);
 }
 // successor state / successor probability of entry e for the coded bit
-__device__ __forceinline__ uint32_t prob_of(entry_t e) { return uint32_t(e) & 0xFF; }
-__device__ __forceinline__ uint32_t next_state(entry_t e, bool bit) { return bit ? byte_of(uint32_t(e), 2) : byte_of(uint32_t(e), 1); }
-__device__ __forceinline__ uint32_t next_prob(entry_t e, bool bit) { return bit ? byte_of(uint32_t(e >> 32), 1) : byte_of(uint32_t(e >> 32), 0); }
+__device__ __forceinline__ uint32_t prob_of(entry_t e) { return byte_of(uint32_t(e), 2); }
+// half of the entry that belongs to the coded bit: byte0 = successor state, byte1 = its probability
+__device__ __forceinline__ uint32_t successor(entry_t e, bool bit) { return bit ? uint32_t(e >> 32) : uint32_t(e); }
+__device__ __forceinline__ uint32_t next_state(entry_t e, bool bit) { return successor(e, bit) & 0xFF; }
 
 // The 8 entries of one context.  `all` = request slots 1..7 together with slot 0 (worth it when most residuals
 // are non-zero); otherwise they are requested after the zero flag turned out 0.
@@ -88,57 +89,57 @@ __device__ __forceinline__ void fetch_rest(Entries& E, const uint32_t (&bank)[2]
 }
 
 // ================================================ ENCODER ========================================================
-// Range encoder of one lane (llcomp.hpp:33-89).  Output bytes are staged in a per-lane LDS ring of 8 dwords laid out
-// [row][lane] (conflict-free) and leave for HBM as aligned 16-byte stores.  `pos` starts at -1: the reference holds
-// its first byte back without emitting (held == -1); here a dummy byte is "emitted" to position -1 instead, which
-// is the same thing without the special case.
+// Range encoder of one lane (llcomp.hpp:33-89).  Output bytes are staged in a per-lane LDS slot of 36 bytes (32-byte
+// ring + 4 spare; 9-dword stride = conflict-free) and leave for HBM as aligned 16-byte stores.  `pos` starts at -1:
+// the reference holds its first byte back without emitting (held == -1); here a dummy byte is "emitted" to position
+// -1 instead, which is the same thing without the special case.
 struct RangeEnc {
     uint32_t low, range, held, pend;
     int32_t pos;      // bytes produced so far
     int32_t flushed;  // bytes already stored to HBM (multiple of 16)
-    uint8_t* ring;    // this lane's first ring byte in LDS (row r is at ring + 256 * r)
+    uint8_t* ring;    // this lane's 36-byte LDS slot
     uint8_t* out;     // slice scratch in HBM, 16-byte aligned
     int32_t cap;
 };
+constexpr int kRingStrideDwords = 9;
 __device__ __forceinline__ void enc_flush16(RangeEnc& e) {
-    const uint32_t r = (uint32_t(e.flushed) >> 2) & 7;  // 0 or 4
-    const uint32_t* row = reinterpret_cast<const uint32_t*>(e.ring + 256 * r);
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(e.ring + (uint32_t(e.flushed) & 16));
     uint4 v;
-    v.x = row[0]; v.y = row[64]; v.z = row[128]; v.w = row[192];
+    v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
     if (e.flushed + 16 <= e.cap) *reinterpret_cast<uint4*>(e.out + e.flushed) = v;
     e.flushed += 16;
 }
-__device__ __forceinline__ void enc_emit(RangeEnc& e, uint32_t b) {
-    const uint32_t p = uint32_t(e.pos);
-    e.ring[((p >> 2) & 7) * 256 + (p & 3)] = uint8_t(b);
-    ++e.pos;
-}
-// one renormalisation step (body of the reference's `while (range < 0x100)`: one step always suffices because
-// range >= 7 after put() and == 0xFF in finish())
-__device__ __forceinline__ void enc_shift(RangeEnc& e) {
-    const uint32_t carry = e.low >> 16;               // low >= 0x10000
-    if (e.low - 0xFF01u < 0xFFu) {                    // 0xFF00 < low < 0x10000: undecided byte
-        ++e.pend;
-    } else {
-        enc_emit(e, e.held + carry);
-        if (__builtin_expect(e.pend != 0, 0)) {
-            const uint32_t fill = carry ? 0x00u : 0xFFu;
-            for (; e.pend; --e.pend) {
-                if (e.pos - e.flushed >= 16) enc_flush16(e);
-                enc_emit(e, fill);
-            }
-        }
-        e.held = (e.low >> 8) & 0xFF;
+// rare: a run of undecided 0xFF bytes is resolved (llcomp.hpp:44-45, 49-50); called before `low` is shifted
+__device__ __forceinline__ void enc_fill(RangeEnc& e) {
+    const uint32_t fill = (e.low >> 16) ? 0x00u : 0xFFu;
+    for (; e.pend; --e.pend) {
+        if (e.pos - e.flushed >= 16) enc_flush16(e);
+        e.ring[uint32_t(e.pos) & 31] = uint8_t(fill);
+        ++e.pos;
     }
-    e.low = (e.low & 0xFF) << 8;
-    e.range <<= 8;
+}
+// Renormalisation (body of the reference's `while (range < 0x100)`: one step always suffices because range >= 7 after
+// put() and == 0xFF in finish()).  ONE exec-masked region for the lanes that renormalise; inside it the three cases of
+// llcomp.hpp:40-54 are selects: every such lane writes one LDS byte -- the leaving byte (held + carry) into the ring when
+// it flushes, into its spare byte when the new byte is still undecided (0xFF00 < low < 0x10000).
+__device__ __forceinline__ void enc_renorm(RangeEnc& e) {
+    if (e.range < 0x100) {
+        const bool undecided = e.low - 0xFF01u < 0xFFu;
+        e.ring[undecided ? 32u : (uint32_t(e.pos) & 31)] = uint8_t(e.held + (e.low >> 16));
+        e.pos += undecided ? 0 : 1;
+        if (__builtin_expect(!undecided && e.pend != 0, 0)) enc_fill(e);
+        e.held = undecided ? e.held : (e.low >> 8) & 0xFF;
+        e.pend += undecided ? 1 : 0;
+        e.low = (e.low & 0xFF) << 8;
+        e.range <<= 8;
+    }
 }
 __device__ __forceinline__ void enc_core(RangeEnc& e, uint32_t P, bool bit) {  // llcomp.hpp:60-73
     const uint32_t r1 = __umul24(e.range, P) >> 8;
     const uint32_t r0 = e.range - r1;
     e.low += bit ? r0 : 0u;
     e.range = bit ? r1 : r0;
-    if (e.range < 0x100) enc_shift(e);
+    enc_renorm(e);
 }
 // a slot that is coded at most once per sample
 template <int SLOT>
@@ -172,8 +173,9 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, uint32_t (&bank)[2], c
                     do {
                         b = ex > i;
                         enc_core(e, P, b);
-                        ns = next_state(cur, b);
-                        P = next_prob(cur, b);
+                        const uint32_t nx = successor(cur, b);
+                        ns = nx & 0xFF;
+                        P = byte_of(nx, 1);
                         cur = tab[ns];
                         ++i;
                     } while (b);
@@ -188,8 +190,9 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, uint32_t (&bank)[2], c
                 do {
                     const bool b = (a >> i) & 1;
                     enc_core(e, P, b);
-                    ns = next_state(cur, b);
-                    P = next_prob(cur, b);
+                    const uint32_t nx = successor(cur, b);
+                    ns = nx & 0xFF;
+                    P = byte_of(nx, 1);
                     cur = tab[ns];
                 } while (--i >= 0);
                 set_slot_state<6>(bank, ns);
@@ -200,8 +203,8 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, uint32_t (&bank)[2], c
 }
 
 __device__ __forceinline__ void enc_finish(RangeEnc& e) {  // llcomp.hpp:75-81
-    e.range = 0xFF; e.low += 0xFF; enc_shift(e);
-    e.range = 0xFF; enc_shift(e);
+    e.range = 0xFF; e.low += 0xFF; enc_renorm(e);
+    e.range = 0xFF; enc_renorm(e);
     while (e.pos - e.flushed > 0) enc_flush16(e);  // tail: whole 16-byte groups, the slack is scratch
 }
 
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
                                                       uint8_t* __restrict__ scratch, uint32_t* __restrict__ slice_len,
                                                       uint32_t* status) {
     __shared__ entry_t tab[128];
-    __shared__ uint32_t ring[8 * 64];
+    __shared__ uint32_t ring[kRingStrideDwords * 64];
     load_table(tab);
     const uint32_t id = blockIdx.x * lpw + threadIdx.x;
     if (threadIdx.x >= lpw || id >= g.n_slices) return;
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     RangeEnc e;
     e.low = 0; e.range = 0xFF00; e.held = 0; e.pend = 0;  // llcomp.hpp:35 (held: see RangeEnc)
     e.pos = -1; e.flushed = 0;
-    e.ring = reinterpret_cast<uint8_t*>(ring + threadIdx.x);
+    e.ring = reinterpret_cast<uint8_t*>(ring + kRingStrideDwords * threadIdx.x);
     e.out = scratch + size_t(id) * g.slice_cap;
     e.cap = int32_t(g.slice_cap);
     const uint32_t n_row = r.sw * NCH;  // samples per slice row
@@ -347,8 +350,13 @@ __device__ __forceinline__ void dec_open(RangeDec& d, const uint8_t* p, uint32_t
     d.whi >>= 16;
     d.nb -= 2;
 }
+// CHECKED == false is the fast path: it never looks at the fill level of the window.  The kernel tops the window up to
+// >= 5 bytes before every sample and afterwards looks at `nb` once: a negative value means the sample consumed more
+// bytes than the window held (possible, a sample can take up to 13 bytes, but rare); the coder state is then rolled
+// back and the sample is decoded again with CHECKED == true, which refills inside the step.
+template <bool CHECKED>
 __device__ __forceinline__ bool dec_core(RangeDec& d, uint32_t P) {  // llcomp.hpp:98-121, branch-free refill
-    if (__builtin_expect(d.nb <= 0, 0)) dec_append(d);
+    if (CHECKED && d.nb <= 0) dec_append(d);
     const uint32_t r1 = __umul24(d.range, P) >> 8;
     const uint32_t r0 = d.range - r1;
     const bool bit = d.low >= r0;
@@ -363,38 +371,39 @@ __device__ __forceinline__ bool dec_core(RangeDec& d, uint32_t P) {  // llcomp.h
     d.nb -= need ? 1 : 0;
     return bit;
 }
-template <int SLOT>
+template <int SLOT, bool CHECKED>
 __device__ __forceinline__ bool dec_once(RangeDec& d, uint32_t (&bank)[2], const Entries& E) {
-    const bool bit = dec_core(d, prob_of(E.get<SLOT>()));
+    const bool bit = dec_core<CHECKED>(d, prob_of(E.get<SLOT>()));
     set_slot_state<SLOT>(bank, next_state(E.get<SLOT>(), bit));
     return bit;
 }
 // getSymbol<true,4,6,7> (llcomp.hpp:219-247).  Returns false on "Invalid exponent".  Arithmetic modulo 2^32.
-template <bool ALL>
+template <bool ALL, bool CHECKED>
 __device__ __forceinline__ bool dec_residual(RangeDec& d, uint32_t (&bank)[2], const entry_t* tab, uint32_t& out) {
     Entries E;
     fetch_slot0(E, bank, tab);
     if (ALL) fetch_rest(E, bank, tab);
-    if (dec_once<0>(d, bank, E)) {
+    if (dec_once<0, CHECKED>(d, bank, E)) {
         out = 0;
         return true;
     }
     if (!ALL) fetch_rest(E, bank, tab);
     int ex = 0;
     bool ok = true;
-    if (dec_once<1>(d, bank, E)) {
+    if (dec_once<1, CHECKED>(d, bank, E)) {
         ex = 1;
-        if (dec_once<2>(d, bank, E)) {
+        if (dec_once<2, CHECKED>(d, bank, E)) {
             ex = 2;
-            if (dec_once<3>(d, bank, E)) {
+            if (dec_once<3, CHECKED>(d, bank, E)) {
                 ex = 3;
                 entry_t cur = E.e4;
                 uint32_t P = prob_of(cur), ns;
                 bool b;
                 do {
-                    b = dec_core(d, P);
-                    ns = next_state(cur, b);
-                    P = next_prob(cur, b);
+                    b = dec_core<CHECKED>(d, P);
+                    const uint32_t nx = successor(cur, b);
+                    ns = nx & 0xFF;
+                    P = byte_of(nx, 1);
                     cur = tab[ns];
                     ex += b ? 1 : 0;
                     if (ex > 31) { ok = false; b = false; }
@@ -406,24 +415,38 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, uint32_t (&bank)[2], c
     if (!ok) return false;
     uint32_t v = 1;
     if (ex > 0) {
-        v += v + uint32_t(dec_once<5>(d, bank, E));
+        v += v + uint32_t(dec_once<5, CHECKED>(d, bank, E));
         if (ex > 1) {
             entry_t cur = E.e6;
             uint32_t P = prob_of(cur), ns;
             int j = ex - 1;
             do {
-                const bool b = dec_core(d, P);
-                ns = next_state(cur, b);
-                P = next_prob(cur, b);
+                const bool b = dec_core<CHECKED>(d, P);
+                const uint32_t nx = successor(cur, b);
+                ns = nx & 0xFF;
+                P = byte_of(nx, 1);
                 cur = tab[ns];
                 v += v + uint32_t(b);
             } while (--j > 0);
             set_slot_state<6>(bank, ns);
         }
     }
-    if (dec_once<7>(d, bank, E)) v = 0u - v;
+    if (dec_once<7, CHECKED>(d, bank, E)) v = 0u - v;
     out = v;
     return true;
+}
+
+// One sample: fast path first, checked replay when the window ran dry (or the fast path saw nonsense because of it).
+__device__ __forceinline__ bool dec_sample(RangeDec& d, uint32_t (&bank)[2], const entry_t* tab, bool hot, uint32_t& v) {
+    const uint32_t s_low = d.low, s_range = d.range, s_wlo = d.wlo, s_whi = d.whi, s_b0 = bank[0], s_b1 = bank[1];
+    const int32_t s_nb = d.nb;
+    bool ok = hot ? dec_residual<true, false>(d, bank, tab, v) : dec_residual<false, false>(d, bank, tab, v);
+    if (__builtin_expect(!ok || d.nb < 0, 0)) {
+        d.low = s_low; d.range = s_range; d.wlo = s_wlo; d.whi = s_whi; d.nb = s_nb;
+        bank[0] = s_b0; bank[1] = s_b1;
+        ok = dec_residual<false, true>(d, bank, tab, v);
+    }
+    return ok;
 }
 
 template <int NCH, bool ROWS>
@@ -475,7 +498,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 const bool c2 = aq > 3, c1 = aq > 0 && !c2;  // |quant5| == 2 / == 1
                 uint32_t bank[2] = {c2 ? B[2][0] : c1 ? B[1][0] : B[0][0], c2 ? B[2][1] : c1 ? B[1][1] : B[0][1]};
                 uint32_t v;
-                const bool ok = hot ? dec_residual<true>(d, bank, tab, v) : dec_residual<false>(d, bank, tab, v);
+                const bool ok = dec_sample(d, bank, tab, hot, v);
                 if (!ok) {
                     atomicOr(status, kStBadExponent);
                     return;
@@ -527,7 +550,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                     const uint64_t b64 = banks[ctx];
                     uint32_t bank[2] = {uint32_t(b64), uint32_t(b64 >> 32)};
                     uint32_t v;
-                    const bool ok = hot ? dec_residual<true>(d, bank, tab, v) : dec_residual<false>(d, bank, tab, v);
+                    const bool ok = dec_sample(d, bank, tab, hot, v);
                     if (!ok) {
                         atomicOr(status, kStBadExponent);
                         return;  // this lane's slice is unusable; the whole call reports the error

@@ -4,9 +4,9 @@
 // /root/reference/llcomp.hpp:252-293) is a 128-state machine, state = 2*level + mps, level 0..63:
 //   P(bit==1)*256 = mps ? 254 - kLpsProb[level] : kLpsProb[level]
 //   bit == mps -> level+1 (saturating at 63);  bit != mps -> level==0 ? flip mps : kLpsFall[level]
-// packed_state(s) folds that into ONE 32-bit word per state so a bin costs a single LDS read (first word of the
-// 8-byte LDS entry {packed_state, packed_successors}):
-//   bits 0..7  P(bit==1)*256      bits 8..15 next state if the coded bit is 0      bits 16..23 next state if 1
+// entry_lo/entry_hi fold that into one 8-byte LDS entry per state, arranged so that ONE select on the coded bit yields
+// both the successor state and the successor's probability:
+//   lo: byte0 next state if bit 0 | byte1 P(that state) | byte2 P(this state)        hi: byte0 next state if bit 1 | byte1 P(that state)
 #pragma once
 #include <cstdint>
 
@@ -32,10 +32,7 @@ constexpr uint32_t state_next(uint32_t s, uint32_t bit) {
     if (level == 0) return mps ^ 1;
     return 2 * kLpsFall[level] + mps;
 }
-constexpr uint32_t packed_state(uint32_t s) { return state_prob(s) | (state_next(s, 0) << 8) | (state_next(s, 1) << 16); }
-// second word of the LDS entry: the probabilities of the two successor states, so that a run of bins on the SAME
-// slot (unary exponent tail, mantissa tail) knows its next probability before the successor's entry has arrived
-//   bits 0..7 P(next state if 0)     bits 8..15 P(next state if 1)
-constexpr uint32_t packed_successors(uint32_t s) { return state_prob(state_next(s, 0)) | (state_prob(state_next(s, 1)) << 8); }
+constexpr uint32_t entry_lo(uint32_t s) { return state_next(s, 0) | (state_prob(state_next(s, 0)) << 8) | (state_prob(s) << 16); }
+constexpr uint32_t entry_hi(uint32_t s) { return state_next(s, 1) | (state_prob(state_next(s, 1)) << 8); }
 
 }  // namespace llcomp_mi
