@@ -203,7 +203,7 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
     {
         Timed t(k, s, 1);
         if (model_is_fused(g)) {
-            HIP_TRY(launch_model_rows_fwd(g, static_cast<const uint8_t*>(d_px), static_cast<uint32_t*>(k->d_lane_order), s));
+            HIP_TRY(launch_model_rows_fwd(g, static_cast<const uint8_t*>(d_px), static_cast<uint16_t*>(k->d_lane_order), s));
         } else {
             HIP_TRY(launch_model_fwd(g, static_cast<const uint8_t*>(d_px), static_cast<uint32_t*>(k->d_sym_or_rec), s));
             HIP_TRY(launch_to_lane_order_u32(g, static_cast<const uint32_t*>(k->d_sym_or_rec),
@@ -212,7 +212,7 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
     }
     {
         Timed t(k, s, 2);
-        HIP_TRY(launch_encode_slices(g, static_cast<const uint32_t*>(k->d_lane_order), k->d_states, k->d_scratch,
+        HIP_TRY(launch_encode_slices(g, k->d_lane_order, k->d_states, k->d_scratch,
                                      static_cast<uint32_t*>(d_slice_len), static_cast<uint32_t*>(d_status), s));
     }
     {

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void k_from_lane_order(const Geometry g, const
 // ---- fused stage A for planar 1-row slices (tile_h == 1, planar) -------------------------------------------------------
 // The headline configuration.  One block = one lane group (64 consecutive slice ids = ~64/C tiles x C channel planes)
 // x 64 consecutive samples: the pixel runs of those tiles are staged raw in LDS (coalesced reads of 66*C bytes each),
-// every thread then models samples of its lane and the block writes symbols straight in lane order (256-byte pieces),
+// every thread then models samples of its lane and the block writes 16-bit symbols straight in lane order,
 // so the image-order symbol array and the transpose pass disappear.  With h == 0 in llcomp.hpp:417-429 the context is
 // 605*quant5(L - l) and the prediction is l.
 template <int C>
@@ -380,7 +380,7 @@ __device__ __forceinline__ void load_row_tiles(const Geometry& g, uint32_t first
 
 template <int C>
 __global__ __launch_bounds__(256) void k_model_rows_fwd(const Geometry g, const uint8_t* __restrict__ px,
-                                                        uint32_t* __restrict__ lanes) {
+                                                        uint16_t* __restrict__ lanes) {
     constexpr int K = 64, RUN = (K + 2) * C, TPG = 64 / C + 2;
     __shared__ uint8_t raw[TPG][RUN + 2];
     __shared__ RowTile tiles[TPG];
@@ -413,7 +413,8 @@ __global__ __launch_bounds__(256) void k_model_rows_fwd(const Geometry g, const 
         const int q = quant5(L - l);
         int res = cur - l;
         if (q < 0) res = -res;  // llcomp.hpp:433-436
-        lanes[lane_order_index(g, id, k)] = uint32_t(605 * (q < 0 ? -q : q)) | (uint32_t(res) << 16);
+        // 16-bit symbol of the fused path: bits 12..13 = |quant5| (context 0 / 605 / 1210), bits 0..11 = residual
+        lanes[lane_order_index(g, id, k)] = uint16_t(((q < 0 ? -q : q) << 12) | (res & 0xFFF));
     }
 }
 
@@ -503,9 +504,9 @@ hipError_t launch_from_lane_order_i16(const Geometry& g, const int16_t* d_lanes,
     return hipGetLastError();
 }
 
-bool model_is_fused(const Geometry& g) { return g.planar && g.tile_h == 1; }
+bool model_is_fused(const Geometry& g) { return g.planar && rows_mode(g); }
 
-hipError_t launch_model_rows_fwd(const Geometry& g, const uint8_t* d_px, uint32_t* d_lanes, hipStream_t stream) {
+hipError_t launch_model_rows_fwd(const Geometry& g, const uint8_t* d_px, uint16_t* d_lanes, hipStream_t stream) {
     const uint64_t blocks = uint64_t(lane_groups(g)) * ((g.tile_w + 63) / 64);
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     LLMI_DISPATCH_C(g.c, (k_model_rows_fwd<C><<<dim3(uint32_t(blocks)), dim3(256), 0, stream>>>(g, d_px, d_lanes)));

@@ -210,9 +210,9 @@ __device__ __forceinline__ void enc_finish(RangeEnc& e) {  // llcomp.hpp:75-81
 
 // Lane-per-slice encoder.  ROWS: every slice is one row high (register-resident states).  `lpw` = slices per
 // wavefront (1..64).
-template <int NCH, bool ROWS>
+template <int NCH, bool ROWS, typename SYM>
 __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const uint32_t lpw,
-                                                      const uint32_t* __restrict__ sym, uint64_t* __restrict__ states,
+                                                      const SYM* __restrict__ sym, uint64_t* __restrict__ states,
                                                       uint8_t* __restrict__ scratch, uint32_t* __restrict__ slice_len,
                                                       uint32_t* status) {
     __shared__ entry_t tab[128];
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     e.cap = int32_t(g.slice_cap);
     const uint32_t n_row = r.sw * NCH;  // samples per slice row
     // symbols in lane order: sample k of this slice is p0[k * GW]; the lanes of a group read one contiguous piece
-    const uint32_t* p0 = sym + lane_order_index(g, id, 0);
+    const SYM* p0 = sym + lane_order_index(g, id, 0);
     const size_t GW = size_t(1) << g.lane_shift;  // distance between consecutive samples of this slice
     const uint32_t total = n_row * r.sh;
     bool hot = false;  // wave-uniform: most lanes had a non-zero residual last time
@@ -247,9 +247,16 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
             s0 = consume_here(s0);  // loaded two samples ago
             const uint32_t s2 = i + 2 < total ? p0[size_t(i + 2) * GW] : 0;
             if (e.pos - e.flushed >= 16) enc_flush16(e);
-            const uint32_t ctx = s0 & 0xFFFF;
-            const int res = int(s0) >> 16;
-            const bool c1 = ctx == 605, c2 = ctx > 605;
+            bool c1, c2;
+            int res;
+            if constexpr (sizeof(SYM) == 2) {  // fused stage A: |quant5| in bits 12..13, residual in bits 0..11
+                c1 = (s0 >> 12) == 1; c2 = (s0 >> 12) == 2;
+                res = int(s0 << 20) >> 20;
+            } else {
+                const uint32_t ctx = s0 & 0xFFFF;
+                c1 = ctx == 605; c2 = ctx > 605;
+                res = int(s0) >> 16;
+            }
             uint32_t bank[2] = {c2 ? B[2][0] : c1 ? B[1][0] : B[0][0], c2 ? B[2][1] : c1 ? B[1][1] : B[0][1]};
             if (hot) enc_residual<true>(e, bank, tab, res); else enc_residual<false>(e, bank, tab, res);
             hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(res != 0)) >= __popcll(__ballot(true)));
@@ -601,20 +608,25 @@ uint32_t lanes_per_wave(uint32_t n_slices) {
     }
 
 // LLCOMP_MI_NOROWS=1 (tests / debugging) sends 1-row slices through the general table-in-HBM kernels as well.
-static bool rows_mode(const Geometry& g) {
+bool rows_mode(const Geometry& g) {
     if (g.tile_h != 1) return false;
     const char* e = std::getenv("LLCOMP_MI_NOROWS");
     return !(e && e[0] == '1');
 }
 bool slices_need_state_tables(const Geometry& g) { return !rows_mode(g); }
 
-hipError_t launch_encode_slices(const Geometry& g, const uint32_t* d_sym, uint64_t* d_states, uint8_t* d_scratch,
+hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* d_states, uint8_t* d_scratch,
                                 uint32_t* d_slice_len, uint32_t* d_status, hipStream_t stream) {
     const uint32_t lpw = lanes_per_wave(g.n_slices);
     const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
+    if (model_is_fused(g)) {  // planar 1-row slices: 16-bit symbols, always the register-resident kernel
+        k_encode_slices<1, true, uint16_t><<<dim3(blocks), dim3(64), 0, stream>>>(
+            g, lpw, static_cast<const uint16_t*>(d_sym), d_states, d_scratch, d_slice_len, d_status);
+        return hipGetLastError();
+    }
     LLMI_DISPATCH_SLICE(g.nch, rows_mode(g),
-                        (k_encode_slices<C, R><<<dim3(blocks), dim3(64), 0, stream>>>(g, lpw, d_sym, d_states, d_scratch,
-                                                                                     d_slice_len, d_status)));
+                        (k_encode_slices<C, R, uint32_t><<<dim3(blocks), dim3(64), 0, stream>>>(
+                            g, lpw, static_cast<const uint32_t*>(d_sym), d_states, d_scratch, d_slice_len, d_status)));
     return hipGetLastError();
 }
 

@@ -291,3 +291,17 @@ def test_cli_roundtrip_matches_reference_behaviour(mi, orc, tmp_path):
     bad.write_bytes(bytes([0x42]) + stream[1:])
     r = subprocess.run([exe_d, str(bad)], capture_output=True, text=True)
     assert r.returncode == 1 and "Invalid magic number" in r.stderr
+
+
+def test_one_row_slices_through_both_kernel_families(mi, orc, monkeypatch):
+    """tile_h == 1 normally runs the register-resident kernels (+ the fused 16-bit-symbol stage A when planar);
+    LLCOMP_MI_NOROWS=1 forces the same slicing through the general table-in-HBM kernels.  Same bytes either way."""
+    img = make_image("g3", 300, 9, 3)
+    img[:, 150:] = make_image("mid", 150, 9, 3)
+    for planar in (False, True):
+        want = orc.compress_sliced(img, 70, 1, planar)
+        for norows in ("0", "1"):
+            monkeypatch.setenv("LLCOMP_MI_NOROWS", norows)
+            s = mi.compress_image(img, 300, 9, 3, format=mi.FORMAT_SLICED, tile_w=70, tile_h=1, planar=planar)
+            assert s == want
+            assert np.array_equal(mi.decompress_image(s).pixels, img)
