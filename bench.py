@@ -75,9 +75,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=8, help="4K frames per step per GPU")
+    ap.add_argument("--frames", type=int, default=16, help="4K frames per step per GPU")
     ap.add_argument("--content", default="g3", choices=["g3", "g2", "mid"])
-    ap.add_argument("--tile-w", type=int, default=960)
+    ap.add_argument("--tile-w", type=int, default=480)
     ap.add_argument("--tile-h", type=int, default=1)
     ap.add_argument("--interleaved", action="store_true", help="channels interleaved in one slice instead of per-channel planes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,6 +166,15 @@ def main():
         stream_bytes = total + (24 + 4 * codec.n_slices // F) * F  # per-frame container headers + slice tables
         algo = raw_bytes + stream_bytes
         achieved = algo / (dom_ms * 1e-3) / 1e9
+        traffic = None  # HBM-side bytes per launch from committed rocprofv3 PMC passes of THIS configuration
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_default_traffic.json")))
+            same = all(tj["config"].get(k) == v for k, v in (("frames_per_step_per_gpu", F), ("tile_w", args.tile_w), ("tile_h", args.tile_h),
+                                                            ("planar", planar), ("content", args.content)))
+            if same and world == 1:
+                traffic = tj["per_launch"][dom]["hbm_bytes_corrected"]
+        except (OSError, KeyError, ValueError):
+            pass
         res = {
             "metric": "encode+decode MPix/s on 4K RGB8, bit-exact",
             "value": round(value, 2),
@@ -190,7 +199,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(dom_ms, 4),
                 "note": "path is serial-dependency bound (one lane per slice), not HBM bound: see DESIGN.md",
             },

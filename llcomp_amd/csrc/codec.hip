@@ -24,7 +24,7 @@ struct llcomp_mi_codec {
     void* d_sym_or_rec = nullptr;   // image order: encode u32 symbols per sample / decode int16 reconstructed samples
     void* d_lane_order = nullptr;   // the same data in lane order [group][k][64] for the serial kernels
     uint64_t* d_states = nullptr;   // u64[n_slices][kContexts]
-    uint8_t* d_scratch = nullptr;   // u8[n_slices][slice_cap]
+    uint8_t* d_scratch = nullptr;   // slice streams in stream lane order: 16-byte units [group][unit][lane]
     uint64_t* d_offsets = nullptr;  // u64[n_slices + 1]
     uint64_t* d_total_tmp = nullptr;
     uint64_t* d_block_sums = nullptr;  // scan scratch
@@ -142,7 +142,7 @@ int llcomp_mi_codec_create(llcomp_mi_codec** out, int32_t device, uint32_t frame
     const uint64_t samples = uint64_t(frames) * w * h * c;
     k->need_states = slices_need_state_tables(g);
     const uint64_t b_sym = samples * 4, b_states = k->need_states ? uint64_t(g.n_slices) * kContexts * 8 : 8,
-                   b_scratch = uint64_t(g.n_slices) * g.slice_cap, b_off = (uint64_t(g.n_slices) + 1) * 8;
+                   b_scratch = (uint64_t(lane_groups(g)) << g.lane_shift) * g.slice_cap, b_off = (uint64_t(g.n_slices) + 1) * 8;
     const uint64_t b_lanes = (uint64_t(lane_groups(g)) * slice_capacity_samples(g) << g.lane_shift) * 4;
     k->workspace_bytes = b_sym + b_lanes + b_states + b_scratch + b_off + 8;
     bool ok = hipMalloc(&k->d_sym_or_rec, b_sym) == hipSuccess && hipMalloc(&k->d_lane_order, b_lanes) == hipSuccess &&
@@ -243,9 +243,14 @@ int llcomp_mi_codec_decode(llcomp_mi_codec* k, const void* d_payload, uint64_t p
         HIP_TRY(launch_scan_lengths(static_cast<const uint32_t*>(d_slice_len), g.n_slices, k->d_offsets, k->d_total_tmp, k->d_block_sums, s));
     }
     {
+        Timed t(k, s, 4);
+        HIP_TRY(launch_stage_streams(g, static_cast<const uint8_t*>(d_payload), payload_bytes,
+                                     static_cast<const uint32_t*>(d_slice_len), k->d_offsets, k->d_scratch,
+                                     static_cast<uint32_t*>(d_status), s));
+    }
+    {
         Timed t(k, s, 5);
-        HIP_TRY(launch_decode_slices(g, static_cast<const uint8_t*>(d_payload), payload_bytes,
-                                     static_cast<const uint32_t*>(d_slice_len), k->d_offsets, k->d_states,
+        HIP_TRY(launch_decode_slices(g, k->d_scratch, static_cast<const uint32_t*>(d_slice_len), k->d_states,
                                      static_cast<int16_t*>(k->d_lane_order), static_cast<uint32_t*>(d_status), s));
     }
     {

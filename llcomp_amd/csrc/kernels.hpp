@@ -37,7 +37,7 @@ bool slices_need_state_tables(const Geometry& g);
 //   d_sym     : symbols in LANE ORDER: u32 (ctx | residual << 16), or the 16-bit form of the fused path when
 //               model_is_fused(g)
 //   d_states  : u64[n_slices][kContexts], zeroed by the caller (8 state bytes per context)
-//   d_scratch : u8[n_slices][slice_cap]  ; d_slice_len : u32[n_slices]
+//   d_scratch : the slices' streams in stream lane order ; d_slice_len : u32[n_slices]
 hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* d_states, uint8_t* d_scratch,
                                 uint32_t* d_slice_len, uint32_t* d_status, hipStream_t stream);
 // Exclusive prefix sum of slice lengths (u64[n_slices+1]; last = total, also stored to d_total).
@@ -45,14 +45,19 @@ hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* 
 uint32_t scan_block_count(uint32_t n);
 hipError_t launch_scan_lengths(const uint32_t* d_slice_len, uint32_t n, uint64_t* d_offsets, uint64_t* d_total,
                                uint64_t* d_block_sums, hipStream_t stream);
-// Packs the per-slice scratch streams back to back into d_payload (capacity payload_cap).
-hipError_t launch_pack_payload(const Geometry& g, const uint8_t* d_scratch, const uint32_t* d_slice_len,
+// Slice streams live in STREAM LANE ORDER for the serial kernels: 16-byte units [group][unit][lane], slice_cap/16 units
+// per slice (model_kernels.hip).  pack: that order -> payload (slices back to back, capacity payload_cap);
+// stage: payload -> that order.
+hipError_t launch_pack_payload(const Geometry& g, const uint8_t* d_units, const uint32_t* d_slice_len,
                                const uint64_t* d_offsets, uint8_t* d_payload, uint64_t payload_cap,
                                uint32_t* d_status, hipStream_t stream);
+hipError_t launch_stage_streams(const Geometry& g, const uint8_t* d_payload, uint64_t payload_bytes,
+                                const uint32_t* d_slice_len, const uint64_t* d_offsets, uint8_t* d_units,
+                                uint32_t* d_status, hipStream_t stream);
 // One lane per slice: range decoder + adaptive states + context model on reconstructed samples.
 // llcomp.hpp:91-127, 219-247, 486-530.  d_rec int16 in LANE ORDER.
-hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_payload, uint64_t payload_bytes,
-                                const uint32_t* d_slice_len, const uint64_t* d_offsets, uint64_t* d_states,
-                                int16_t* d_rec, uint32_t* d_status, hipStream_t stream);
+// d_units: the slices' streams in stream lane order (launch_stage_streams).
+hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_units, const uint32_t* d_slice_len,
+                                uint64_t* d_states, int16_t* d_rec, uint32_t* d_status, hipStream_t stream);
 
 }  // namespace llcomp_mi

@@ -98,15 +98,17 @@ struct RangeEnc {
     int32_t pos;      // bytes produced so far
     int32_t flushed;  // bytes already stored to HBM (multiple of 16)
     uint8_t* ring;    // this lane's 36-byte LDS slot
-    uint8_t* out;     // slice scratch in HBM, 16-byte aligned
+    uint8_t* out;     // this lane's first 16-byte unit in the stream lane order array
     int32_t cap;
+    uint32_t shift;   // lane_shift
 };
 constexpr int kRingStrideDwords = 9;
 __device__ __forceinline__ void enc_flush16(RangeEnc& e) {
     const uint32_t* w = reinterpret_cast<const uint32_t*>(e.ring + (uint32_t(e.flushed) & 16));
     uint4 v;
     v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
-    if (e.flushed + 16 <= e.cap) *reinterpret_cast<uint4*>(e.out + e.flushed) = v;
+    // stream lane order: unit u of this lane is (u << lane_shift) units further on
+    if (e.flushed + 16 <= e.cap) *reinterpret_cast<uint4*>(e.out + (size_t(uint32_t(e.flushed)) << e.shift)) = v;
     e.flushed += 16;
 }
 // rare: a run of undecided 0xFF bytes is resolved (llcomp.hpp:44-45, 49-50); called before `low` is shifted
@@ -225,8 +227,9 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     e.low = 0; e.range = 0xFF00; e.held = 0; e.pend = 0;  // llcomp.hpp:35 (held: see RangeEnc)
     e.pos = -1; e.flushed = 0;
     e.ring = reinterpret_cast<uint8_t*>(ring + kRingStrideDwords * threadIdx.x);
-    e.out = scratch + size_t(id) * g.slice_cap;
+    e.out = scratch + ((((size_t(id >> g.lane_shift) * (g.slice_cap >> 4)) << g.lane_shift) + (id & ((1u << g.lane_shift) - 1))) << 4);
     e.cap = int32_t(g.slice_cap);
+    e.shift = g.lane_shift;
     const uint32_t n_row = r.sw * NCH;  // samples per slice row
     // symbols in lane order: sample k of this slice is p0[k * GW]; the lanes of a group read one contiguous piece
     const SYM* p0 = sym + lane_order_index(g, id, 0);
@@ -311,16 +314,18 @@ struct RangeDec {
     int32_t nb;             // valid bytes in the window
     uint32_t nxt;           // prefetched dword that follows the window, RAW (masked only when it is appended, so the
     uint32_t nxt_mask;      //   load's latency is never waited for at the point of issue)
-    const uint32_t* words;  // aligned base: word k holds stream bytes [4k - skew, 4k - skew + 4)
-    uint32_t end;           // len + skew (0 when the slice is empty)
-    uint32_t kmax;          // last word that holds stream bytes
-    uint32_t kn;            // next word to prefetch
+    const uint32_t* words;  // this lane's first unit in the stream lane order array (launch_stage_streams)
+    uint32_t shift;         // lane_shift: dword k sits at words[((k >> 2) << (shift + 2)) + (k & 3)]
+    uint32_t end;           // stream length in bytes
+    uint32_t kmax;          // last dword that holds stream bytes
+    uint32_t kn;            // next dword to prefetch
 };
-// issues the load of word k and records the mask of its valid stream bytes.  The load is UNCONDITIONAL (index clamped
-// to the last word that holds stream bytes) so that its result lands directly in the loop-carried register; a
+// issues the load of dword k and records the mask of its valid stream bytes.  The load is UNCONDITIONAL (index clamped
+// to the last dword that holds stream bytes) so that its result lands directly in the loop-carried register; a
 // conditional load ends in a register copy, and hipcc waits vmcnt(0) for that copy right after the issue.
 __device__ __forceinline__ void dec_prefetch(RangeDec& d, uint32_t k) {
-    d.nxt = d.words[min(k, d.kmax)];
+    const uint32_t kc = min(k, d.kmax);
+    d.nxt = d.words[(size_t(kc >> 2) << (d.shift + 2)) + (kc & 3)];
     const int32_t nvalid = int32_t(d.end) - int32_t(k * 4);
     d.nxt_mask = nvalid >= 4 ? 0xFFFFFFFFu : (nvalid <= 0 ? 0u : (1u << (8 * nvalid)) - 1);
 }
@@ -339,15 +344,15 @@ __device__ __forceinline__ void dec_append(RangeDec& d) {  // requires nb <= 4
     d.nb += 4;
     dec_prefetch(d, d.kn++);
 }
-__device__ __forceinline__ void dec_open(RangeDec& d, const uint8_t* p, uint32_t len) {
-    const uint32_t skew = uint32_t(uintptr_t(p) & 3);
-    d.words = reinterpret_cast<const uint32_t*>(p - skew);
-    d.end = len ? len + skew : 0;
-    d.kmax = d.end ? (d.end - 1) >> 2 : 0;
+__device__ __forceinline__ void dec_open(RangeDec& d, const uint32_t* words, uint32_t shift, uint32_t len) {
+    d.words = words;
+    d.shift = shift;
+    d.end = len;
+    d.kmax = len ? (len - 1) >> 2 : 0;
     dec_prefetch(d, 0);
-    d.wlo = (d.nxt & d.nxt_mask) >> (8 * skew);
+    d.wlo = d.nxt & d.nxt_mask;
     d.whi = 0;
-    d.nb = int32_t(4 - skew);
+    d.nb = 4;
     dec_prefetch(d, 1);
     d.kn = 2;
     dec_append(d);
@@ -458,10 +463,8 @@ __device__ __forceinline__ bool dec_sample(RangeDec& d, uint32_t (&bank)[2], con
 
 template <int NCH, bool ROWS>
 __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const uint32_t lpw,
-                                                      const uint8_t* __restrict__ payload,
-                                                      const uint64_t payload_bytes,
+                                                      const uint8_t* __restrict__ units,
                                                       const uint32_t* __restrict__ slice_len,
-                                                      const uint64_t* __restrict__ offsets,
                                                       uint64_t* __restrict__ states, int16_t* __restrict__ rec,
                                                       uint32_t* status) {
     __shared__ entry_t tab[128];
@@ -470,13 +473,11 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
     if (threadIdx.x >= lpw || id >= g.n_slices) return;
     const SliceRect r = slice_rect(g, id);
     RangeDec d;
-    const uint64_t off = offsets[id];
-    uint64_t len = slice_len[id];
-    if (off + len > payload_bytes) {  // slice table promises more than the data holds
-        atomicOr(status, kStTruncated);
-        len = off < payload_bytes ? payload_bytes - off : 0;
-    }
-    dec_open(d, payload + ((len && off < payload_bytes) ? off : 0), uint32_t(len));  // empty slice: any readable word
+    // streams come staged in stream lane order; lengths beyond the payload were clipped (and reported) by the stager
+    const uint32_t len = min(slice_len[id], g.slice_cap);
+    dec_open(d, reinterpret_cast<const uint32_t*>(units) +
+                    ((((size_t(id >> g.lane_shift) * (g.slice_cap >> 4)) << g.lane_shift) + (id & ((1u << g.lane_shift) - 1))) << 2),
+             g.lane_shift, len);
 
     // reconstructed samples in lane order: sample k of this slice is p0[k * GW]
     int16_t* p0 = rec + lane_order_index(g, id, 0);
@@ -630,14 +631,13 @@ hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* 
     return hipGetLastError();
 }
 
-hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_payload, uint64_t payload_bytes,
-                                const uint32_t* d_slice_len, const uint64_t* d_offsets, uint64_t* d_states,
-                                int16_t* d_rec, uint32_t* d_status, hipStream_t stream) {
+hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_units, const uint32_t* d_slice_len,
+                                uint64_t* d_states, int16_t* d_rec, uint32_t* d_status, hipStream_t stream) {
     const uint32_t lpw = lanes_per_wave(g.n_slices);
     const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
     LLMI_DISPATCH_SLICE(g.nch, rows_mode(g),
                         (k_decode_slices<C, R><<<dim3(blocks), dim3(64), 0, stream>>>(
-                            g, lpw, d_payload, payload_bytes, d_slice_len, d_offsets, d_states, d_rec, d_status)));
+                            g, lpw, d_units, d_slice_len, d_states, d_rec, d_status)));
     return hipGetLastError();
 }
 
