@@ -31,7 +31,9 @@ out = {}
 for (k, c), v in fetch.items():
     if "llcomp_mi" not in k:
         continue
-    short = k.split("::")[-1].split("(")[0].split("<")[0]
+    import re
+    m = re.search(r"(k_[a-z_0-9]+)", k)
+    short = m.group(1) if m else k
     w = write.get((k, "WRITE_SIZE"), 0.0)
     out[short] = {"fetch_size_kib": v, "write_size_kib": w, "hbm_bytes_corrected": int(2 * v * 1024 + w * 1024)}
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
