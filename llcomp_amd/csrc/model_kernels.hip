@@ -468,7 +468,8 @@ template <int C>
 __global__ __launch_bounds__(256) void k_model_rows_fwd(const Geometry g, const uint8_t* __restrict__ px,
                                                         uint16_t* __restrict__ lanes) {
     constexpr int K = 64, RUN = (K + 2) * C, TPG = 64 / C + 2;
-    __shared__ uint8_t raw[TPG][RUN + 2];
+    constexpr int RUNW = (RUN + 3) / 4 + 1;  // dwords that cover a run at any byte alignment
+    __shared__ uint32_t raw[TPG][RUNW + 1];
     __shared__ RowTile tiles[TPG];
     const uint32_t chunks = (g.tile_w + K - 1) / K;
     const uint32_t group = blockIdx.x / chunks, k0 = (blockIdx.x - group * chunks) * K;
@@ -478,39 +479,52 @@ __global__ __launch_bounds__(256) void k_model_rows_fwd(const Geometry g, const 
     const uint32_t first_tile = first_id / C, ntiles = (end_id - 1) / C - first_tile + 1;
     load_row_tiles<C>(g, first_tile, ntiles, tiles);
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < ntiles * RUN; i += 256) {
-        const uint32_t tt = i / RUN, b = i - tt * RUN;
-        const int off = (int(k0) - 2) * C + int(b);  // byte offset from the tile's first pixel
-        raw[tt][b] = (off >= 0 && off < int(tiles[tt].sw) * C) ? px[tiles[tt].base + off] : uint8_t(0);
+    // stage the pixel runs [k0-2, k0+64) of every tile as aligned dwords (coalesced); consumers add the byte skew
+    const size_t total_bytes = size_t(g.frames) * g.h * g.w * C;
+    for (uint32_t i = threadIdx.x; i < ntiles * RUNW; i += 256) {
+        const uint32_t tt = i / RUNW, d = i - tt * RUNW;
+        const long long start = (long long)tiles[tt].base + (long long)(int(k0) - 2) * C;  // may be < 0 for the first run
+        const long long al = (start & ~3ll) + 4ll * d;
+        raw[tt][d] = (al >= 0 && size_t(al) + 4 <= ((total_bytes + 3) & ~size_t(3)))
+                         ? *reinterpret_cast<const uint32_t*>(px + al) : 0u;
     }
     __syncthreads();
-    const uint32_t j = threadIdx.x & 63;
+    const uint32_t j = threadIdx.x & 63, b = threadIdx.x >> 6;
     const uint32_t id = first_id + j;
     if (j >= gw || id >= end_id) return;
     const uint32_t tt = id / C - first_tile, ch = id - (id / C) * C;
     const uint32_t sw = tiles[tt].sw;
-    for (uint32_t kk = threadIdx.x >> 6; kk < uint32_t(K); kk += 4) {
-        const uint32_t k = k0 + kk;
-        if (k >= sw) break;
-        const uint8_t* p = &raw[tt][(kk + 2) * C];
+    const uint32_t skew = uint32_t(((long long)tiles[tt].base + (long long)(int(k0) - 2) * C) & 3);
+    const uint8_t* run = reinterpret_cast<const uint8_t*>(&raw[tt][0]) + skew;  // byte 0 = pixel k0-2
+    // this thread: samples k0 + 16*b + i, i = 0..15, walking left to right so l and L come from registers
+    const uint32_t kb = k0 + 16 * b;
+    if (kb >= sw) return;
+    const uint8_t* p = run + (16 * b + 2) * C;
+    int l = kb > 0 ? rct_channel<C>(p - C, ch) : 128;            // llcomp.hpp:417
+    int L = kb > 1 ? rct_channel<C>(p - 2 * C, ch) : l;          // llcomp.hpp:419
+    uint16_t* out = lanes + lane_order_index(g, id, kb);
+    const uint32_t n = sw - kb < 16 ? sw - kb : 16;
+    for (uint32_t i = 0; i < n; ++i, p += C) {
         const int cur = rct_channel<C>(p, ch);
-        const int l = k > 0 ? rct_channel<C>(p - C, ch) : 128;  // llcomp.hpp:417
-        const int L = k > 1 ? rct_channel<C>(p - 2 * C, ch) : l;  // llcomp.hpp:419
-        const int q = quant5(L - l);
+        const int Lq = (kb + i) > 1 ? L : l;
+        const int q = quant5(Lq - l);
         int res = cur - l;
         if (q < 0) res = -res;  // llcomp.hpp:433-436
         // 16-bit symbol of the fused path: bits 12..13 = |quant5| (context 0 / 605 / 1210), bits 0..11 = residual
-        lanes[lane_order_index(g, id, k)] = uint16_t(((q < 0 ? -q : q) << 12) | (res & 0xFFF));
+        out[size_t(i) << g.lane_shift] = uint16_t(((q < 0 ? -q : q) << 12) | (res & 0xFFF));
+        L = l;
+        l = cur;
     }
 }
 
 // Decode side: lane-order reconstructed samples -> pixels.  One block = the tiles whose FIRST channel plane lies in one
 // lane group x 64 samples; the other planes of the last tile may sit in the next group, hence 64 + C - 1 lanes.
+// Each thread turns 4 consecutive pixels into 4*C bytes and stores them as C (unaligned) dwords.
 template <int C>
 __global__ __launch_bounds__(256) void k_model_rows_inv(const Geometry g, const int16_t* __restrict__ lanes,
                                                         uint8_t* __restrict__ px) {
     constexpr int K = 64, TPG = 64 / C + 2;
-    __shared__ int16_t tile[K][64 + C + 1];
+    __shared__ __attribute__((aligned(4))) int16_t tile[K][64 + C + 1 + ((C + 1) & 1)];  // even row length: dword rows
     __shared__ RowTile tiles[TPG];
     const uint32_t chunks = (g.tile_w + K - 1) / K;
     const uint32_t group = blockIdx.x / chunks, k0 = (blockIdx.x - group * chunks) * K;
@@ -522,31 +536,64 @@ __global__ __launch_bounds__(256) void k_model_rows_inv(const Geometry g, const 
     if (first_tile >= end_tile) return;
     const uint32_t ntiles = end_tile - first_tile;
     load_row_tiles<C>(g, first_tile, ntiles, tiles);
-    const uint32_t lane0 = first_tile * C;                       // slice id held in LDS column 0
-    const uint32_t ncols = ntiles * C;
-    for (uint32_t i = threadIdx.x; i < uint32_t(K) * (64 + C - 1); i += 256) {
-        const uint32_t kk = i / (64 + C - 1), col = i - kk * (64 + C - 1);
-        const uint32_t id = lane0 + col, k = k0 + kk;
-        tile[kk][col] = (col < ncols && id < g.n_slices && k < g.tile_w) ? lanes[lane_order_index(g, id, k)] : int16_t(0);
+    // LDS column = lane index relative to this group (0..63), columns 64.. = first C-1 lanes of the NEXT group.
+    // Rows of this group are read as whole 128-byte pieces (32 dwords = 64 samples); the few extra lanes one by one.
+    for (uint32_t i = threadIdx.x; i < uint32_t(K) * 32; i += 256) {
+        const uint32_t kk = i >> 5, d = i & 31, k = k0 + kk;
+        uint32_t w = 0;
+        if (k < g.tile_w && g.lane_shift == 6)
+            w = *reinterpret_cast<const uint32_t*>(lanes + lane_order_index(g, first_id + 2 * d, k));
+        *reinterpret_cast<uint32_t*>(&tile[kk][2 * d]) = w;
+    }
+    if (g.lane_shift != 6) {  // fewer than 64 slices in total: narrow group, plain element loads
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < uint32_t(K) * gw; i += 256) {
+            const uint32_t kk = i / gw, col = i - kk * gw, k = k0 + kk;
+            tile[kk][col] = (first_id + col < g.n_slices && k < g.tile_w) ? lanes[lane_order_index(g, first_id + col, k)] : int16_t(0);
+        }
+    }
+    if constexpr (C > 1) {
+        for (uint32_t i = threadIdx.x; i < uint32_t(K) * (C - 1); i += 256) {
+            const uint32_t kk = i / (C - 1), e = i - kk * (C - 1), k = k0 + kk;
+            const uint32_t id = first_id + gw + e;
+            tile[kk][64 + e] = (id < g.n_slices && k < g.tile_w) ? lanes[lane_order_index(g, id, k)] : int16_t(0);
+        }
     }
     __syncthreads();
-    const uint32_t kk = threadIdx.x & 63, k = k0 + kk;
-    for (uint32_t tt = threadIdx.x >> 6; tt < ntiles; tt += 4) {
-        if (k >= tiles[tt].sw) continue;
-        const int16_t* s = &tile[kk][tt * C];
-        uint8_t* o = px + tiles[tt].base + size_t(k) * C;
-        if constexpr (C >= 3) {  // llcomp.hpp:532-543
-            int r = s[0], gg = s[1], b = s[2];
-            gg -= (r + b) / 4;
-            r += gg;
-            b += gg;
-            o[0] = uint8_t(min(max(r, 0), 255));
-            o[1] = uint8_t(min(max(gg, 0), 255));
-            o[2] = uint8_t(min(max(b, 0), 255));
-            if constexpr (C == 4) o[3] = uint8_t(s[3]);
-        } else {
+    const uint32_t col0 = first_tile * C - first_id;  // group-relative lane of the first tile's channel 0
+    const uint32_t q4 = threadIdx.x & 15;  // which group of 4 pixels of the 64-sample chunk
+    for (uint32_t tt = threadIdx.x >> 4; tt < ntiles; tt += 16) {
+        const uint32_t sw = tiles[tt].sw, kb = k0 + 4 * q4;
+        if (kb >= sw) continue;
+        uint8_t bytes[4 * C];
 #pragma unroll
-            for (int c = 0; c < C; ++c) o[c] = uint8_t(s[c]);
+        for (int i = 0; i < 4; ++i) {
+            const int16_t* s = &tile[4 * q4 + i][col0 + tt * C];
+            if constexpr (C >= 3) {  // llcomp.hpp:532-543
+                int r = s[0], gg = s[1], bb = s[2];
+                gg -= (r + bb) / 4;
+                r += gg;
+                bb += gg;
+                bytes[i * C + 0] = uint8_t(min(max(r, 0), 255));
+                bytes[i * C + 1] = uint8_t(min(max(gg, 0), 255));
+                bytes[i * C + 2] = uint8_t(min(max(bb, 0), 255));
+                if constexpr (C == 4) bytes[i * C + 3] = uint8_t(s[3]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) bytes[i * C + c] = uint8_t(s[c]);
+            }
+        }
+        uint8_t* o = px + tiles[tt].base + size_t(kb) * C;
+        const uint32_t npx = sw - kb < 4 ? sw - kb : 4;
+        if (npx == 4) {
+            uint32_t w[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                w[c] = uint32_t(bytes[4 * c]) | (uint32_t(bytes[4 * c + 1]) << 8) | (uint32_t(bytes[4 * c + 2]) << 16) |
+                       (uint32_t(bytes[4 * c + 3]) << 24);
+            __builtin_memcpy(o, w, 4 * C);  // pixel rows start at arbitrary byte offsets: unaligned dword stores
+        } else {
+            for (uint32_t i = 0; i < npx * C; ++i) o[i] = bytes[i];
         }
     }
 }
