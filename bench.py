@@ -4,8 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--content g3|g2|mid] [--tile-w TW --tile-h TH] [--interleaved]
 
 A "step" = one pass of the hot path over one batch: F frames of 3840x2160 RGB8 already resident in HBM are
-encoded into the sliced container payload (k_model_fwd -> k_encode_slices -> scan+pack) and decoded back
-(k_decode_slices -> k_model_inv); the round trip is verified bit-exact outside the timed region.
+encoded into the sliced container payload (stage A -> k_encode_slices -> scan + pack) and decoded back
+(stage streams -> k_decode_slices -> stage A inverse); the round trip is verified bit-exact outside the timed region.
+The frames of a step are split over --streams independent pipelines (codec object + HIP stream each) so that the
+memory-bound kernels of one overlap the issue-bound slice kernels of another.
 value = pixels coded / wall time, i.e. w*h / (t_enc + t_dec) per frame, whole job over all ranks.
 N > 1: launched by torch.distributed.run, one rank per GPU; frames are independent objects, so ranks shard
 frames with no data-path collective (weak scaling: F frames per rank).
@@ -80,6 +82,7 @@ def main():
     ap.add_argument("--tile-w", type=int, default=480)
     ap.add_argument("--tile-h", type=int, default=1)
     ap.add_argument("--interleaved", action="store_true", help="channels interleaved in one slice instead of per-channel planes")
+    ap.add_argument("--streams", type=int, default=2, help="split the frames of a step over this many HIP streams (codec objects)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -102,49 +105,71 @@ def main():
 
     planar = not args.interleaved
     F = args.frames
+    S = max(1, min(args.streams, F))
     frames_np = make_frames(args.content, F, rank)
     d_px = torch.from_numpy(frames_np).cuda()
-    codec = mi.Codec(F, W4K, H4K, C4K, args.tile_w, args.tile_h, planar, device=local_rank)
-    raw_bytes = frames_np.size
-    cap = min(codec.max_payload_bytes, 2 * raw_bytes + 64 * codec.n_slices + 4096)
-    d_pay = torch.empty(cap, dtype=torch.uint8, device="cuda")
-    d_len = torch.empty(codec.n_slices, dtype=torch.int32, device="cuda")
-    d_tot = torch.zeros(1, dtype=torch.int64, device="cuda")
-    d_st = torch.zeros(2, dtype=torch.int32, device="cuda")
     d_out = torch.empty_like(d_px)
-    stream = torch.cuda.current_stream().cuda_stream
+    raw_bytes = frames_np.size
+    # S independent pipelines (codec object + HIP stream each) over disjoint frame ranges: the memory-bound stage-A /
+    # pack / stage kernels of one overlap the issue-bound slice kernels of another
+    parts = []
+    lo = 0
+    for i in range(S):
+        n = F // S + (1 if i < F % S else 0)
+        codec = mi.Codec(n, W4K, H4K, C4K, args.tile_w, args.tile_h, planar, device=local_rank)
+        cap = min(codec.max_payload_bytes, 2 * n * W4K * H4K * C4K + 64 * codec.n_slices + 4096)
+        parts.append(dict(codec=codec, lo=lo, n=n, cap=cap, stream=torch.cuda.Stream() if S > 1 else torch.cuda.current_stream(),
+                          pay=torch.empty(cap, dtype=torch.uint8, device="cuda"), len=torch.empty(codec.n_slices, dtype=torch.int32, device="cuda"),
+                          tot=torch.zeros(1, dtype=torch.int64, device="cuda"), st=torch.zeros(2, dtype=torch.int32, device="cuda"), total=None))
+        lo += n
+    n_slices = sum(p["codec"].n_slices for p in parts)
 
-    def step(total_hint=None):
-        codec.encode(d_px.data_ptr(), d_pay.data_ptr(), cap, d_len.data_ptr(), d_tot.data_ptr(), d_st.data_ptr(), stream)
-        # decode needs the payload size on the host only as an upper bound for its bounds checks
-        codec.decode(d_pay.data_ptr(), total_hint if total_hint is not None else cap, d_len.data_ptr(), d_out.data_ptr(), d_st[1:].data_ptr(), stream)
+    def step():
+        for p in parts:
+            c, st = p["codec"], p["stream"].cuda_stream
+            px, out = d_px[p["lo"]:p["lo"] + p["n"]], d_out[p["lo"]:p["lo"] + p["n"]]
+            c.encode(px.data_ptr(), p["pay"].data_ptr(), p["cap"], p["len"].data_ptr(), p["tot"].data_ptr(), p["st"].data_ptr(), st)
+            # decode needs the payload size on the host only as an upper bound for its bounds checks
+            c.decode(p["pay"].data_ptr(), p["total"] if p["total"] is not None else p["cap"], p["len"].data_ptr(), out.data_ptr(), p["st"][1:].data_ptr(), st)
 
-    # first pass: learn the payload size, check status and the bit-exact round trip (outside the timed region)
+    def check():
+        torch.cuda.synchronize()
+        for p in parts:
+            assert int(p["st"][0].item()) == 0 and int(p["st"][1].item()) == 0, f"status {p['st'].tolist()}"
+        assert torch.equal(d_out, d_px), "round trip is not lossless"
+
+    # first pass: learn the payload sizes, check status and the bit-exact round trip (outside the timed region)
+    torch.cuda.synchronize()
     step()
-    torch.cuda.synchronize()
-    assert int(d_st[0].item()) == 0 and int(d_st[1].item()) == 0, f"status {d_st.tolist()}"
-    total = int(d_tot.item())
-    assert torch.equal(d_out, d_px), "round trip is not lossless"
+    check()
+    for p in parts:
+        p["total"] = int(p["tot"].item())
+    total = sum(p["total"] for p in parts)
     for _ in range(max(0, args.warmup - 1)):
-        step(total)
+        step()
     torch.cuda.synchronize()
 
-    codec.set_profiling(True)
-    codec.get_profile()
+    for p in parts:
+        p["codec"].set_profiling(True)
+        p["codec"].get_profile()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(total)
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    prof, n_enc, n_dec = codec.get_profile()
-    codec.set_profiling(False)
-    assert int(d_st[0].item()) == 0 and int(d_st[1].item()) == 0
-    assert torch.equal(d_out, d_px), "round trip is not lossless after the timed steps"
+    prof, n_enc, n_dec = {}, 0, 0
+    for p in parts:
+        pr, ne, nd = p["codec"].get_profile()
+        p["codec"].set_profiling(False)
+        for k, v in pr.items():
+            prof[k] = prof.get(k, 0.0) + v
+        n_enc, n_dec = n_enc + ne, n_dec + nd
+    check()
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -160,17 +185,18 @@ def main():
         pix_per_step = world * F * W4K * H4K
         value = pix_per_step * args.steps / dt / 1e6
         # roofline of the dominant kernel (algorithmic bytes of one coding direction = raw + stream)
+        # mean duration of ONE launch (a launch covers F/S frames); algorithmic bytes below are per launch as well
         k_enc = prof["k_encode_slices"] / max(1, n_enc)
         k_dec = prof["k_decode_slices"] / max(1, n_dec)
         dom, dom_ms = ("k_decode_slices", k_dec) if k_dec >= k_enc else ("k_encode_slices", k_enc)
-        stream_bytes = total + (24 + 4 * codec.n_slices // F) * F  # per-frame container headers + slice tables
-        algo = raw_bytes + stream_bytes
+        stream_bytes = total + 24 * F + 4 * n_slices  # per-frame container headers + slice tables
+        algo = (raw_bytes + stream_bytes) // S
         achieved = algo / (dom_ms * 1e-3) / 1e9
         traffic = None  # HBM-side bytes per launch from committed rocprofv3 PMC passes of THIS configuration
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_default_traffic.json")))
             same = all(tj["config"].get(k) == v for k, v in (("frames_per_step_per_gpu", F), ("tile_w", args.tile_w), ("tile_h", args.tile_h),
-                                                            ("planar", planar), ("content", args.content)))
+                                                            ("planar", planar), ("content", args.content), ("streams", S)))
             if same and world == 1:
                 traffic = tj["per_launch"][dom]["hbm_bytes_corrected"]
         except (OSError, KeyError, ValueError):
@@ -191,17 +217,17 @@ def main():
             "config": {
                 "workload": f"C3 3840x2160 RGB8 {args.content} ({'std::mt19937 noise' if args.content == 'g3' else args.content}), "
                             f"{F} frames/step/GPU resident in HBM, sliced container: {args.tile_w}x{args.tile_h} tiles, "
-                            f"{'per-channel planes' if planar else 'channels interleaved'}, {codec.n_slices // F} slices/frame",
+                            f"{'per-channel planes' if planar else 'channels interleaved'}, {n_slices // F} slices/frame, {S} stream(s)",
                 "frames_per_step_per_gpu": F, "tile_w": args.tile_w, "tile_h": args.tile_h, "planar": planar, "content": args.content,
-                "slices_per_frame": codec.n_slices // F,
-                "compression_ratio": round(world * raw_bytes / (total_all + world * (24 * F + 4 * codec.n_slices)), 4),
+                "slices_per_frame": n_slices // F, "streams": S,
+                "compression_ratio": round(world * raw_bytes / (total_all + world * (24 * F + 4 * n_slices)), 4),
                 "parallelism": f"frames sharded over {world} GPU(s), no data-path collective",
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(dom_ms, 4),
-                "note": "path is serial-dependency bound (one lane per slice), not HBM bound: see DESIGN.md",
+                "note": "path is serial-dependency / instruction-issue bound (one lane per slice), not HBM bound: DESIGN.md 4; launch durations are measured while the pipelines of the other stream(s) run beside them",
             },
             "kernel_ms_per_step": {k: round(v / max(1, args.steps), 4) for k, v in prof.items()},
         }
@@ -209,7 +235,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(args.content, args.tile_w, args.tile_h, planar)
             res["speedup_vs_cpu_baseline"] = round(value / res["cpu_baseline"]["value"], 1)
         print(json.dumps(res), flush=True)
-    codec.close()
+    for p in parts:
+        p["codec"].close()
     if world > 1:
         dist.destroy_process_group()
 
