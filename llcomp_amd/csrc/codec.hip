@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -195,6 +196,7 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
     if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Geometry& g = k->g;
+    if (slices_need_state_tables(g) && !k->need_states) return LLCOMP_MI_BAD_ARGS;  // kernel family changed under us
     HIP_TRY(hipMemsetAsync(d_status, 0, 4, s));
     {
         Timed t(k, s, 0);
@@ -233,6 +235,7 @@ int llcomp_mi_codec_decode(llcomp_mi_codec* k, const void* d_payload, uint64_t p
     if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Geometry& g = k->g;
+    if (slices_need_state_tables(g) && !k->need_states) return LLCOMP_MI_BAD_ARGS;  // kernel family changed under us
     HIP_TRY(hipMemsetAsync(d_status, 0, 4, s));
     {
         Timed t(k, s, 7);
@@ -294,6 +297,64 @@ int llcomp_mi_codec_get_profile(llcomp_mi_codec* k, double* ms8, uint32_t* n_enc
     return rc;
 }
 
+}  // extern "C"
+
+namespace {
+// The host-buffer calls need a codec object (GBs of workspace for a 4K frame) per call; allocating it every time costs
+// more than the coding.  A few idle ones are kept, keyed by device + geometry.  Never torn down at exit on purpose (the
+// HIP runtime may already be gone by then).
+struct CodecCache {
+    struct Item { llcomp_mi_codec* k; uint64_t stamp; };
+    std::mutex mu;
+    std::vector<Item> idle;
+    uint64_t clock = 0;
+    static constexpr size_t kMaxIdle = 4;
+    static constexpr uint64_t kMaxIdleBytes = 12ull << 30;
+
+    llcomp_mi_codec* take(int dev, const Geometry& g) {
+        std::lock_guard<std::mutex> lock(mu);
+        for (size_t i = 0; i < idle.size(); ++i)
+            if (idle[i].k->device == dev && std::memcmp(&idle[i].k->g, &g, sizeof(Geometry)) == 0 &&
+                idle[i].k->need_states == slices_need_state_tables(g)) {
+                llcomp_mi_codec* k = idle[i].k;
+                idle.erase(idle.begin() + long(i));
+                return k;
+            }
+        return nullptr;
+    }
+    void give(llcomp_mi_codec* k) {
+        std::vector<llcomp_mi_codec*> drop;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            idle.push_back({k, ++clock});
+            auto bytes = [&]() { uint64_t b = 0; for (auto& it : idle) b += it.k->workspace_bytes; return b; };
+            while (idle.size() > kMaxIdle || (idle.size() > 1 && bytes() > kMaxIdleBytes)) {
+                size_t oldest = 0;
+                for (size_t i = 1; i < idle.size(); ++i) if (idle[i].stamp < idle[oldest].stamp) oldest = i;
+                drop.push_back(idle[oldest].k);
+                idle.erase(idle.begin() + long(oldest));
+            }
+        }
+        for (auto* d : drop) llcomp_mi_codec_destroy(d);
+    }
+};
+CodecCache& codec_cache() {
+    static CodecCache* c = new CodecCache;  // leaked deliberately
+    return *c;
+}
+int acquire_codec(llcomp_mi_codec** out, int32_t device, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h,
+                  uint32_t planar) {
+    Geometry g;
+    if (!make_geometry(g, 1, w, h, c, tile_w, tile_h, planar)) return LLCOMP_MI_BAD_ARGS;
+    int dev = 0;
+    if (int rc = resolve_device(device, &dev)) return rc;
+    if ((*out = codec_cache().take(dev, g))) return LLCOMP_MI_OK;
+    return llcomp_mi_codec_create(out, dev, 1, w, h, c, tile_w, tile_h, planar);
+}
+}  // namespace
+
+extern "C" {
+
 // ---- host-buffer API --------------------------------------------------------------------------------------------
 int llcomp_mi_encode(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, const llcomp_mi_opts* opts, uint8_t** out,
                      size_t* out_len) {
@@ -318,7 +379,7 @@ int llcomp_mi_encode(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, cons
     const uint32_t planar = legacy ? 0 : (o.planar ? 1 : 0);
 
     llcomp_mi_codec* k = nullptr;
-    if (int rc = llcomp_mi_codec_create(&k, o.device, 1, w, h, c, tile_w, tile_h, planar)) return rc;
+    if (int rc = acquire_codec(&k, o.device, w, h, c, tile_w, tile_h, planar)) return rc;
     DeviceGuard guard(k->device);
     const Geometry& g = k->g;
     const uint64_t raw = uint64_t(w) * h * c;
@@ -332,7 +393,7 @@ int llcomp_mi_encode(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, cons
     int rc = LLCOMP_MI_OK;
     auto cleanup = [&]() {
         (void)hipFree(d_px); (void)hipFree(d_payload); (void)hipFree(d_len); (void)hipFree(d_total); (void)hipFree(d_status);
-        llcomp_mi_codec_destroy(k);
+        codec_cache().give(k);
     };
     auto fail = [&](int code) { cleanup(); std::free(host); return code; };
     if (hipMalloc(reinterpret_cast<void**>(&d_px), raw) != hipSuccess ||
@@ -349,7 +410,7 @@ int llcomp_mi_encode(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, cons
         rc = llcomp_mi_codec_encode(k, d_px, d_payload, cap, d_len, d_total, d_status, nullptr);
         if (rc) return fail(rc);
         uint32_t bits = 0;
-        if (hipDeviceSynchronize() != hipSuccess) return fail(LLCOMP_MI_HIP_ERROR);
+        if (hipStreamSynchronize(nullptr) != hipSuccess) return fail(LLCOMP_MI_HIP_ERROR);
         if (hipMemcpy(&bits, d_status, 4, hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(&total, d_total, 8, hipMemcpyDeviceToHost) != hipSuccess)
             return fail(LLCOMP_MI_HIP_ERROR);
@@ -387,8 +448,7 @@ int llcomp_mi_decode(const uint8_t* data, size_t len, int32_t device, uint8_t** 
     if (int rc = llcomp_mi_probe(data, len, &info)) return rc;
     if (!info.width || !info.height || info.channels < 1 || info.channels > 4) return LLCOMP_MI_BAD_ARGS;
     llcomp_mi_codec* k = nullptr;
-    if (int rc = llcomp_mi_codec_create(&k, device, 1, info.width, info.height, info.channels, info.tile_w, info.tile_h, info.planar))
-        return rc;
+    if (int rc = acquire_codec(&k, device, info.width, info.height, info.channels, info.tile_w, info.tile_h, info.planar)) return rc;
     DeviceGuard guard(k->device);
     const Geometry& g = k->g;
     const uint64_t raw = uint64_t(info.width) * info.height * info.channels;
@@ -400,7 +460,7 @@ int llcomp_mi_decode(const uint8_t* data, size_t len, int32_t device, uint8_t** 
     uint8_t* host = nullptr;
     auto cleanup = [&]() {
         (void)hipFree(d_px); (void)hipFree(d_payload); (void)hipFree(d_len); (void)hipFree(d_status);
-        llcomp_mi_codec_destroy(k);
+        codec_cache().give(k);
     };
     auto fail = [&](int code) { cleanup(); std::free(host); return code; };
     if (hipMalloc(reinterpret_cast<void**>(&d_px), raw) != hipSuccess ||
@@ -418,7 +478,7 @@ int llcomp_mi_decode(const uint8_t* data, size_t len, int32_t device, uint8_t** 
             return fail(LLCOMP_MI_HIP_ERROR);
     }
     if (int rc = llcomp_mi_codec_decode(k, d_payload, payload_bytes, d_len, d_px, d_status, nullptr)) return fail(rc);
-    if (hipDeviceSynchronize() != hipSuccess) return fail(LLCOMP_MI_HIP_ERROR);
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return fail(LLCOMP_MI_HIP_ERROR);
     uint32_t bits = 0;
     if (hipMemcpy(&bits, d_status, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(LLCOMP_MI_HIP_ERROR);
     if (int rc = status_from_bits(bits)) return fail(rc);

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""BASELINE config 5: a batch of 64 random 4K RGB8 frames streamed through encode -> decode from HOST memory,
+steady-state MPix/s (PCIe-inclusive, so NOT bench.py's `value`) and compression ratio vs the reference's whole-image
+ratio.  Two pipelines (codec + HIP stream + pinned staging each) alternate so that H2D / D2H copies of one batch run
+beside the kernels of the other.
+
+    python tools/stream_c5.py [--frames 64] [--batch 4] [--tile-w 480] [--content g3]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+W, H, C = 3840, 2160, 3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--tile-w", type=int, default=480)
+    ap.add_argument("--tile-h", type=int, default=1)
+    ap.add_argument("--content", default="g3")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct frames generated on the host (cycled)")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+
+    import llcomp_amd as mi
+    import orc as orc_mod
+
+    B = args.batch
+    nb = args.frames // B
+    src = np.stack([orc_mod.gen_g3(W, H, C, seed=1234 + i) if args.content == "g3" else orc_mod.gen_mid(W, H, C, seed=1234 + i) for i in range(args.distinct)])
+    host_in = [torch.from_numpy(np.stack([src[(b * B + i) % args.distinct] for i in range(B)])).pin_memory() for b in range(min(nb, args.distinct))]
+    raw = B * W * H * C
+
+    class Pipe:
+        def __init__(self):
+            self.codec = mi.Codec(B, W, H, C, args.tile_w, args.tile_h, True)
+            self.stream = torch.cuda.Stream()
+            self.cap = min(self.codec.max_payload_bytes, 2 * raw)
+            self.d_px = torch.empty((B, H, W, C), dtype=torch.uint8, device="cuda")
+            self.d_out = torch.empty_like(self.d_px)
+            self.d_pay = torch.empty(self.cap, dtype=torch.uint8, device="cuda")
+            self.d_pay2 = torch.empty(self.cap, dtype=torch.uint8, device="cuda")
+            self.d_len = torch.empty(self.codec.n_slices, dtype=torch.int32, device="cuda")
+            self.d_tot = torch.zeros(1, dtype=torch.int64, device="cuda")
+            self.d_st = torch.zeros(2, dtype=torch.int32, device="cuda")
+            self.h_pay = torch.empty(self.cap, dtype=torch.uint8).pin_memory()
+            self.h_len = torch.empty(self.codec.n_slices, dtype=torch.int32).pin_memory()
+            self.h_tot = torch.zeros(1, dtype=torch.int64).pin_memory()
+            self.h_out = torch.empty((B, H, W, C), dtype=torch.uint8).pin_memory()
+
+    pipes = [Pipe(), Pipe()]
+    stream_bytes = 0
+
+    def run_batch(p, b):
+        nonlocal stream_bytes
+        st = p.stream.cuda_stream
+        with torch.cuda.stream(p.stream):
+            p.d_px.copy_(host_in[b % len(host_in)], non_blocking=True)                       # H2D pixels
+            p.codec.encode(p.d_px.data_ptr(), p.d_pay.data_ptr(), p.cap, p.d_len.data_ptr(), p.d_tot.data_ptr(), p.d_st.data_ptr(), st)
+            p.h_tot.copy_(p.d_tot, non_blocking=True)
+            p.h_len.copy_(p.d_len, non_blocking=True)                                        # D2H slice table
+            p.stream.synchronize()                                                           # need the size on the host
+            total = int(p.h_tot.item())
+            p.h_pay[:total].copy_(p.d_pay[:total], non_blocking=True)                        # D2H payload = the "file"
+            # ... the container now lives on the host; read it back in and decode
+            p.d_pay2[:total].copy_(p.h_pay[:total], non_blocking=True)                       # H2D payload
+            p.codec.decode(p.d_pay2.data_ptr(), total, p.d_len.data_ptr(), p.d_out.data_ptr(), p.d_st[1:].data_ptr(), st)
+            p.h_out.copy_(p.d_out, non_blocking=True)                                        # D2H pixels
+        stream_bytes += total + 24 * B + 4 * p.codec.n_slices
+        return total
+
+    # warm-up = first batch on each pipe (also validates)
+    for i, p in enumerate(pipes):
+        run_batch(p, i)
+        p.stream.synchronize()
+        assert int(p.d_st[0].item()) == 0 and int(p.d_st[1].item()) == 0
+        assert torch.equal(p.h_out, host_in[i % len(host_in)]), "round trip through host memory is not lossless"
+    stream_bytes = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in range(nb):
+        run_batch(pipes[b % 2], b)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    frames = nb * B
+    res = {"config": f"C5: {frames} frames 3840x2160 RGB8 {args.content}, batches of {B}, 2 pipelines, planar {args.tile_w}x{args.tile_h} slices, host -> GPU -> host -> GPU -> host",
+           "end_to_end_MPix_s": round(frames * W * H / dt / 1e6, 1), "seconds": round(dt, 4),
+           "pcie_bytes_per_frame": int((2 * raw + 2 * stream_bytes / nb) / B),
+           "compression_ratio_sliced": round(frames * W * H * C / stream_bytes, 4),
+           "reference_whole_image_ratio_seed1234": 0.8026 if args.content == "g3" else None}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
