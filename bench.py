@@ -231,7 +231,7 @@ def main():
             },
             "kernel_ms_per_step": {k: round(v / max(1, args.steps), 4) for k, v in prof.items()},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU reference is timed at N=1 only
             res["cpu_baseline"] = cpu_baseline(args.content, args.tile_w, args.tile_h, planar)
             res["speedup_vs_cpu_baseline"] = round(value / res["cpu_baseline"]["value"], 1)
         print(json.dumps(res), flush=True)
