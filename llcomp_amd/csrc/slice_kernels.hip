@@ -449,11 +449,12 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, uint32_t (&bank)[2], c
 }
 
 // One sample: fast path first, checked replay when the window ran dry (or the fast path saw nonsense because of it).
-__device__ __forceinline__ bool dec_sample(RangeDec& d, uint32_t (&bank)[2], const entry_t* tab, bool hot, uint32_t& v) {
+__device__ __forceinline__ bool dec_sample(RangeDec& d, uint32_t (&bank)[2], const entry_t* tab, bool hot, bool replay_always,
+                                           uint32_t& v) {
     const uint32_t s_low = d.low, s_range = d.range, s_wlo = d.wlo, s_whi = d.whi, s_b0 = bank[0], s_b1 = bank[1];
     const int32_t s_nb = d.nb;
     bool ok = hot ? dec_residual<true, false>(d, bank, tab, v) : dec_residual<false, false>(d, bank, tab, v);
-    if (__builtin_expect(!ok || d.nb < 0, 0)) {
+    if (__builtin_expect(!ok || d.nb < 0 || replay_always, 0)) {
         d.low = s_low; d.range = s_range; d.wlo = s_wlo; d.whi = s_whi; d.nb = s_nb;
         bank[0] = s_b0; bank[1] = s_b1;
         ok = dec_residual<false, true>(d, bank, tab, v);
@@ -462,13 +463,15 @@ __device__ __forceinline__ bool dec_sample(RangeDec& d, uint32_t (&bank)[2], con
 }
 
 template <int NCH, bool ROWS>
-__global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const uint32_t lpw,
+__global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const uint32_t lpw_and_flags,
                                                       const uint8_t* __restrict__ units,
                                                       const uint32_t* __restrict__ slice_len,
                                                       uint64_t* __restrict__ states, int16_t* __restrict__ rec,
                                                       uint32_t* status) {
     __shared__ entry_t tab[128];
     load_table(tab);
+    const uint32_t lpw = lpw_and_flags & 0xFF;
+    const bool replay_always = (lpw_and_flags >> 8) & 1;  // test hook: send every sample through the checked replay too
     const uint32_t id = blockIdx.x * lpw + threadIdx.x;
     if (threadIdx.x >= lpw || id >= g.n_slices) return;
     const SliceRect r = slice_rect(g, id);
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 const bool c2 = aq > 3, c1 = aq > 0 && !c2;  // |quant5| == 2 / == 1
                 uint32_t bank[2] = {c2 ? B[2][0] : c1 ? B[1][0] : B[0][0], c2 ? B[2][1] : c1 ? B[1][1] : B[0][1]};
                 uint32_t v;
-                const bool ok = dec_sample(d, bank, tab, hot, v);
+                const bool ok = dec_sample(d, bank, tab, hot, replay_always, v);
                 if (!ok) {
                     atomicOr(status, kStBadExponent);
                     return;
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                     const uint64_t b64 = banks[ctx];
                     uint32_t bank[2] = {uint32_t(b64), uint32_t(b64 >> 32)};
                     uint32_t v;
-                    const bool ok = dec_sample(d, bank, tab, hot, v);
+                    const bool ok = dec_sample(d, bank, tab, hot, replay_always, v);
                     if (!ok) {
                         atomicOr(status, kStBadExponent);
                         return;  // this lane's slice is unusable; the whole call reports the error
@@ -635,9 +638,11 @@ hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_units, const
                                 uint64_t* d_states, int16_t* d_rec, uint32_t* d_status, hipStream_t stream) {
     const uint32_t lpw = lanes_per_wave(g.n_slices);
     const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
+    const char* fr = std::getenv("LLCOMP_MI_FORCE_REPLAY");  // tests: exercise the decoder's rollback + checked replay
+    const uint32_t arg = lpw | ((fr && fr[0] == '1') ? 0x100u : 0u);
     LLMI_DISPATCH_SLICE(g.nch, rows_mode(g),
                         (k_decode_slices<C, R><<<dim3(blocks), dim3(64), 0, stream>>>(
-                            g, lpw, d_units, d_slice_len, d_states, d_rec, d_status)));
+                            g, arg, d_units, d_slice_len, d_states, d_rec, d_status)));
     return hipGetLastError();
 }
 

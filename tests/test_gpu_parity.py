@@ -305,3 +305,20 @@ def test_one_row_slices_through_both_kernel_families(mi, orc, monkeypatch):
             s = mi.compress_image(img, 300, 9, 3, format=mi.FORMAT_SLICED, tile_w=70, tile_h=1, planar=planar)
             assert s == want
             assert np.array_equal(mi.decompress_image(s).pixels, img)
+
+
+def test_decoder_rollback_and_checked_replay(mi, orc, monkeypatch):
+    """The decoder's fast path never checks its input window; a sample that outruns the window is rolled back and
+    replayed with per-step refills.  That almost never happens on real data, so LLCOMP_MI_FORCE_REPLAY=1 sends EVERY
+    sample through rollback + replay: the pixels must not change.  Also a hostile-statistics image (long constant runs,
+    then maximal spikes) through the normal path."""
+    y, x, k = np.meshgrid(np.arange(24), np.arange(400), np.arange(3), indexing="ij")
+    spikes = np.where((x % 97 == 96) & (k != 1), 255, np.where((x % 2 == 0) & (k == 0), 128, 0)).astype(np.uint8)
+    for img in (make_image("g3", 160, 12, 3), make_image("mid", 160, 12, 3), spikes):
+        h, w, c = img.shape
+        for tw, th, planar in ((w, 1, True), (50, 1, False), (64, 8, True)):
+            want = orc.compress_sliced(img, tw, th, planar)
+            for force in ("0", "1"):
+                monkeypatch.setenv("LLCOMP_MI_FORCE_REPLAY", force)
+                assert mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar) == want
+                assert np.array_equal(mi.decompress_image(want).pixels, img)
