@@ -6,6 +6,7 @@
 // fresh adaptive state and slice-local border rules, so they are independent: one GPU lane each.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 
 #if defined(__HIPCC__)
 #define LLMI_HD __host__ __device__
@@ -55,6 +56,21 @@ LLMI_HD inline SliceRect slice_rect(const Geometry& g, uint32_t id) {
     return r;
 }
 
+// Width of a lane group = slices per wavefront.  A wavefront owns whole rows of the lane-order arrays (rows shared
+// between wavefronts on different XCDs are false sharing across non-coherent L2s: measured 2x slower), so the only
+// knob for "few slices" is a narrower group: full 64-lane groups as soon as that still gives >= kMinWaves wavefronts.
+// LLCOMP_MI_LANE_SHIFT overrides (tuning / tests).
+inline uint32_t default_lane_shift(uint32_t n_slices) {
+    if (const char* e = std::getenv("LLCOMP_MI_LANE_SHIFT")) {
+        const long v = std::strtol(e, nullptr, 10);
+        if (v >= 0 && v <= 6) return uint32_t(v);
+    }
+    constexpr uint32_t kMinWaves = 96;
+    uint32_t s = 6;
+    while (s > 0 && (n_slices >> s) < kMinWaves) --s;
+    return s;
+}
+
 inline bool make_geometry(Geometry& g, uint32_t frames, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w,
                           uint32_t tile_h, uint32_t planar) {
     if (!frames || !w || !h || c < 1 || c > 4) return false;
@@ -75,8 +91,7 @@ inline bool make_geometry(Geometry& g, uint32_t frames, uint32_t w, uint32_t h, 
     if (cap >= (1ull << 32)) return false;
     g.slice_cap = uint32_t(cap);
     g.slice_samples = tile_w * tile_h * g.nch;
-    g.lane_shift = 0;
-    while (g.lane_shift < 6 && (1u << g.lane_shift) < g.n_slices) ++g.lane_shift;
+    g.lane_shift = default_lane_shift(g.n_slices);
     return true;
 }
 

@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void k_model_rows_inv(const Geometry g, const 
     if (first_tile >= end_tile) return;
     const uint32_t ntiles = end_tile - first_tile;
     load_row_tiles<C>(g, first_tile, ntiles, tiles);
-    // LDS column = lane index relative to this group (0..63), columns 64.. = first C-1 lanes of the NEXT group.
+    // LDS column = lane index relative to this group (0..gw-1), columns gw.. = first C-1 lanes of the NEXT group.
     // Rows of this group are read as whole 128-byte pieces (32 dwords = 64 samples); the few extra lanes one by one.
     for (uint32_t i = threadIdx.x; i < uint32_t(K) * 32; i += 256) {
         const uint32_t kk = i >> 5, d = i & 31, k = k0 + kk;
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void k_model_rows_inv(const Geometry g, const 
         for (uint32_t i = threadIdx.x; i < uint32_t(K) * (C - 1); i += 256) {
             const uint32_t kk = i / (C - 1), e = i - kk * (C - 1), k = k0 + kk;
             const uint32_t id = first_id + gw + e;
-            tile[kk][64 + e] = (id < g.n_slices && k < g.tile_w) ? lanes[lane_order_index(g, id, k)] : int16_t(0);
+            tile[kk][gw + e] = (id < g.n_slices && k < g.tile_w) ? lanes[lane_order_index(g, id, k)] : int16_t(0);
         }
     }
     __syncthreads();

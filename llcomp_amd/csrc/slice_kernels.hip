@@ -583,17 +583,15 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
     }
 }
 
-// Slices per wavefront.  A slice is one serial chain, so with few slices the best use of the chip is one chain per
-// SIMD (256 CUs x 4 SIMDs): spread them over ~kTargetWaves wavefronts with few active lanes each; only once there
-// are more slices than that do wavefronts fill up to 64 lanes.  LLCOMP_MI_LPW overrides (tuning / tests).
-uint32_t lanes_per_wave(uint32_t n_slices) {
+// Slices per wavefront = width of a lane group (Geometry::lane_shift): a wavefront owns whole rows of the lane-order
+// arrays.  LLCOMP_MI_LPW can force fewer active lanes (tests).
+uint32_t lanes_per_wave(const Geometry& g) {
+    const uint32_t gw = 1u << g.lane_shift;
     if (const char* e = std::getenv("LLCOMP_MI_LPW")) {
         const long v = std::strtol(e, nullptr, 10);
-        if (v >= 1 && v <= 64) return uint32_t(v);
+        if (v >= 1 && v <= long(gw)) return uint32_t(v);
     }
-    constexpr uint32_t kTargetWaves = 256 * 4 * 2;
-    uint32_t lpw = (n_slices + kTargetWaves - 1) / kTargetWaves;
-    return lpw < 1 ? 1 : (lpw > 64 ? 64 : lpw);
+    return gw;
 }
 
 }  // namespace
@@ -621,7 +619,7 @@ bool slices_need_state_tables(const Geometry& g) { return !rows_mode(g); }
 
 hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* d_states, uint8_t* d_scratch,
                                 uint32_t* d_slice_len, uint32_t* d_status, hipStream_t stream) {
-    const uint32_t lpw = lanes_per_wave(g.n_slices);
+    const uint32_t lpw = lanes_per_wave(g);
     const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
     if (model_is_fused(g)) {  // planar 1-row slices: 16-bit symbols, always the register-resident kernel
         k_encode_slices<1, true, uint16_t><<<dim3(blocks), dim3(64), 0, stream>>>(
@@ -636,7 +634,7 @@ hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* 
 
 hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_units, const uint32_t* d_slice_len,
                                 uint64_t* d_states, int16_t* d_rec, uint32_t* d_status, hipStream_t stream) {
-    const uint32_t lpw = lanes_per_wave(g.n_slices);
+    const uint32_t lpw = lanes_per_wave(g);
     const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
     const char* fr = std::getenv("LLCOMP_MI_FORCE_REPLAY");  // tests: exercise the decoder's rollback + checked replay
     const uint32_t arg = lpw | ((fr && fr[0] == '1') ? 0x100u : 0u);
