@@ -1,58 +1,66 @@
-// llcompc -- compressor CLI with the reference's behaviour (/root/reference/llcompc.cpp:14-43): one positional image
-// path, writes <path>.llcomp, exit 1 on usage / load / open errors.  The image decoder is image_io.hpp (binary
-// PGM/PPM/PAM) because stb_image is neither vendored nor installed.  Default output is the reference's own format;
-// optional flags after the path select the parallel container:  --sliced TWxTH  [--interleaved]
-#include <fstream>
-#include <iostream>
+// llcompc <image> [--sliced TWxTH] [--interleaved]
+//
+// Compressor front end on libllcomp_mi.so with the observable behaviour of the reference tool
+// (/root/reference/llcompc.cpp:14-43): exactly one required positional argument, output written next to the input as
+// "<image>.llcomp", exit status 1 for usage, unreadable image or unwritable output, 0 otherwise.  stb_image is neither
+// vendored nor installed, so the image reader is tools/image_io.hpp (binary PGM / PPM / PAM).  Without options the
+// stream is the reference's own format; --sliced selects the parallel container.
+#include <cstdio>
+#include <exception>
 #include <string>
 #include <vector>
 
 #include "../include/llcomp_mi.hpp"
+#include "cli_common.hpp"
 #include "image_io.hpp"
 
-int main(int argc, char** argv) {
-    if (argc < 2) {
-        std::cerr << "Usage: " << argv[0] << " <image_path> [--sliced TWxTH] [--interleaved]" << std::endl;
-        return 1;
-    }
-    const char* filename = argv[1];
-    llcomp::Options opt;
+namespace {
+
+bool parse_flags(int argc, char** argv, llcomp::Options& opt) {
     for (int i = 2; i < argc; ++i) {
-        const std::string a = argv[i];
-        if (a == "--sliced" && i + 1 < argc) {
-            opt.sliced = true;
+        const std::string flag = argv[i];
+        if (flag == "--interleaved") {
+            opt.planar = false;
+        } else if (flag == "--sliced" && i + 1 < argc) {
             unsigned tw = 0, th = 0;
-            if (sscanf(argv[++i], "%ux%u", &tw, &th) != 2) {
-                std::cerr << "Usage: --sliced TWxTH" << std::endl;
-                return 1;
-            }
+            if (std::sscanf(argv[++i], "%ux%u", &tw, &th) != 2) return false;
+            opt.sliced = true;
             opt.tile_w = tw;
             opt.tile_h = th;
-        } else if (a == "--interleaved") {
-            opt.planar = false;
-        }
+        }  // anything else is ignored, as the reference ignores everything after its first argument
     }
-    int width, height, channels;
-    std::vector<uint8_t> rgb;
-    const std::string why = image_io::load_pnm(filename, rgb, width, height, channels);
-    if (!why.empty()) {
-        std::cerr << "Error loading image: " << why << std::endl;
-        return 1;
+    return true;
+}
+
+int compress_file(const std::string& image_path, const llcomp::Options& opt) {
+    std::vector<uint8_t> pixels;
+    int w = 0, h = 0, c = 0;
+    if (const std::string reason = image_io::load_pnm(image_path, pixels, w, h, c); !reason.empty()) {
+        std::fprintf(stderr, "Error loading image: %s\n", reason.c_str());
+        return cli::kFailed;
     }
-    std::vector<uint8_t> compressed;
+    std::vector<uint8_t> stream;
     try {
-        compressed = llcomp::compressImage(rgb, width, height, channels, opt);
-    } catch (const std::exception& e) {  // the reference has no failure mode here; the GPU path can (no device, ...)
-        std::cerr << "Error compressing image: " << e.what() << std::endl;
-        return 1;
+        stream = llcomp::compressImage(pixels, w, h, c, opt);
+    } catch (const std::exception& e) {  // no counterpart in the reference (its encoder cannot fail): no GPU, ...
+        std::fprintf(stderr, "Error compressing image: %s\n", e.what());
+        return cli::kFailed;
     }
-    std::string outputFile = std::string(filename) + llcomp::ext;
-    std::ofstream outFile(outputFile, std::ios::binary);
-    if (!outFile) {
-        std::cerr << "Error opening output file: " << outputFile << std::endl;
-        return 1;
+    const std::string target = image_path + llcomp::ext;
+    if (!cli::spill(target, stream)) {
+        std::fprintf(stderr, "Error opening output file: %s\n", target.c_str());
+        return cli::kFailed;
     }
-    outFile.write(reinterpret_cast<const char*>(compressed.data()), std::streamsize(compressed.size()));
-    outFile.close();
-    return 0;
+    return cli::kDone;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    llcomp::Options opt;
+    if (argc < 2 || !parse_flags(argc, argv, opt)) {
+        std::fprintf(stderr, "Usage: %s <image_path> [--sliced TWxTH] [--interleaved]\n", argc ? argv[0] : "llcompc");
+        return cli::kFailed;
+    }
+    return compress_file(argv[1], opt);
 }

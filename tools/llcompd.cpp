@@ -1,40 +1,50 @@
-// llcompd -- decompressor CLI with the reference's behaviour (/root/reference/llcompd.cpp:11-41): one positional
-// path, writes <path>.png, exit 1 on std::exception, 2 on anything else, and -- like the reference -- still 0 when
-// only the PNG write fails (llcompd.cpp:29-31).  PNG writing is image_io.hpp (stb_image_write is not available).
-#include <fstream>
-#include <iostream>
-#include <iterator>
+// llcompd <file.llcomp>
+//
+// Decompressor front end on libllcomp_mi.so with the observable behaviour of the reference tool
+// (/root/reference/llcompd.cpp:11-41): one positional argument, the picture is written as "<file>.png", exit status 1
+// when the input cannot be read or the stream is rejected with a std::exception (message printed), 2 for any other
+// exception, and -- faithfully -- still 0 when only writing the PNG failed (llcompd.cpp:29-31).  stb_image_write is not
+// available; tools/image_io.hpp writes the PNG (stored deflate blocks).  Reads both wire formats.
+#include <cstdio>
+#include <exception>
 #include <string>
 #include <vector>
 
 #include "../include/llcomp_mi.hpp"
+#include "cli_common.hpp"
 #include "image_io.hpp"
+
+namespace {
+
+int expand_file(const std::string& stream_path) {
+    std::vector<uint8_t> stream;
+    if (!cli::slurp(stream_path, stream)) {
+        std::fprintf(stderr, "Error opening input file: %s\n", stream_path.c_str());
+        return cli::kFailed;
+    }
+    llcomp::RawImage picture;
+    try {
+        picture = llcomp::decompressImage(stream);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "Error decompressing image: %s\n", e.what());
+        return cli::kFailed;
+    } catch (...) {
+        std::fprintf(stderr, "Unknown error occurred\n");
+        return cli::kUnknown;
+    }
+    const std::string target = stream_path + ".png";
+    const int row_bytes = int(picture.width) * picture.channels;
+    if (!image_io::write_png(target, int(picture.width), int(picture.height), picture.channels, picture.pixels.data(), row_bytes))
+        std::fprintf(stderr, "Error writing output file: %s\n", target.c_str());  // not an error status in the reference
+    return cli::kDone;
+}
+
+}  // namespace
 
 int main(int argc, char** argv) {
     if (argc < 2) {
-        std::cerr << "Usage: " << argv[0] << " <image_path>" << std::endl;
-        return 1;
+        std::fprintf(stderr, "Usage: %s <image_path>\n", argc ? argv[0] : "llcompd");
+        return cli::kFailed;
     }
-    const char* filename = argv[1];
-    std::ifstream inFile(filename, std::ios::binary);
-    if (!inFile) {
-        std::cerr << "Error opening input file: " << filename << std::endl;
-        return 1;
-    }
-    std::vector<uint8_t> compressed((std::istreambuf_iterator<char>(inFile)), std::istreambuf_iterator<char>());
-    inFile.close();
-    try {
-        auto [pixels, width, height, channels] = llcomp::decompressImage(compressed);
-        std::string outputFile = std::string(filename) + ".png";
-        if (!image_io::write_png(outputFile, int(width), int(height), channels, pixels.data(), int(width) * channels)) {
-            std::cerr << "Error writing output file: " << outputFile << std::endl;
-        }
-    } catch (const std::exception& e) {
-        std::cerr << "Error decompressing image: " << e.what() << std::endl;
-        return 1;
-    } catch (...) {
-        std::cerr << "Unknown error occurred" << std::endl;
-        return 2;
-    }
-    return 0;
+    return expand_file(argv[1]);
 }
