@@ -371,13 +371,17 @@ __device__ __forceinline__ bool dec_core(RangeDec& d, uint32_t P) {  // llcomp.h
     if (CHECKED && d.nb <= 0) dec_append(d);
     const uint32_t r1 = __umul24(d.range, P) >> 8;
     const uint32_t r0 = d.range - r1;
-    const bool bit = d.low >= r0;
-    d.low = min(d.low, d.low - r0);  // unsigned: low - r0 wraps above low exactly when low < r0
-    d.range = bit ? r1 : r0;
+    uint32_t diff;
+    const bool under = __builtin_usub_overflow(d.low, r0, &diff);  // one v_sub_co: difference and the decision
+    const bool bit = !under;
+    d.low = under ? d.low : diff;
+    d.range = under ? r0 : r1;
     const bool need = d.range < 0x100;
     const uint32_t sh = need ? 8u : 0u;
     d.range <<= sh;
-    d.low = (d.low << sh) | (d.wlo & (need ? 0xFFu : 0u));
+    // low < range < 0x100 when a byte is shifted in, so (low << 8) | byte is a byte permute: [next byte, low.b0, 0, 0]
+    const uint32_t shifted = __builtin_amdgcn_perm(d.low, d.wlo, 0x0C0C0400u);
+    d.low = need ? shifted : d.low;
     d.wlo = __builtin_amdgcn_alignbit(d.whi, d.wlo, sh);
     d.whi >>= sh;
     d.nb -= need ? 1 : 0;
@@ -409,18 +413,19 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, uint32_t (&bank)[2], c
             if (dec_once<3, CHECKED>(d, bank, E)) {
                 ex = 3;
                 entry_t cur = E.e4;
-                uint32_t P = prob_of(cur), ns;
+                uint32_t nx = uint32_t(cur) >> 8;  // byte 1 = probability of the current state (entry_lo byte 2)
                 bool b;
                 do {
-                    b = dec_core<CHECKED>(d, P);
-                    const uint32_t nx = successor(cur, b);
-                    ns = nx & 0xFF;
-                    P = byte_of(nx, 1);
-                    cur = tab[ns];
+                    b = dec_core<CHECKED>(d, (nx >> 8) & 0xFF);
+                    nx = successor(cur, b);
+                    cur = tab[nx & 0xFF];
                     ex += b ? 1 : 0;
-                    if (ex > 31) { ok = false; b = false; }
+                    if (CHECKED && ex > 31) { ok = false; b = false; }
                 } while (b);
-                set_slot_state<4>(bank, ns);
+                // fast path: no per-step limit -- the run ends by itself once the window holds only zeros; a run
+                // longer than 31 is "Invalid exponent" (llcomp.hpp:230-235) and is confirmed by the checked replay
+                if (!CHECKED && ex > 31) ok = false;
+                set_slot_state<4>(bank, nx & 0xFF);
             }
         }
     }
@@ -430,17 +435,15 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, uint32_t (&bank)[2], c
         v += v + uint32_t(dec_once<5, CHECKED>(d, bank, E));
         if (ex > 1) {
             entry_t cur = E.e6;
-            uint32_t P = prob_of(cur), ns;
-            int j = ex - 1;
+            uint32_t nx = uint32_t(cur) >> 8;
+            const uint32_t limit = 1u << ex;  // v has ex + 1 significant bits when the mantissa is complete
             do {
-                const bool b = dec_core<CHECKED>(d, P);
-                const uint32_t nx = successor(cur, b);
-                ns = nx & 0xFF;
-                P = byte_of(nx, 1);
-                cur = tab[ns];
+                const bool b = dec_core<CHECKED>(d, (nx >> 8) & 0xFF);
+                nx = successor(cur, b);
+                cur = tab[nx & 0xFF];
                 v += v + uint32_t(b);
-            } while (--j > 0);
-            set_slot_state<6>(bank, ns);
+            } while (v < limit);
+            set_slot_state<6>(bank, nx & 0xFF);
         }
     }
     if (dec_once<7, CHECKED>(d, bank, E)) v = 0u - v;
