@@ -122,32 +122,38 @@ __device__ __forceinline__ void enc_fill(RangeEnc& e) {
 }
 // Renormalisation (body of the reference's `while (range < 0x100)`: one step always suffices because range >= 7 after
 // put() and == 0xFF in finish()).  ONE exec-masked region for the lanes that renormalise; inside it the three cases of
-// llcomp.hpp:40-54 are selects: every such lane writes one LDS byte -- the leaving byte (held + carry) into the ring when
-// it flushes, into its spare byte when the new byte is still undecided (0xFF00 < low < 0x10000).
+// llcomp.hpp:40-54 are arithmetic on an all-ones / zero mask.  Every such lane writes the would-be leaving byte
+// (held + carry) at ring[pos]; when the new byte is still undecided (0xFF00 < low < 0x10000) `pos` simply does not move,
+// so that slot is overwritten before it can ever be flushed.
 __device__ __forceinline__ void enc_renorm(RangeEnc& e) {
     if (e.range < 0x100) {
-        const bool undecided = e.low - 0xFF01u < 0xFFu;
-        e.ring[undecided ? 32u : (uint32_t(e.pos) & 31)] = uint8_t(e.held + (e.low >> 16));
-        e.pos += undecided ? 0 : 1;
-        if (__builtin_expect(!undecided && e.pend != 0, 0)) enc_fill(e);
-        e.held = undecided ? e.held : (e.low >> 8) & 0xFF;
-        e.pend += undecided ? 1 : 0;
+        const uint32_t und = (e.low - 0xFF01u < 0xFFu) ? 0xFFFFFFFFu : 0u;  // undecided
+        e.ring[uint32_t(e.pos) & 31] = uint8_t(e.held + (e.low >> 16));
+        e.pos += 1 + int32_t(und);
+        if (__builtin_expect(und == 0 && e.pend != 0, 0)) enc_fill(e);
+        e.held = (e.held & und) | (((e.low >> 8) & 0xFF) & ~und);
+        e.pend -= und;
         e.low = (e.low & 0xFF) << 8;
         e.range <<= 8;
     }
 }
-__device__ __forceinline__ void enc_core(RangeEnc& e, uint32_t P, bool bit) {  // llcomp.hpp:60-73
+// `m` = all ones when the coded bit is 1, zero when it is 0 (llcomp.hpp:60-73)
+__device__ __forceinline__ void enc_core(RangeEnc& e, uint32_t P, uint32_t m) {
     const uint32_t r1 = __umul24(e.range, P) >> 8;
     const uint32_t r0 = e.range - r1;
-    e.low += bit ? r0 : 0u;
-    e.range = bit ? r1 : r0;
+    e.low += r0 & m;
+    e.range = (r1 & m) | (r0 & ~m);  // v_bfi_b32
     enc_renorm(e);
 }
+__device__ __forceinline__ uint32_t successor_m(entry_t e, uint32_t m) {  // successor() on a mask
+    return (uint32_t(e >> 32) & m) | (uint32_t(e) & ~m);
+}
+__device__ __forceinline__ uint32_t ones_if(bool b) { return b ? 0xFFFFFFFFu : 0u; }
 // a slot that is coded at most once per sample
 template <int SLOT>
-__device__ __forceinline__ void enc_once(RangeEnc& e, uint32_t (&bank)[2], const Entries& E, bool bit) {
-    enc_core(e, prob_of(E.get<SLOT>()), bit);
-    set_slot_state<SLOT>(bank, next_state(E.get<SLOT>(), bit));
+__device__ __forceinline__ void enc_once(RangeEnc& e, uint32_t (&bank)[2], const Entries& E, uint32_t m) {
+    enc_core(e, prob_of(E.get<SLOT>()), m);
+    set_slot_state<SLOT>(bank, successor_m(E.get<SLOT>(), m) & 0xFF);
 }
 
 // putSymbol<true,4,6,7> (llcomp.hpp:166-206).  All lanes walk the phases together, so the slot of every bin is a
@@ -157,50 +163,46 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, uint32_t (&bank)[2], c
     Entries E;
     fetch_slot0(E, bank, tab);
     if (ALL) fetch_rest(E, bank, tab);
-    enc_once<0>(e, bank, E, res == 0);
+    enc_once<0>(e, bank, E, ones_if(res == 0));
     if (res != 0) {
         if (!ALL) fetch_rest(E, bank, tab);
         const uint32_t a = uint32_t(res < 0 ? -res : res);
         const int ex = 31 - __clz(int(a));
-        enc_once<1>(e, bank, E, ex > 0);
+        enc_once<1>(e, bank, E, ones_if(ex > 0));
         if (ex > 0) {
-            enc_once<2>(e, bank, E, ex > 1);
+            enc_once<2>(e, bank, E, ones_if(ex > 1));
             if (ex > 1) {
-                enc_once<3>(e, bank, E, ex > 2);
-                if (ex > 2) {  // unary tail on slot 4
+                enc_once<3>(e, bank, E, ones_if(ex > 2));
+                if (ex > 2) {  // unary tail on slot 4: (ex - 3) ones, then a zero
                     entry_t cur = E.e4;
-                    uint32_t P = prob_of(cur), ns;
-                    int i = 3;
-                    bool b;
+                    uint32_t nx = uint32_t(cur) >> 8;  // byte 1 = probability of the current state
+                    int left = ex - 3;
+                    uint32_t m;
                     do {
-                        b = ex > i;
-                        enc_core(e, P, b);
-                        const uint32_t nx = successor(cur, b);
-                        ns = nx & 0xFF;
-                        P = byte_of(nx, 1);
-                        cur = tab[ns];
-                        ++i;
-                    } while (b);
-                    set_slot_state<4>(bank, ns);
+                        m = uint32_t((0 - left) >> 31);  // ones while left > 0
+                        enc_core(e, (nx >> 8) & 0xFF, m);
+                        nx = successor_m(cur, m);
+                        cur = tab[nx & 0xFF];
+                        left += int32_t(m);
+                    } while (m);
+                    set_slot_state<4>(bank, nx & 0xFF);
                 }
             }
-            enc_once<5>(e, bank, E, (a >> (ex - 1)) & 1);
-            if (ex > 1) {  // mantissa tail on slot 6
+            enc_once<5>(e, bank, E, uint32_t(__builtin_amdgcn_sbfe(int(a), uint32_t(ex - 1), 1u)));
+            if (ex > 1) {  // mantissa tail on slot 6, MSB first
                 entry_t cur = E.e6;
-                uint32_t P = prob_of(cur), ns;
+                uint32_t nx = uint32_t(cur) >> 8;
                 int i = ex - 2;
                 do {
-                    const bool b = (a >> i) & 1;
-                    enc_core(e, P, b);
-                    const uint32_t nx = successor(cur, b);
-                    ns = nx & 0xFF;
-                    P = byte_of(nx, 1);
-                    cur = tab[ns];
+                    const uint32_t m = uint32_t(__builtin_amdgcn_sbfe(int(a), uint32_t(i), 1u));
+                    enc_core(e, (nx >> 8) & 0xFF, m);
+                    nx = successor_m(cur, m);
+                    cur = tab[nx & 0xFF];
                 } while (--i >= 0);
-                set_slot_state<6>(bank, ns);
+                set_slot_state<6>(bank, nx & 0xFF);
             }
         }
-        enc_once<7>(e, bank, E, res < 0);
+        enc_once<7>(e, bank, E, uint32_t(res >> 31));
     }
 }
 
