@@ -61,13 +61,13 @@ def compress_image(rgb, width, height, channels, *, format=FORMAT_LEGACY, tile_w
 def decompress_image(data, *, device=-1):
     """RawImage(pixels: np.uint8[h,w,c], width, height, channels) from either wire format."""
     L = _lib.load()
-    data = bytes(data)
-    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data or b"\0")
+    data = bytes(data)  # no copy when it already is bytes
+    src = C.cast(C.c_char_p(data or b"\0"), _lib.u8p)  # borrows the bytes object's buffer for the call
     px, w, h, c = _lib.u8p(), C.c_uint32(), C.c_uint32(), C.c_uint32()
-    _check(L.llcomp_mi_decode(C.cast(buf, _lib.u8p), len(data), device, C.byref(px), C.byref(w), C.byref(h), C.byref(c)))
+    _check(L.llcomp_mi_decode(src, len(data), device, C.byref(px), C.byref(w), C.byref(h), C.byref(c)))
     try:
         n = w.value * h.value * c.value
-        pixels = np.frombuffer(C.string_at(px, n), dtype=np.uint8).reshape(h.value, w.value, c.value)
+        pixels = np.ctypeslib.as_array(px, shape=(max(n, 1),))[:n].copy().reshape(h.value, w.value, c.value)
     finally:
         L.llcomp_mi_free(px)
     return RawImage(pixels, w.value, h.value, c.value)
