@@ -273,6 +273,10 @@ __device__ __forceinline__ void load_group_streams(const Geometry& g, uint32_t g
                 atomicOr(status, err_bit);
                 n = err_bit == kStOverflow ? 0u : (o < limit ? uint32_t(limit - o) : 0u);
             }
+            if (n > g.slice_cap) {  // no valid stream is longer than the proven bound: damaged slice table
+                atomicOr(status, err_bit);
+                n = g.slice_cap;
+            }
         }
         gs.off[threadIdx.x] = o;
         gs.len[threadIdx.x] = n;

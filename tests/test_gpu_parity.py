@@ -322,3 +322,35 @@ def test_decoder_rollback_and_checked_replay(mi, orc, monkeypatch):
                 monkeypatch.setenv("LLCOMP_MI_FORCE_REPLAY", force)
                 assert mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar) == want
                 assert np.array_equal(mi.decompress_image(want).pixels, img)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_damaged_sliced_containers_never_crash(mi, orc, seed):
+    """Valid header, damaged slice table and/or payload: the call must either decode (to whatever the bits say) or
+    raise LlcompError -- never fault.  Truncation and over-long table entries must be reported."""
+    rng = np.random.default_rng(4000 + seed)
+    w, h, c = int(rng.integers(8, 90)), int(rng.integers(1, 30)), int(rng.integers(1, 5))
+    tw, th = int(rng.integers(1, w + 1)), int(rng.integers(1, min(h, 9) + 1))
+    planar = bool(rng.integers(0, 2))
+    img = rng.integers(0, 256, size=(h, w, c), dtype=np.uint8)
+    good = bytearray(orc.compress_sliced(img, tw, th, planar))
+    n = int.from_bytes(good[20:24], "little")
+    kind = seed % 4
+    bad = bytearray(good)
+    if kind == 0:      # random payload, table intact
+        bad[24 + 4 * n:] = rng.integers(0, 256, size=len(bad) - 24 - 4 * n, dtype=np.uint8).tobytes()
+    elif kind == 1:    # one table entry claims far too much
+        k = int(rng.integers(0, n))
+        bad[24 + 4 * k:28 + 4 * k] = (0x7FFFFFF0).to_bytes(4, "little")
+    elif kind == 2:    # payload cut short
+        bad = bad[: 24 + 4 * n + max(0, (len(bad) - 24 - 4 * n) // 2)]
+    else:              # random table
+        bad[24:24 + 4 * n] = rng.integers(0, 2000, size=n, dtype=np.uint32).astype("<u4").tobytes()
+    try:
+        out = mi.decompress_image(bytes(bad))
+        assert out.pixels.shape == (h, w, c)
+        assert kind == 0 or kind == 3, "a truncated container must not decode silently"
+    except mi.LlcompError as e:
+        assert e.status in (mi.TRUNCATED, mi.BAD_EXPONENT, mi.BAD_ARGS)
+    # and the good one still decodes afterwards (codec cache state is clean)
+    assert np.array_equal(mi.decompress_image(bytes(good)).pixels, img)
