@@ -354,3 +354,12 @@ def test_damaged_sliced_containers_never_crash(mi, orc, seed):
         assert e.status in (mi.TRUNCATED, mi.BAD_EXPONENT, mi.BAD_ARGS)
     # and the good one still decodes afterwards (codec cache state is clean)
     assert np.array_equal(mi.decompress_image(bytes(good)).pixels, img)
+
+
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
+def test_batch_codec_fused_rows_all_channel_counts(mi, orc, c):
+    """Planar 1-row slices go through the fused stage-A kernels and 16-bit symbols; tiles straddle lane-group
+    boundaries differently for every channel count, widths are ragged, several frames per call."""
+    _batch_roundtrip(mi, orc, 3, 250, 11, c, 70, 1, True, ["g3", "mid", "g1"])
+    _batch_roundtrip(mi, orc, 2, 131, 40, c, 131, 1, True, ["mid", "checker"])
+    _batch_roundtrip(mi, orc, 2, 97, 5, c, 16, 1, False, ["g3", "g2"])  # interleaved rows: register kernels, u32 symbols
