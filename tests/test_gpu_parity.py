@@ -363,3 +363,15 @@ def test_batch_codec_fused_rows_all_channel_counts(mi, orc, c):
     _batch_roundtrip(mi, orc, 3, 250, 11, c, 70, 1, True, ["g3", "mid", "g1"])
     _batch_roundtrip(mi, orc, 2, 131, 40, c, 131, 1, True, ["mid", "checker"])
     _batch_roundtrip(mi, orc, 2, 97, 5, c, 16, 1, False, ["g3", "g2"])  # interleaved rows: register kernels, u32 symbols
+
+
+@pytest.mark.parametrize("shift", ["0", "2", "5"])
+def test_lane_group_width_does_not_change_bytes(mi, orc, shift, monkeypatch):
+    """Lane groups narrower than 64 (few slices, or forced here) change every HBM layout but not a single byte."""
+    monkeypatch.setenv("LLCOMP_MI_LANE_SHIFT", shift)
+    img = make_image("g3", 190, 21, 3)
+    img[:, 90:] = make_image("mid", 100, 21, 3)
+    for tw, th, planar in ((45, 1, True), (45, 1, False), (32, 8, True), (190, 21, False)):
+        s = mi.compress_image(img, 190, 21, 3, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar)
+        assert s == orc.compress_sliced(img, tw, th, planar)
+        assert np.array_equal(mi.decompress_image(s).pixels, img)
