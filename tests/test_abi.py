@@ -59,13 +59,21 @@ def test_no_cpu_fallback(mi):
 
 
 def test_product_never_imports_oracle():
-    for dp, _, files in os.walk(os.path.join(ROOT, "llcomp_amd")):
-        for f in files:
-            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
-                src = open(os.path.join(dp, f)).read()
-                assert "liborc" not in src and "oracle/" not in src.replace("oracle/_ref", "") or f == "__init__.py" and "oracle" not in src, f
-    for f in ("include/llcomp_mi.h",):
-        assert "liborc" not in open(os.path.join(ROOT, f)).read()
+    """The oracle is test infrastructure: nothing under llcomp_amd/, include/ or tools/ may load, link or name it."""
+    banned = ("liborc", "llcomp_oracle", "libllcomp_ref", "oracle/", "import orc", "from orc")
+    roots = [os.path.join(ROOT, d) for d in ("llcomp_amd", "include")] + [os.path.join(ROOT, "tools", f) for f in ("llcompc.cpp", "llcompd.cpp", "image_io.hpp", "cli_common.hpp", "Makefile")]
+    files = []
+    for r in roots:
+        if os.path.isdir(r):
+            for dp, _, fs in os.walk(r):
+                files += [os.path.join(dp, f) for f in fs if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")) or f == "Makefile"]
+        else:
+            files.append(r)
+    assert files
+    for f in files:
+        src = open(f).read()
+        for word in banned:
+            assert word not in src, f"{f} mentions {word!r}"
 
 
 def test_probe_and_error_strings(mi, orc):
