@@ -378,15 +378,16 @@ __device__ __forceinline__ bool dec_core(RangeDec& d, uint32_t P) {  // llcomp.h
     const bool bit = !under;
     d.low = under ? d.low : diff;
     d.range = under ? r0 : r1;
-    const bool need = d.range < 0x100;
-    const uint32_t sh = need ? 8u : 0u;
-    d.range <<= sh;
-    // low < range < 0x100 when a byte is shifted in, so (low << 8) | byte is a byte permute: [next byte, low.b0, 0, 0]
-    const uint32_t shifted = __builtin_amdgcn_perm(d.low, d.wlo, 0x0C0C0400u);
-    d.low = need ? shifted : d.low;
-    d.wlo = __builtin_amdgcn_alignbit(d.whi, d.wlo, sh);
-    d.whi >>= sh;
-    d.nb -= need ? 1 : 0;
+    // Refill inside ONE exec-masked region with constant shift amounts.  (Measured on gfx950, tools/ubench: shifts by a
+    // register, v_cndmask with an SGPR mask, v_perm, v_alignbit, v_cmp all take 4 cycles per wavefront, plain
+    // add/sub/and/or/mov and shifts by a constant take 2; the branch-free form of this block cost eight 4-cycle ops.)
+    if (d.range < 0x100) {
+        d.range <<= 8;
+        d.low = (d.low << 8) | (d.wlo & 0xFF);  // low < range < 0x100 here
+        d.wlo = (d.wlo >> 8) | (d.whi << 24);
+        d.whi >>= 8;
+        d.nb -= 1;
+    }
     return bit;
 }
 template <int SLOT, bool CHECKED>
@@ -438,7 +439,10 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, uint32_t (&bank)[2], c
         if (ex > 1) {
             entry_t cur = E.e6;
             uint32_t nx = uint32_t(cur) >> 8;
-            const uint32_t limit = 1u << ex;  // v has ex + 1 significant bits when the mantissa is complete
+            // v has ex + 1 significant bits when the mantissa is complete.  `limit` is hidden from the optimiser, which
+            // would otherwise turn `v < limit` into a shift by a register + compare (two 4-cycle ops per step).
+            uint32_t limit = 1u << ex;
+            asm volatile("" : "+v"(limit));
             do {
                 const bool b = dec_core<CHECKED>(d, (nx >> 8) & 0xFF);
                 nx = successor(cur, b);
