@@ -121,18 +121,19 @@ __device__ __forceinline__ void enc_fill(RangeEnc& e) {
     }
 }
 // Renormalisation (body of the reference's `while (range < 0x100)`: one step always suffices because range >= 7 after
-// put() and == 0xFF in finish()).  ONE exec-masked region for the lanes that renormalise; inside it the three cases of
-// llcomp.hpp:40-54 are arithmetic on an all-ones / zero mask.  Every such lane writes the would-be leaving byte
-// (held + carry) at ring[pos]; when the new byte is still undecided (0xFF00 < low < 0x10000) `pos` simply does not move,
-// so that slot is overwritten before it can ever be flushed.
+// put() and == 0xFF in finish()).  One exec-masked region for the lanes that renormalise.  Its common path (the new byte
+// is decided: llcomp.hpp:42-51) is straight-line code made of 2-cycle operations; the two rare cases -- the byte is
+// still undecided, 0xFF00 < low < 0x10000 (llcomp.hpp:52-54), and a run of such bytes being resolved -- are branches.
 __device__ __forceinline__ void enc_renorm(RangeEnc& e) {
     if (e.range < 0x100) {
-        const uint32_t und = (e.low - 0xFF01u < 0xFFu) ? 0xFFFFFFFFu : 0u;  // undecided
-        e.ring[uint32_t(e.pos) & 31] = uint8_t(e.held + (e.low >> 16));
-        e.pos += 1 + int32_t(und);
-        if (__builtin_expect(und == 0 && e.pend != 0, 0)) enc_fill(e);
-        e.held = (e.held & und) | (((e.low >> 8) & 0xFF) & ~und);
-        e.pend -= und;
+        if (__builtin_expect(e.low - 0xFF01u < 0xFFu, 0)) {
+            ++e.pend;
+        } else {
+            e.ring[uint32_t(e.pos) & 31] = uint8_t(e.held + (e.low >> 16));  // held + carry
+            ++e.pos;
+            if (__builtin_expect(e.pend != 0, 0)) enc_fill(e);
+            e.held = (e.low >> 8) & 0xFF;
+        }
         e.low = (e.low & 0xFF) << 8;
         e.range <<= 8;
     }
@@ -145,8 +146,10 @@ __device__ __forceinline__ void enc_core(RangeEnc& e, uint32_t P, uint32_t m) {
     e.range = (r1 & m) | (r0 & ~m);  // v_bfi_b32
     enc_renorm(e);
 }
-__device__ __forceinline__ uint32_t successor_m(entry_t e, uint32_t m) {  // successor() on a mask
-    return (uint32_t(e >> 32) & m) | (uint32_t(e) & ~m);
+__device__ __forceinline__ uint32_t successor_m(entry_t e, uint32_t m) {  // successor() on a mask: ONE v_bfi_b32
+    uint32_t r;  // (hipcc splits the bit-select into not/and/and/or when both halves are live: four ops instead of one)
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(uint32_t(e >> 32)), "v"(uint32_t(e)));
+    return r;
 }
 __device__ __forceinline__ uint32_t ones_if(bool b) { return b ? 0xFFFFFFFFu : 0u; }
 // a slot that is coded at most once per sample
@@ -192,13 +195,15 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, uint32_t (&bank)[2], c
             if (ex > 1) {  // mantissa tail on slot 6, MSB first
                 entry_t cur = E.e6;
                 uint32_t nx = uint32_t(cur) >> 8;
-                int i = ex - 2;
+                // remaining mantissa bits left-aligned, followed by a sentinel 1: the loop needs no counter
+                uint32_t bits = ((a << 1) | 1u) << (32 - ex);
                 do {
-                    const uint32_t m = uint32_t(__builtin_amdgcn_sbfe(int(a), uint32_t(i), 1u));
+                    const uint32_t m = uint32_t(int32_t(bits) >> 31);
+                    bits <<= 1;
                     enc_core(e, (nx >> 8) & 0xFF, m);
                     nx = successor_m(cur, m);
                     cur = tab[nx & 0xFF];
-                } while (--i >= 0);
+                } while (bits != 0x80000000u);
                 set_slot_state<6>(bank, nx & 0xFF);
             }
         }
