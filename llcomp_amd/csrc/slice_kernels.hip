@@ -143,7 +143,7 @@ __device__ __forceinline__ void enc_core(RangeEnc& e, uint32_t P, uint32_t m) {
     const uint32_t r1 = __umul24(e.range, P) >> 8;
     const uint32_t r0 = e.range - r1;
     e.low += r0 & m;
-    e.range = (r1 & m) | (r0 & ~m);  // v_bfi_b32
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(e.range) : "v"(m), "v"(r1), "v"(r0));  // m ? r1 : r0 (see successor_m)
     enc_renorm(e);
 }
 __device__ __forceinline__ uint32_t successor_m(entry_t e, uint32_t m) {  // successor() on a mask: ONE v_bfi_b32
