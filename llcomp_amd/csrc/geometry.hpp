@@ -87,7 +87,7 @@ inline bool make_geometry(Geometry& g, uint32_t frames, uint32_t w, uint32_t h, 
     g.slices_per_frame = uint32_t(spf);
     g.n_slices = uint32_t(spf * frames);
     g.nch = g.planar ? 1 : c;
-    const uint64_t cap = (uint64_t(tile_w) * tile_h * g.nch * 13 + 16 + 15) & ~15ull;
+    const uint64_t cap = (uint64_t(tile_w) * tile_h * g.nch * 13 + 32 + 15) & ~15ull;  // 13 B/sample bound + slack
     if (cap >= (1ull << 32)) return false;
     g.slice_cap = uint32_t(cap);
     g.slice_samples = tile_w * tile_h * g.nch;

@@ -273,9 +273,9 @@ __device__ __forceinline__ void load_group_streams(const Geometry& g, uint32_t g
                 atomicOr(status, err_bit);
                 n = err_bit == kStOverflow ? 0u : (o < limit ? uint32_t(limit - o) : 0u);
             }
-            if (n > g.slice_cap) {  // no valid stream is longer than the proven bound: damaged slice table
+            if (n > g.slice_cap - 16) {  // no valid stream is longer than the proven bound: damaged slice table
                 atomicOr(status, err_bit);
-                n = g.slice_cap;
+                n = g.slice_cap - 16;
             }
         }
         gs.off[threadIdx.x] = o;
@@ -334,7 +334,8 @@ __global__ __launch_bounds__(256) void k_stage_streams(const Geometry g, const u
     load_group_streams(g, group, slice_len, off, payload_bytes, status, kStTruncated, gs);
     const uint32_t cap16 = g.slice_cap >> 4;
     const uint32_t a = threadIdx.x & 63, b = threadIdx.x >> 6;
-    for (uint32_t c0 = 0; c0 * 256 < gs.max_len; ++c0) {
+    // "+ 4": the dword right behind every stream is staged too (as zeros) -- the decoder clamps its reads to it
+    for (uint32_t c0 = 0; c0 * 256 < gs.max_len + 4; ++c0) {
         for (uint32_t j = b; j < 64; j += 4) {
             const uint32_t n = gs.len[j], p = c0 * 256 + a * 4;
             uint32_t w = 0;

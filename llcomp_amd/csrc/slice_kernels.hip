@@ -319,22 +319,20 @@ struct RangeDec {
     uint32_t low, range;
     uint32_t wlo, whi;      // window, LSB first; bits above `nb` bytes are zero
     int32_t nb;             // valid bytes in the window
-    uint32_t nxt;           // prefetched dword that follows the window, RAW (masked only when it is appended, so the
-    uint32_t nxt_mask;      //   load's latency is never waited for at the point of issue)
-    const uint32_t* words;  // this lane's first unit in the stream lane order array (launch_stage_streams)
-    uint32_t shift;         // lane_shift: dword k sits at words[((k >> 2) << (shift + 2)) + (k & 3)]
-    uint32_t end;           // stream length in bytes
-    uint32_t kmax;          // last dword that holds stream bytes
+    uint32_t nxt;           // prefetched dword that follows the window
+    const uint32_t* group;  // WAVE-UNIFORM: first dword of this lane group in the stream lane order array
+    uint32_t lane_dw;       // this lane's dword offset inside a row of units (lane * 4)
+    uint32_t shift;         // lane_shift: dword k sits at group[((k >> 2) << (shift + 2)) + lane_dw + (k & 3)]
+    uint32_t kmax1;         // first dword AFTER the stream; the stager guarantees it (and every byte past the end
+                            // of the stream inside the last dword) reads zero, as llcomp.hpp:475-479 wants
     uint32_t kn;            // next dword to prefetch
 };
-// issues the load of dword k and records the mask of its valid stream bytes.  The load is UNCONDITIONAL (index clamped
-// to the last dword that holds stream bytes) so that its result lands directly in the loop-carried register; a
-// conditional load ends in a register copy, and hipcc waits vmcnt(0) for that copy right after the issue.
+// issues the load of dword k.  UNCONDITIONAL (index clamped to the zero dword behind the stream) so that its result
+// lands directly in the loop-carried register -- a conditional load ends in a register copy and hipcc waits vmcnt(0)
+// for that copy right after the issue; 32-bit offset from a wave-uniform base = one global_load with an SGPR base.
 __device__ __forceinline__ void dec_prefetch(RangeDec& d, uint32_t k) {
-    const uint32_t kc = min(k, d.kmax);
-    d.nxt = d.words[(size_t(kc >> 2) << (d.shift + 2)) + (kc & 3)];
-    const int32_t nvalid = int32_t(d.end) - int32_t(k * 4);
-    d.nxt_mask = nvalid >= 4 ? 0xFFFFFFFFu : (nvalid <= 0 ? 0u : (1u << (8 * nvalid)) - 1);
+    const uint32_t kc = min(k, d.kmax1);
+    d.nxt = d.group[(((kc >> 2) << d.shift) << 2) + d.lane_dw + (kc & 3)];
 }
 // Pins the point where a value that was loaded earlier is consumed: the compiler's s_waitcnt for it lands HERE (the
 // load was issued a whole sample ago, so it has long returned) and no later load may be hoisted above it -- otherwise
@@ -343,21 +341,22 @@ __device__ __forceinline__ uint32_t consume_here(uint32_t v) {
     asm volatile("" : "+v"(v) : : "memory");
     return v;
 }
-__device__ __forceinline__ void dec_append(RangeDec& d) {  // requires nb <= 4
+__device__ __forceinline__ void dec_append(RangeDec& d) {  // requires 0 <= nb <= 4
     const uint32_t ready = consume_here(d.nxt);
-    const uint64_t w = (uint64_t(ready & d.nxt_mask) << (8 * d.nb)) | (uint64_t(d.whi) << 32) | d.wlo;
-    d.wlo = uint32_t(w);
-    d.whi = uint32_t(w >> 32);
+    // window |= ready << (8 * nb), in 32-bit pieces (a 64-bit shift by a register is several 4-cycle ops)
+    const uint32_t sh = 8u * uint32_t(d.nb);                 // 0, 8, 16, 24 or 32
+    d.wlo |= sh < 32 ? ready << sh : 0u;
+    d.whi |= (ready >> 1) >> (31 - (sh & 31)) | (sh == 32 ? ready : 0u);  // sh == 0 gives 0; sh == 32: whole dword
     d.nb += 4;
     dec_prefetch(d, d.kn++);
 }
-__device__ __forceinline__ void dec_open(RangeDec& d, const uint32_t* words, uint32_t shift, uint32_t len) {
-    d.words = words;
+__device__ __forceinline__ void dec_open(RangeDec& d, const uint32_t* group, uint32_t lane_dw, uint32_t shift, uint32_t len) {
+    d.group = group;
+    d.lane_dw = lane_dw;
     d.shift = shift;
-    d.end = len;
-    d.kmax = len ? (len - 1) >> 2 : 0;
+    d.kmax1 = (len + 3) >> 2;
     dec_prefetch(d, 0);
-    d.wlo = d.nxt & d.nxt_mask;
+    d.wlo = d.nxt;
     d.whi = 0;
     d.nb = 4;
     dec_prefetch(d, 1);
@@ -490,15 +489,19 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
     if (threadIdx.x >= lpw || id >= g.n_slices) return;
     const SliceRect r = slice_rect(g, id);
     RangeDec d;
-    // streams come staged in stream lane order; lengths beyond the payload were clipped (and reported) by the stager
-    const uint32_t len = min(slice_len[id], g.slice_cap);
-    dec_open(d, reinterpret_cast<const uint32_t*>(units) +
-                    ((((size_t(id >> g.lane_shift) * (g.slice_cap >> 4)) << g.lane_shift) + (id & ((1u << g.lane_shift) - 1))) << 2),
-             g.lane_shift, len);
+    // streams come staged in stream lane order; lengths beyond the payload were clipped (and reported) by the stager.
+    // All lanes of a wavefront belong to one lane group (lanes_per_wave divides the group width): its base is uniform.
+    const uint32_t len = min(slice_len[id], g.slice_cap - 16);
+    const uint32_t grp = __builtin_amdgcn_readfirstlane(id >> g.lane_shift);
+    const uint32_t lane_in_group = id & ((1u << g.lane_shift) - 1);
+    dec_open(d, reinterpret_cast<const uint32_t*>(units) + ((size_t(grp) * (g.slice_cap >> 4)) << (g.lane_shift + 2)),
+             lane_in_group * 4, g.lane_shift, len);
 
     // reconstructed samples in lane order: sample k of this slice is p0[k * GW]
     int16_t* p0 = rec + lane_order_index(g, id, 0);
     const ptrdiff_t GW = ptrdiff_t(1) << g.lane_shift;  // distance between consecutive samples of this slice
+    // the same through a wave-uniform base + 32-bit element offset (one store instruction, no 64-bit address math)
+    int16_t* const gbase = rec + ((size_t(grp) * g.slice_samples) << g.lane_shift);
     bool hot = false;
 
     if constexpr (ROWS) {
@@ -508,13 +511,15 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
         int l[NCH], L[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) l[k] = L[k] = 128;
-        int held_val = 0;           // the previous sample: stored only AFTER the window top-up of the next one, so the
-        int16_t* held_at = nullptr; // top-up never waits for a store that was issued a moment ago (see the encoder)
+        // The previous sample is stored only AFTER the window top-up of the next one, so the top-up never waits for a
+        // store that was issued a moment ago (see the encoder).  The very first store is a dummy to sample 0's own slot.
+        int held_val = 0;
+        uint32_t held_off = lane_in_group;
         for (uint32_t x = 0; x < r.sw; ++x) {
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 if (d.nb <= 4) dec_append(d);
-                if (held_at) *held_at = int16_t(held_val);
+                gbase[held_off] = int16_t(held_val);
                 const int lv = l[k];                 // x == 0: 128
                 const int Lv = x > 1 ? L[k] : lv;    // llcomp.hpp:496
                 const int dq = Lv - lv;
@@ -536,12 +541,12 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 if (neg) v = 0u - v;
                 const int val = int(int16_t(uint32_t(lv) + v));
                 held_val = val;
-                held_at = p0 + (ptrdiff_t(x) * NCH + k) * GW;
+                held_off = ((x * NCH + uint32_t(k)) << g.lane_shift) + lane_in_group;
                 L[k] = lv;
                 l[k] = val;
             }
         }
-        if (held_at) *held_at = int16_t(held_val);
+        gbase[held_off] = int16_t(held_val);
     } else {
         // Neighbours of the row above rotate through registers (tl <- t <- tr); the two values the NEXT pixel needs
         // from memory (top-right, top-top) are loaded while the current one decodes.
@@ -601,9 +606,13 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
 // arrays.  LLCOMP_MI_LPW can force fewer active lanes (tests).
 uint32_t lanes_per_wave(const Geometry& g) {
     const uint32_t gw = 1u << g.lane_shift;
-    if (const char* e = std::getenv("LLCOMP_MI_LPW")) {
+    if (const char* e = std::getenv("LLCOMP_MI_LPW")) {  // rounded down to a power of two: a wavefront never straddles groups
         const long v = std::strtol(e, nullptr, 10);
-        if (v >= 1 && v <= long(gw)) return uint32_t(v);
+        if (v >= 1) {
+            uint32_t p = 1;
+            while (p * 2 <= uint32_t(v) && p * 2 <= gw) p *= 2;
+            return p;
+        }
     }
     return gw;
 }
