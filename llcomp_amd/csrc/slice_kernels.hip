@@ -88,6 +88,14 @@ __device__ __forceinline__ void fetch_rest(Entries& E, const uint32_t (&bank)[2]
     E.e7 = tab[slot_state<7>(bank)];
 }
 
+// tab[nx & 0xFF] with the byte extraction and the scaling in ONE SDWA shift (hipcc emits v_and + v_lshl next to inline asm)
+__device__ __forceinline__ entry_t entry_at(const entry_t* tab, uint32_t nx) {
+    uint32_t off;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
+        : "=v"(off) : "v"(3u), "v"(nx));
+    return *reinterpret_cast<const entry_t*>(reinterpret_cast<const char*>(tab) + off);
+}
+
 // ================================================ ENCODER ========================================================
 // Range encoder of one lane (llcomp.hpp:33-89).  Output bytes are staged in a per-lane LDS slot of 36 bytes (32-byte
 // ring + 4 spare; 9-dword stride = conflict-free) and leave for HBM as aligned 16-byte stores.  `pos` starts at -1:
@@ -95,6 +103,7 @@ __device__ __forceinline__ void fetch_rest(Entries& E, const uint32_t (&bank)[2]
 // -1 instead, which is the same thing without the special case.
 struct RangeEnc {
     uint32_t low, range, held, pend;
+    uint32_t calm;    // ~0 while pend == 0, 0 while a run of undecided bytes is open
     int32_t pos;      // bytes produced so far
     int32_t flushed;  // bytes already stored to HBM (multiple of 16)
     uint8_t* ring;    // this lane's 36-byte LDS slot
@@ -114,6 +123,7 @@ __device__ __forceinline__ void enc_flush16(RangeEnc& e) {
 // rare: a run of undecided 0xFF bytes is resolved (llcomp.hpp:44-45, 49-50); called before `low` is shifted
 __device__ __forceinline__ void enc_fill(RangeEnc& e) {
     const uint32_t fill = (e.low >> 16) ? 0x00u : 0xFFu;
+#pragma nounroll
     for (; e.pend; --e.pend) {
         if (e.pos - e.flushed >= 16) enc_flush16(e);
         e.ring[uint32_t(e.pos) & 31] = uint8_t(fill);
@@ -126,12 +136,27 @@ __device__ __forceinline__ void enc_fill(RangeEnc& e) {
 // still undecided, 0xFF00 < low < 0x10000 (llcomp.hpp:52-54), and a run of such bytes being resolved -- are branches.
 __device__ __forceinline__ void enc_renorm(RangeEnc& e) {
     if (e.range < 0x100) {
-        if (__builtin_expect(e.low - 0xFF01u < 0xFFu, 0)) {
-            ++e.pend;
+        // ONE test for both rare cases: `calm` is all ones while no undecided run is open and zero while one is, so the
+        // masked difference is < 0xFF exactly when this byte is undecided or a run is waiting to be resolved.
+        const uint32_t und = e.low - 0xFF01u;
+        if (__builtin_expect((und & e.calm) < 0xFFu, 0)) {
+            if (und < 0xFFu) {
+                ++e.pend;
+                e.calm = 0;
+            } else {
+                // (same as the common path below; `lw` is opaque so that hipcc does not merge the two copies and then
+                // pay for the merge with register moves on the common path)
+                uint32_t lw = e.low;
+                asm volatile("" : "+v"(lw), "+v"(e.pos));
+                e.ring[uint32_t(e.pos) & 31] = uint8_t(e.held + (lw >> 16));
+                e.pos -= -1;
+                enc_fill(e);
+                e.calm = ~0u;
+                e.held = (lw >> 8) & 0xFF;
+            }
         } else {
             e.ring[uint32_t(e.pos) & 31] = uint8_t(e.held + (e.low >> 16));  // held + carry
             ++e.pos;
-            if (__builtin_expect(e.pend != 0, 0)) enc_fill(e);
             e.held = (e.low >> 8) & 0xFF;
         }
         e.low = (e.low & 0xFF) << 8;
@@ -151,12 +176,43 @@ __device__ __forceinline__ uint32_t successor_m(entry_t e, uint32_t m) {  // suc
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(uint32_t(e >> 32)), "v"(uint32_t(e)));
     return r;
 }
-__device__ __forceinline__ uint32_t ones_if(bool b) { return b ? 0xFFFFFFFFu : 0u; }
-// a slot that is coded at most once per sample
+// One bin of a run on one slot (unary tail, mantissa tail): codes the top bit of `bits`, shifts `bits` left and returns
+// the half of entry `cur` that belongs to the coded bit.  The shift is an add with carry-out, so the bit arrives in VCC
+// and the three selects are 2-cycle v_cndmask_e32 (a mask in a VGPR costs a 4-cycle v_bfi per select).
+__device__ __forceinline__ uint32_t enc_step_msb(RangeEnc& e, uint32_t P, uint32_t& bits, entry_t cur) {
+    const uint32_t r1 = __umul24(e.range, P) >> 8;
+    const uint32_t r0 = e.range - r1;
+    uint32_t add, nx;
+    asm("v_add_co_u32_e32 %[bits], vcc, %[bits], %[bits]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e32 %[add], 0, %[r0], vcc\n\t"
+        "v_cndmask_b32_e32 %[range], %[r0], %[r1], vcc\n\t"
+        "v_cndmask_b32_e32 %[nx], %[lo], %[hi], vcc"
+        : [bits] "+v"(bits), [add] "=&v"(add), [range] "=&v"(e.range), [nx] "=v"(nx)
+        : [r0] "v"(r0), [r1] "v"(r1), [lo] "v"(uint32_t(cur)), [hi] "v"(uint32_t(cur >> 32))
+        : "vcc");
+    e.low += add;
+    enc_renorm(e);
+    return nx;
+}
+// a slot that is coded at most once per sample; the bit as a mask (all ones / zero) ...
 template <int SLOT>
-__device__ __forceinline__ void enc_once(RangeEnc& e, uint32_t (&bank)[2], const Entries& E, uint32_t m) {
+__device__ __forceinline__ void enc_once_m(RangeEnc& e, uint32_t (&bank)[2], const Entries& E, uint32_t m) {
     enc_core(e, prob_of(E.get<SLOT>()), m);
     set_slot_state<SLOT>(bank, successor_m(E.get<SLOT>(), m) & 0xFF);
+}
+// ... or as a condition the caller branches on anyway: its compare leaves the bit in VCC, and all three selects are
+// issued before the renormalisation region so that they stay 2-cycle v_cndmask_e32
+template <int SLOT>
+__device__ __forceinline__ void enc_once(RangeEnc& e, uint32_t (&bank)[2], const Entries& E, bool bit) {
+    const entry_t en = E.get<SLOT>();
+    const uint32_t r1 = __umul24(e.range, prob_of(en)) >> 8;
+    const uint32_t r0 = e.range - r1;
+    e.low += bit ? r0 : 0u;
+    e.range = bit ? r1 : r0;
+    const uint32_t ns = successor(en, bit);
+    enc_renorm(e);
+    set_slot_state<SLOT>(bank, ns & 0xFF);
 }
 
 // putSymbol<true,4,6,7> (llcomp.hpp:166-206).  All lanes walk the phases together, so the slot of every bin is a
@@ -166,48 +222,42 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, uint32_t (&bank)[2], c
     Entries E;
     fetch_slot0(E, bank, tab);
     if (ALL) fetch_rest(E, bank, tab);
-    enc_once<0>(e, bank, E, ones_if(res == 0));
+    enc_once<0>(e, bank, E, res == 0);
     if (res != 0) {
         if (!ALL) fetch_rest(E, bank, tab);
         const uint32_t a = uint32_t(res < 0 ? -res : res);
         const int ex = 31 - __clz(int(a));
-        enc_once<1>(e, bank, E, ones_if(ex > 0));
+        enc_once<1>(e, bank, E, ex > 0);
         if (ex > 0) {
-            enc_once<2>(e, bank, E, ones_if(ex > 1));
+            enc_once<2>(e, bank, E, ex > 1);
             if (ex > 1) {
-                enc_once<3>(e, bank, E, ones_if(ex > 2));
+                enc_once<3>(e, bank, E, ex > 2);
                 if (ex > 2) {  // unary tail on slot 4: (ex - 3) ones, then a zero
                     entry_t cur = E.e4;
                     uint32_t nx = uint32_t(cur) >> 8;  // byte 1 = probability of the current state
-                    int left = ex - 3;
-                    uint32_t m;
+                    // the bins left-aligned -- (ex - 3) ones, a zero -- followed by a sentinel 1 (as in the mantissa loop)
+                    uint32_t bits = ((0xFFFFFFFCu << (ex - 3)) ^ 0xFFFFFFFDu) << (33 - ex);
                     do {
-                        m = uint32_t((0 - left) >> 31);  // ones while left > 0
-                        enc_core(e, (nx >> 8) & 0xFF, m);
-                        nx = successor_m(cur, m);
-                        cur = tab[nx & 0xFF];
-                        left += int32_t(m);
-                    } while (m);
+                        nx = enc_step_msb(e, (nx >> 8) & 0xFF, bits, cur);
+                        cur = entry_at(tab, nx);
+                    } while (bits != 0x80000000u);
                     set_slot_state<4>(bank, nx & 0xFF);
                 }
             }
-            enc_once<5>(e, bank, E, uint32_t(__builtin_amdgcn_sbfe(int(a), uint32_t(ex - 1), 1u)));
+            enc_once_m<5>(e, bank, E, uint32_t(__builtin_amdgcn_sbfe(int(a), uint32_t(ex - 1), 1u)));
             if (ex > 1) {  // mantissa tail on slot 6, MSB first
                 entry_t cur = E.e6;
                 uint32_t nx = uint32_t(cur) >> 8;
                 // remaining mantissa bits left-aligned, followed by a sentinel 1: the loop needs no counter
                 uint32_t bits = ((a << 1) | 1u) << (32 - ex);
                 do {
-                    const uint32_t m = uint32_t(int32_t(bits) >> 31);
-                    bits <<= 1;
-                    enc_core(e, (nx >> 8) & 0xFF, m);
-                    nx = successor_m(cur, m);
-                    cur = tab[nx & 0xFF];
+                    nx = enc_step_msb(e, (nx >> 8) & 0xFF, bits, cur);
+                    cur = entry_at(tab, nx);
                 } while (bits != 0x80000000u);
                 set_slot_state<6>(bank, nx & 0xFF);
             }
         }
-        enc_once<7>(e, bank, E, uint32_t(res >> 31));
+        enc_once_m<7>(e, bank, E, uint32_t(res >> 31));
     }
 }
 
@@ -231,7 +281,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     if (threadIdx.x >= lpw || id >= g.n_slices) return;
     const SliceRect r = slice_rect(g, id);
     RangeEnc e;
-    e.low = 0; e.range = 0xFF00; e.held = 0; e.pend = 0;  // llcomp.hpp:35 (held: see RangeEnc)
+    e.low = 0; e.range = 0xFF00; e.held = 0; e.pend = 0; e.calm = ~0u;  // llcomp.hpp:35 (held: see RangeEnc)
     e.pos = -1; e.flushed = 0;
     e.ring = reinterpret_cast<uint8_t*>(ring + kRingStrideDwords * threadIdx.x);
     e.out = scratch + ((((size_t(id >> g.lane_shift) * (g.slice_cap >> 4)) << g.lane_shift) + (id & ((1u << g.lane_shift) - 1))) << 4);
@@ -394,6 +444,33 @@ __device__ __forceinline__ bool dec_core(RangeDec& d, uint32_t P) {  // llcomp.h
     }
     return bit;
 }
+// dec_core for a run of bins on one slot whose bits are gathered in `w` (inverted: see dec_residual): the borrow of the
+// subtraction stays in VCC for all three selects (2-cycle v_cndmask_e32) and is shifted into `w` by an add-with-carry.
+// Returns the half of entry `cur` that belongs to the decoded bit.
+template <bool CHECKED>
+__device__ __forceinline__ uint32_t dec_step_acc(RangeDec& d, uint32_t P, entry_t cur, uint32_t& w) {
+    if (CHECKED && d.nb <= 0) dec_append(d);
+    const uint32_t r1 = __umul24(d.range, P) >> 8;
+    const uint32_t r0 = d.range - r1;
+    uint32_t diff, nx;
+    asm("v_sub_co_u32_e32 %[diff], vcc, %[low], %[r0]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e32 %[range], %[r1], %[r0], vcc\n\t"   // borrow: bit 0, range = r0, low stays
+        "v_cndmask_b32_e32 %[low], %[diff], %[low], vcc\n\t"
+        "v_cndmask_b32_e32 %[nx], %[hi], %[lo], vcc\n\t"
+        "v_addc_co_u32_e32 %[w], vcc, %[w], %[w], vcc"
+        : [diff] "=&v"(diff), [range] "=&v"(d.range), [low] "+v"(d.low), [nx] "=&v"(nx), [w] "+v"(w)
+        : [r0] "v"(r0), [r1] "v"(r1), [lo] "v"(uint32_t(cur)), [hi] "v"(uint32_t(cur >> 32))
+        : "vcc");
+    if (d.range < 0x100) {  // refill: see dec_core
+        d.range <<= 8;
+        d.low = (d.low << 8) | (d.wlo & 0xFF);
+        d.wlo = (d.wlo >> 8) | (d.whi << 24);
+        d.whi >>= 8;
+        d.nb -= 1;
+    }
+    return nx;
+}
 template <int SLOT, bool CHECKED>
 __device__ __forceinline__ bool dec_once(RangeDec& d, uint32_t (&bank)[2], const Entries& E) {
     const bool bit = dec_core<CHECKED>(d, prob_of(E.get<SLOT>()));
@@ -425,7 +502,7 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, uint32_t (&bank)[2], c
                 do {
                     b = dec_core<CHECKED>(d, (nx >> 8) & 0xFF);
                     nx = successor(cur, b);
-                    cur = tab[nx & 0xFF];
+                    cur = entry_at(tab, nx);
                     ex += b ? 1 : 0;
                     if (CHECKED && ex > 31) { ok = false; b = false; }
                 } while (b);
@@ -437,25 +514,27 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, uint32_t (&bank)[2], c
         }
     }
     if (!ok) return false;
-    uint32_t v = 1;
+    // The mantissa is gathered with INVERTED bits below its leading one (w), because the decision of a bin is the borrow
+    // of a subtraction and the decoded bit is its complement: w = 2w + borrow is one add-with-carry (dec_step_acc).
+    uint32_t w = 1;
+    const uint32_t ones = (1u << ex) - 1;
     if (ex > 0) {
-        v += v + uint32_t(dec_once<5, CHECKED>(d, bank, E));
+        w += w + uint32_t(!dec_once<5, CHECKED>(d, bank, E));
         if (ex > 1) {
             entry_t cur = E.e6;
             uint32_t nx = uint32_t(cur) >> 8;
-            // v has ex + 1 significant bits when the mantissa is complete.  `limit` is hidden from the optimiser, which
-            // would otherwise turn `v < limit` into a shift by a register + compare (two 4-cycle ops per step).
-            uint32_t limit = 1u << ex;
+            // w has ex + 1 significant bits when the mantissa is complete.  `limit` is hidden from the optimiser, which
+            // would otherwise turn `w < limit` into a shift by a register + compare (two 4-cycle ops per step).
+            uint32_t limit = ones + 1;
             asm volatile("" : "+v"(limit));
             do {
-                const bool b = dec_core<CHECKED>(d, (nx >> 8) & 0xFF);
-                nx = successor(cur, b);
-                cur = tab[nx & 0xFF];
-                v += v + uint32_t(b);
-            } while (v < limit);
+                nx = dec_step_acc<CHECKED>(d, (nx >> 8) & 0xFF, cur, w);
+                cur = entry_at(tab, nx);
+            } while (w < limit);
             set_slot_state<6>(bank, nx & 0xFF);
         }
     }
+    uint32_t v = w ^ ones;
     if (dec_once<7, CHECKED>(d, bank, E)) v = 0u - v;
     out = v;
     return true;
