@@ -97,23 +97,33 @@ __device__ __forceinline__ entry_t entry_at(const entry_t* tab, uint32_t nx) {
 }
 
 // ================================================ ENCODER ========================================================
-// Range encoder of one lane (llcomp.hpp:33-89).  Output bytes are staged in a per-lane LDS slot of 36 bytes (32-byte
-// ring + 4 spare; 9-dword stride = conflict-free) and leave for HBM as aligned 16-byte stores.  `pos` starts at -1:
+// Range encoder of one lane (llcomp.hpp:33-89).  Output bytes are staged in a per-lane 32-byte LDS ring and
+// leave for HBM as aligned 16-byte stores.  `pos` starts at -1:
 // the reference holds its first byte back without emitting (held == -1); here a dummy byte is "emitted" to position
 // -1 instead, which is the same thing without the special case.
 struct RangeEnc {
-    uint32_t low, range, held, pend;
-    uint32_t calm;    // ~0 while pend == 0, 0 while a run of undecided bytes is open
+    uint32_t low, range;
+    uint32_t held;    // bits 0..7: the byte held back (llcomp.hpp: outstanding_byte); bits 8..: length of the run of
+                      // undecided 0xFF bytes behind it (outstanding_count) -- zero on the common path
+    uint32_t thr;     // 0xFE while pend == 0, ~0 while a run of undecided bytes is open (see enc_renorm)
     int32_t pos;      // bytes produced so far
     int32_t flushed;  // bytes already stored to HBM (multiple of 16)
-    uint8_t* ring;    // this lane's 36-byte LDS slot
+    uint8_t* ring8;   // the block's LDS staging area; this lane's 32-byte ring starts at ring8[slot]
+    uint32_t slot;    // lane * 32
     uint8_t* out;     // this lane's first 16-byte unit in the stream lane order array
     int32_t cap;
     uint32_t shift;   // lane_shift
 };
-constexpr int kRingStrideDwords = 9;
+// Ring stride 32 bytes: index = slot | (pos & 31) is ONE v_and_or.  (Lanes 8 apart share LDS banks, but only the few
+// lanes that renormalise in a step -- one in eleven -- touch the ring at the same time.)
+constexpr int kRingBytes = 32;
+__device__ __forceinline__ uint8_t& ring_at(RangeEnc& e, uint32_t pos) {
+    uint32_t idx;  // (hipcc turns the `|` of disjoint bits into mask + add with the ring's address)
+    asm("v_and_or_b32 %0, %1, 31, %2" : "=v"(idx) : "v"(pos), "v"(e.slot));
+    return e.ring8[idx];
+}
 __device__ __forceinline__ void enc_flush16(RangeEnc& e) {
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(e.ring + (uint32_t(e.flushed) & 16));
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(e.ring8 + (e.slot | (uint32_t(e.flushed) & 16)));
     uint4 v;
     v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
     // stream lane order: unit u of this lane is (u << lane_shift) units further on
@@ -121,45 +131,51 @@ __device__ __forceinline__ void enc_flush16(RangeEnc& e) {
     e.flushed += 16;
 }
 // rare: a run of undecided 0xFF bytes is resolved (llcomp.hpp:44-45, 49-50); called before `low` is shifted
-__device__ __forceinline__ void enc_fill(RangeEnc& e) {
+__device__ __forceinline__ void enc_fill(RangeEnc& e, uint32_t count) {
     const uint32_t fill = (e.low >> 16) ? 0x00u : 0xFFu;
 #pragma nounroll
-    for (; e.pend; --e.pend) {
+    for (; count; --count) {
         if (e.pos - e.flushed >= 16) enc_flush16(e);
-        e.ring[uint32_t(e.pos) & 31] = uint8_t(fill);
+        ring_at(e, uint32_t(e.pos)) = uint8_t(fill);
         ++e.pos;
     }
 }
+// low = (low & 0xFF) << 8 as one SDWA shift (hipcc: shift + and)
+__device__ __forceinline__ uint32_t low_byte_up(uint32_t low) {
+    uint32_t r;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
+        : "=v"(r) : "v"(8u), "v"(low));
+    return r;
+}
 // Renormalisation (body of the reference's `while (range < 0x100)`: one step always suffices because range >= 7 after
 // put() and == 0xFF in finish()).  One exec-masked region for the lanes that renormalise.  Its common path (the new byte
-// is decided: llcomp.hpp:42-51) is straight-line code made of 2-cycle operations; the two rare cases -- the byte is
-// still undecided, 0xFF00 < low < 0x10000 (llcomp.hpp:52-54), and a run of such bytes being resolved -- are branches.
+// is decided: llcomp.hpp:42-51) is straight-line code; the two rare cases -- the byte is still undecided, 0xFF00 < low <
+// 0x10000 (llcomp.hpp:52-54), and a run of such bytes being resolved -- share ONE test: low - 0xFF01 <= thr, where thr
+// is 0xFE normally (exactly the undecided interval) and ~0 while a run is open (always true).
 __device__ __forceinline__ void enc_renorm(RangeEnc& e) {
     if (e.range < 0x100) {
-        // ONE test for both rare cases: `calm` is all ones while no undecided run is open and zero while one is, so the
-        // masked difference is < 0xFF exactly when this byte is undecided or a run is waiting to be resolved.
         const uint32_t und = e.low - 0xFF01u;
-        if (__builtin_expect((und & e.calm) < 0xFFu, 0)) {
+        if (__builtin_expect(und <= e.thr, 0)) {
             if (und < 0xFFu) {
-                ++e.pend;
-                e.calm = 0;
+                e.held += 0x100;
+                e.thr = ~0u;
             } else {
                 // (same as the common path below; `lw` is opaque so that hipcc does not merge the two copies and then
                 // pay for the merge with register moves on the common path)
                 uint32_t lw = e.low;
                 asm volatile("" : "+v"(lw), "+v"(e.pos));
-                e.ring[uint32_t(e.pos) & 31] = uint8_t(e.held + (lw >> 16));
+                ring_at(e, uint32_t(e.pos)) = uint8_t(e.held + (lw >> 16));
                 e.pos -= -1;
-                enc_fill(e);
-                e.calm = ~0u;
+                enc_fill(e, e.held >> 8);
+                e.thr = 0xFEu;
                 e.held = (lw >> 8) & 0xFF;
             }
         } else {
-            e.ring[uint32_t(e.pos) & 31] = uint8_t(e.held + (e.low >> 16));  // held + carry
+            ring_at(e, uint32_t(e.pos)) = uint8_t(e.held + (e.low >> 16));  // held + carry
             ++e.pos;
             e.held = (e.low >> 8) & 0xFF;
         }
-        e.low = (e.low & 0xFF) << 8;
+        e.low = low_byte_up(e.low);
         e.range <<= 8;
     }
 }
@@ -275,15 +291,16 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
                                                       uint8_t* __restrict__ scratch, uint32_t* __restrict__ slice_len,
                                                       uint32_t* status) {
     __shared__ entry_t tab[128];
-    __shared__ uint32_t ring[kRingStrideDwords * 64];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kRingBytes * 64];
     load_table(tab);
     const uint32_t id = blockIdx.x * lpw + threadIdx.x;
     if (threadIdx.x >= lpw || id >= g.n_slices) return;
     const SliceRect r = slice_rect(g, id);
     RangeEnc e;
-    e.low = 0; e.range = 0xFF00; e.held = 0; e.pend = 0; e.calm = ~0u;  // llcomp.hpp:35 (held: see RangeEnc)
+    e.low = 0; e.range = 0xFF00; e.held = 0; e.thr = 0xFEu;  // llcomp.hpp:35 (held: see RangeEnc)
     e.pos = -1; e.flushed = 0;
-    e.ring = reinterpret_cast<uint8_t*>(ring + kRingStrideDwords * threadIdx.x);
+    e.ring8 = ring;
+    e.slot = threadIdx.x * kRingBytes;
     e.out = scratch + ((((size_t(id >> g.lane_shift) * (g.slice_cap >> 4)) << g.lane_shift) + (id & ((1u << g.lane_shift) - 1))) << 4);
     e.cap = int32_t(g.slice_cap);
     e.shift = g.lane_shift;
