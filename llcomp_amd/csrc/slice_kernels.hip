@@ -97,15 +97,22 @@ __device__ __forceinline__ entry_t entry_at(const entry_t* tab, uint32_t nx) {
 }
 
 // ================================================ ENCODER ========================================================
-// Range encoder of one lane (llcomp.hpp:33-89).  Output bytes are staged in a per-lane 32-byte LDS ring and
-// leave for HBM as aligned 16-byte stores.  `pos` starts at -1:
-// the reference holds its first byte back without emitting (held == -1); here a dummy byte is "emitted" to position
-// -1 instead, which is the same thing without the special case.
+// Range encoder of one lane (llcomp.hpp:33-89).  Output bytes are staged in a per-lane 32-byte LDS ring and leave for
+// HBM as aligned 16-byte stores.
+//
+// Carries.  The reference holds one byte back (outstanding_byte) plus a count of undecided 0xFF bytes behind it
+// (outstanding_count) and writes them once it knows whether a carry reaches them (llcomp.hpp:40-57).  That is long
+// addition done lazily; the bytes it finally emits are those of the exact sum.  Here the same sum is formed eagerly:
+// only ONE byte is held back, an undecided 0xFF is emitted like any other byte, and in the rare event that a carry
+// arrives while the held byte is 0xFF (about one renormalisation in a thousand) the carry is propagated into the bytes
+// already written -- in the LDS ring or, behind the last flush, in this lane's own units in HBM.  The common path of a
+// renormalisation is then seven instructions with a single test.  (The reference's `outstanding_byte + 1` cannot
+// overflow a byte: low < 0x1FE00 always, so a byte 0xFF is never held when low >= 0x10000 produced it.)
+// `pos` starts at -1: the reference emits nothing for its first renormalisation (outstanding_byte == -1); here a dummy
+// byte goes to position -1 instead, which is the same thing without the special case.
 struct RangeEnc {
     uint32_t low, range;
-    uint32_t held;    // bits 0..7: the byte held back (llcomp.hpp: outstanding_byte); bits 8..: length of the run of
-                      // undecided 0xFF bytes behind it (outstanding_count) -- zero on the common path
-    uint32_t thr;     // 0xFE while pend == 0, ~0 while a run of undecided bytes is open (see enc_renorm)
+    uint32_t held;    // the byte held back, 0..255
     int32_t pos;      // bytes produced so far
     int32_t flushed;  // bytes already stored to HBM (multiple of 16)
     uint8_t* ring8;   // the block's LDS staging area; this lane's 32-byte ring starts at ring8[slot]
@@ -122,22 +129,33 @@ __device__ __forceinline__ uint8_t& ring_at(RangeEnc& e, uint32_t pos) {
     asm("v_and_or_b32 %0, %1, 31, %2" : "=v"(idx) : "v"(pos), "v"(e.slot));
     return e.ring8[idx];
 }
+// stream lane order: unit u of this lane is (u << lane_shift) units further on
+__device__ __forceinline__ uint8_t* unit_byte(RangeEnc& e, uint32_t k) {
+    return e.out + ((size_t(k >> 4) << (e.shift + 4)) + (k & 15));
+}
 __device__ __forceinline__ void enc_flush16(RangeEnc& e) {
     const uint32_t* w = reinterpret_cast<const uint32_t*>(e.ring8 + (e.slot | (uint32_t(e.flushed) & 16)));
     uint4 v;
     v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
-    // stream lane order: unit u of this lane is (u << lane_shift) units further on
-    if (e.flushed + 16 <= e.cap) *reinterpret_cast<uint4*>(e.out + (size_t(uint32_t(e.flushed)) << e.shift)) = v;
+    if (e.flushed + 16 <= e.cap) *reinterpret_cast<uint4*>(unit_byte(e, uint32_t(e.flushed))) = v;
     e.flushed += 16;
 }
-// rare: a run of undecided 0xFF bytes is resolved (llcomp.hpp:44-45, 49-50); called before `low` is shifted
-__device__ __forceinline__ void enc_fill(RangeEnc& e, uint32_t count) {
-    const uint32_t fill = (e.low >> 16) ? 0x00u : 0xFFu;
-#pragma nounroll
-    for (; count; --count) {
-        if (e.pos - e.flushed >= 16) enc_flush16(e);
-        ring_at(e, uint32_t(e.pos)) = uint8_t(fill);
-        ++e.pos;
+// rare: +1 into the bytes before position `pos` (the byte at `pos` itself just wrapped from 0xFF to 0x00)
+__device__ __forceinline__ void enc_carry_back(RangeEnc& e) {
+    for (int32_t k = e.pos - 1; k >= 0; --k) {
+        uint32_t v;
+        if (k >= e.flushed) {
+            uint8_t& r = ring_at(e, uint32_t(k));
+            v = r;
+            r = uint8_t(v + 1);
+        } else if (k < e.cap) {
+            uint8_t* g = unit_byte(e, uint32_t(k));
+            v = *g;
+            *g = uint8_t(v + 1);
+        } else {
+            break;  // beyond the scratch capacity: the slice is reported as overflowed anyway
+        }
+        if (v != 0xFF) break;
     }
 }
 // low = (low & 0xFF) << 8 as one SDWA shift (hipcc: shift + and)
@@ -148,33 +166,14 @@ __device__ __forceinline__ uint32_t low_byte_up(uint32_t low) {
     return r;
 }
 // Renormalisation (body of the reference's `while (range < 0x100)`: one step always suffices because range >= 7 after
-// put() and == 0xFF in finish()).  One exec-masked region for the lanes that renormalise.  Its common path (the new byte
-// is decided: llcomp.hpp:42-51) is straight-line code; the two rare cases -- the byte is still undecided, 0xFF00 < low <
-// 0x10000 (llcomp.hpp:52-54), and a run of such bytes being resolved -- share ONE test: low - 0xFF01 <= thr, where thr
-// is 0xFE normally (exactly the undecided interval) and ~0 while a run is open (always true).
+// put() and == 0xFF in finish()).  One exec-masked region for the lanes that renormalise.
 __device__ __forceinline__ void enc_renorm(RangeEnc& e) {
     if (e.range < 0x100) {
-        const uint32_t und = e.low - 0xFF01u;
-        if (__builtin_expect(und <= e.thr, 0)) {
-            if (und < 0xFFu) {
-                e.held += 0x100;
-                e.thr = ~0u;
-            } else {
-                // (same as the common path below; `lw` is opaque so that hipcc does not merge the two copies and then
-                // pay for the merge with register moves on the common path)
-                uint32_t lw = e.low;
-                asm volatile("" : "+v"(lw), "+v"(e.pos));
-                ring_at(e, uint32_t(e.pos)) = uint8_t(e.held + (lw >> 16));
-                e.pos -= -1;
-                enc_fill(e, e.held >> 8);
-                e.thr = 0xFEu;
-                e.held = (lw >> 8) & 0xFF;
-            }
-        } else {
-            ring_at(e, uint32_t(e.pos)) = uint8_t(e.held + (e.low >> 16));  // held + carry
-            ++e.pos;
-            e.held = (e.low >> 8) & 0xFF;
-        }
+        const uint32_t b = e.held + (e.low >> 16);  // held + carry
+        ring_at(e, uint32_t(e.pos)) = uint8_t(b);
+        if (__builtin_expect(b > 0xFF, 0)) enc_carry_back(e);
+        ++e.pos;
+        e.held = __builtin_amdgcn_ubfe(e.low, 8, 8);
         e.low = low_byte_up(e.low);
         e.range <<= 8;
     }
@@ -297,7 +296,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     if (threadIdx.x >= lpw || id >= g.n_slices) return;
     const SliceRect r = slice_rect(g, id);
     RangeEnc e;
-    e.low = 0; e.range = 0xFF00; e.held = 0; e.thr = 0xFEu;  // llcomp.hpp:35 (held: see RangeEnc)
+    e.low = 0; e.range = 0xFF00; e.held = 0;  // llcomp.hpp:35 (held: see RangeEnc)
     e.pos = -1; e.flushed = 0;
     e.ring8 = ring;
     e.slot = threadIdx.x * kRingBytes;
