@@ -511,20 +511,21 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, uint32_t (&bank)[2], c
         if (dec_once<2, CHECKED>(d, bank, E)) {
             ex = 2;
             if (dec_once<3, CHECKED>(d, bank, E)) {
-                ex = 3;
                 entry_t cur = E.e4;
                 uint32_t nx = uint32_t(cur) >> 8;  // byte 1 = probability of the current state (entry_lo byte 2)
+                int n = 0;  // bins of the unary tail: n - 1 ones and the closing zero
                 bool b;
                 do {
                     b = dec_core<CHECKED>(d, (nx >> 8) & 0xFF);
                     nx = successor(cur, b);
                     cur = entry_at(tab, nx);
-                    ex += b ? 1 : 0;
-                    if (CHECKED && ex > 31) { ok = false; b = false; }
+                    ++n;
+                    if (CHECKED && n > 29) break;  // exponent would exceed 31
                 } while (b);
+                ex = 2 + n;
                 // fast path: no per-step limit -- the run ends by itself once the window holds only zeros; a run
                 // longer than 31 is "Invalid exponent" (llcomp.hpp:230-235) and is confirmed by the checked replay
-                if (!CHECKED && ex > 31) ok = false;
+                if (ex > 31) ok = false;
                 set_slot_state<4>(bank, nx & 0xFF);
             }
         }
