@@ -291,6 +291,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
                                                       uint32_t* status) {
     __shared__ entry_t tab[128];
     __shared__ __attribute__((aligned(16))) uint8_t ring[kRingBytes * 64];
+    __shared__ unsigned long long rowbank[ROWS ? 3 * 64 : 1];
     load_table(tab);
     const uint32_t id = blockIdx.x * lpw + threadIdx.x;
     if (threadIdx.x >= lpw || id >= g.n_slices) return;
@@ -311,8 +312,9 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     bool hot = false;  // wave-uniform: most lanes had a non-zero residual last time
 
     if constexpr (ROWS) {
-        // contexts 0 / 605 / 1210 only: three banks in registers
-        uint32_t B[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+        // contexts 0 / 605 / 1210 only: their state bytes sit in LDS, [context][lane] (a read + a write per sample
+        // instead of selecting among / writing back to three register pairs: twelve v_cndmask)
+        rowbank[threadIdx.x] = rowbank[64 + threadIdx.x] = rowbank[128 + threadIdx.x] = 0;
         uint32_t s0 = p0[0];
         uint32_t s1 = total > 1 ? p0[GW] : 0;
         for (uint32_t i = 0; i < total; ++i) {
@@ -323,23 +325,21 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
             s0 = consume_here(s0);  // loaded two samples ago
             const uint32_t s2 = i + 2 < total ? p0[size_t(i + 2) * GW] : 0;
             if (e.pos - e.flushed >= 16) enc_flush16(e);
-            bool c1, c2;
+            uint32_t cidx;
             int res;
             if constexpr (sizeof(SYM) == 2) {  // fused stage A: |quant5| in bits 12..13, residual in bits 0..11
-                c1 = (s0 >> 12) == 1; c2 = (s0 >> 12) == 2;
+                cidx = s0 >> 12;
                 res = int(s0 << 20) >> 20;
             } else {
-                const uint32_t ctx = s0 & 0xFFFF;
-                c1 = ctx == 605; c2 = ctx > 605;
+                cidx = ((s0 & 0xFFFF) * 109u) >> 16;  // 0 / 605 / 1210 -> 0 / 1 / 2
                 res = int(s0) >> 16;
             }
-            uint32_t bank[2] = {c2 ? B[2][0] : c1 ? B[1][0] : B[0][0], c2 ? B[2][1] : c1 ? B[1][1] : B[0][1]};
+            unsigned long long* bp = &rowbank[cidx * 64 + threadIdx.x];
+            const unsigned long long b64 = *bp;
+            uint32_t bank[2] = {uint32_t(b64), uint32_t(b64 >> 32)};
             if (hot) enc_residual<true>(e, bank, tab, res); else enc_residual<false>(e, bank, tab, res);
             hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(res != 0)) >= __popcll(__ballot(true)));
-            const bool c0 = !(c1 || c2);  // branch-free write-back (six v_cndmask)
-            B[0][0] = c0 ? bank[0] : B[0][0]; B[0][1] = c0 ? bank[1] : B[0][1];
-            B[1][0] = c1 ? bank[0] : B[1][0]; B[1][1] = c1 ? bank[1] : B[1][1];
-            B[2][0] = c2 ? bank[0] : B[2][0]; B[2][1] = c2 ? bank[1] : B[2][1];
+            *bp = (unsigned long long)bank[0] | ((unsigned long long)bank[1] << 32);
             s0 = s1;
             s1 = s2;
         }
@@ -578,6 +578,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                                                       uint64_t* __restrict__ states, int16_t* __restrict__ rec,
                                                       uint32_t* status) {
     __shared__ entry_t tab[128];
+    __shared__ unsigned long long rowbank[ROWS ? 3 * 64 : 1];
     load_table(tab);
     const uint32_t lpw = lpw_and_flags & 0xFF;
     const bool replay_always = (lpw_and_flags >> 8) & 1;  // test hook: send every sample through the checked replay too
@@ -602,8 +603,9 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
 
     if constexpr (ROWS) {
         // one-row slice (llcomp.hpp:494-509 with h == 0): l = left (128 at the start), everything above = l, so
-        // hash = 605*quant5(L - l), prediction = l.  Three banks in registers, no state memory.
-        uint32_t B[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+        // hash = 605*quant5(L - l), prediction = l.  The three banks sit in LDS ([context][lane], see the encoder); no
+        // state memory in HBM.
+        rowbank[threadIdx.x] = rowbank[64 + threadIdx.x] = rowbank[128 + threadIdx.x] = 0;
         int l[NCH], L[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) l[k] = L[k] = 128;
@@ -621,8 +623,10 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 const int dq = Lv - lv;
                 const uint32_t aq = uint32_t(dq < 0 ? -dq : dq);
                 const bool neg = dq < 0;               // hash = 605*quant5(L-l) < 0
-                const bool c2 = aq > 3, c1 = aq > 0 && !c2;  // |quant5| == 2 / == 1
-                uint32_t bank[2] = {c2 ? B[2][0] : c1 ? B[1][0] : B[0][0], c2 ? B[2][1] : c1 ? B[1][1] : B[0][1]};
+                const uint32_t cidx = min(aq, 1u) + (aq > 3 ? 1u : 0u);  // |quant5(L - l)|
+                unsigned long long* bp = &rowbank[cidx * 64 + threadIdx.x];
+                const unsigned long long b64 = *bp;
+                uint32_t bank[2] = {uint32_t(b64), uint32_t(b64 >> 32)};
                 uint32_t v;
                 const bool ok = dec_sample(d, bank, tab, hot, replay_always, v);
                 if (!ok) {
@@ -630,10 +634,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                     return;
                 }
                 hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true)));
-                const bool c0 = !(c1 || c2);  // branch-free write-back (six v_cndmask)
-                B[0][0] = c0 ? bank[0] : B[0][0]; B[0][1] = c0 ? bank[1] : B[0][1];
-                B[1][0] = c1 ? bank[0] : B[1][0]; B[1][1] = c1 ? bank[1] : B[1][1];
-                B[2][0] = c2 ? bank[0] : B[2][0]; B[2][1] = c2 ? bank[1] : B[2][1];
+                *bp = (unsigned long long)bank[0] | ((unsigned long long)bank[1] << 32);
                 if (neg) v = 0u - v;
                 const int val = int(int16_t(uint32_t(lv) + v));
                 held_val = val;
