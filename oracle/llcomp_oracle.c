@@ -94,6 +94,13 @@ typedef struct {
 static void renc_init(renc_t* e, sink_t* out) {  /* hpp:35 */
     e->low = 0; e->range = 0xFF00; e->held = -1; e->pend = 0; e->out = out;
 }
+/* test coverage only: how often a carry had to travel through a run of undecided 0xFF bytes, and the longest run */
+static long g_carry_runs, g_carry_longest;
+void orc_carry_stats(long* runs, long* longest, int reset) {
+    if (runs) *runs = g_carry_runs;
+    if (longest) *longest = g_carry_longest;
+    if (reset) g_carry_runs = g_carry_longest = 0;
+}
 static void renc_renorm(renc_t* e) {  /* hpp:38-58 */
     while (e->range < 0x100) {
         if (e->held < 0) {
@@ -103,6 +110,10 @@ static void renc_renorm(renc_t* e) {  /* hpp:38-58 */
             for (; e->pend; e->pend--) sink_put(e->out, 0xFF);
             e->held = e->low >> 8;
         } else if (e->low >= 0x10000) {
+            if (e->pend) {
+                g_carry_runs++;
+                if (e->pend > g_carry_longest) g_carry_longest = e->pend;
+            }
             sink_put(e->out, (uint8_t)(e->held + 1));
             for (; e->pend; e->pend--) sink_put(e->out, 0x00);
             e->held = (e->low >> 8) & 0xFF;

@@ -67,6 +67,9 @@ int orc_decompress(const uint8_t* data, size_t len, uint8_t** px, int* w, int* h
 /* slice bookkeeping shared by tests */
 long orc_slice_count(int w, int h, int c, int tile_w, int tile_h, int planar);
 uint64_t orc_fnv1a64(const uint8_t* p, size_t n);
+/* coverage counters of the encoder since the last reset: carries that travelled through a run of undecided 0xFF
+   bytes (hpp:49-50 with outstanding_count > 0) and the longest such run.  Not thread-safe; tests only. */
+void orc_carry_stats(long* runs, long* longest, int reset);
 void orc_free(void* p);
 
 #ifdef __cplusplus

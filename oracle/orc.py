@@ -108,6 +108,8 @@ class Orc:
         L.orc_fnv1a64.restype = C.c_uint64
         L.orc_fnv1a64.argtypes = [_u8p, C.c_size_t]
         L.orc_free.argtypes = [C.c_void_p]
+        L.orc_carry_stats.restype = None
+        L.orc_carry_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_int]
         for f in ("orc_quant11", "orc_quant5", "orc_state_p"):
             getattr(L, f).restype = C.c_int
             getattr(L, f).argtypes = [C.c_int]
@@ -115,6 +117,12 @@ class Orc:
         L.orc_state_next.argtypes = [C.c_int, C.c_int]
         L.orc_median.restype = C.c_int
         L.orc_median.argtypes = [C.c_int] * 3
+
+    def carry_stats(self, reset=False):
+        """(carries through a run of undecided 0xFF bytes, longest run) seen by the encoder since the last reset"""
+        runs, longest = C.c_long(), C.c_long()
+        self.lib.orc_carry_stats(C.byref(runs), C.byref(longest), int(reset))
+        return runs.value, longest.value
 
     def _take(self, ptr, n):
         out = C.string_at(ptr, n)

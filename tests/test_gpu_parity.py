@@ -221,6 +221,22 @@ def test_c2_1080p_noise_one_slice_per_row(mi, orc):
     assert np.array_equal(mi.decompress_image(s).pixels, img)
 
 
+def test_carries_through_ff_runs_match_oracle(mi, orc):
+    """The encoder propagates carries eagerly into bytes it has already written (LDS ring, or its units in HBM behind
+    the last 16-byte flush) where the reference resolves a held run lazily (llcomp.hpp:40-57).  Noise makes both happen
+    thousands of times: the oracle counts its carries through 0xFF runs for this very input, the containers must agree
+    byte for byte, and a run of 2+ bytes plus the number of events make a flush-boundary crossing certain."""
+    img = make_image("g3", 1920, 1080, 3)
+    for tw, planar in ((480, True), (1920, False)):
+        orc.carry_stats(reset=True)
+        want = orc.compress_sliced(img, tile_w=tw, tile_h=1, planar=planar)
+        runs, longest = orc.carry_stats()
+        assert runs > 1000 and longest >= 2, (runs, longest)
+        got = mi.compress_image(img, 1920, 1080, 3, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=1, planar=planar)
+        assert got == want
+        assert np.array_equal(mi.decompress_image(got).pixels, img)
+
+
 def test_c4_8k_roundtrip_and_band_merge_property(mi, orc):
     """8192x8192 RGB8: encode two halves as separate bands (what two GPUs would do), merge with the host
     concatenator, compare with the one-piece encode, decode, compare with the input."""
