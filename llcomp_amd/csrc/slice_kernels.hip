@@ -409,10 +409,10 @@ __device__ __forceinline__ uint32_t consume_here(uint32_t v) {
 }
 __device__ __forceinline__ void dec_append(RangeDec& d) {  // requires 0 <= nb <= 4
     const uint32_t ready = consume_here(d.nxt);
-    // window |= ready << (8 * nb), in 32-bit pieces (a 64-bit shift by a register is several 4-cycle ops)
-    const uint32_t sh = 8u * uint32_t(d.nb);                 // 0, 8, 16, 24 or 32
-    d.wlo |= sh < 32 ? ready << sh : 0u;
-    d.whi |= (ready >> 1) >> (31 - (sh & 31)) | (sh == 32 ? ready : 0u);  // sh == 0 gives 0; sh == 32: whole dword
+    // window |= ready << (8 * nb): one 64-bit shift (0, 8, 16, 24 or 32 bits) and two ORs
+    const unsigned long long t = (unsigned long long)ready << (8u * uint32_t(d.nb));
+    d.wlo |= uint32_t(t);
+    d.whi |= uint32_t(t >> 32);
     d.nb += 4;
     dec_prefetch(d, d.kn++);
 }
