@@ -30,7 +30,7 @@ struct llcomp_mi_codec {
     uint64_t* d_total_tmp = nullptr;
     uint64_t* d_block_sums = nullptr;  // scan scratch
     uint64_t workspace_bytes = 0;
-    bool need_states = true;  // false for 1-row slices (states live in registers)
+    bool need_states = true;  // false when the states live in LDS (1-row slices; one slice per wavefront)
     // optional per-kernel timing (hipEvents on the caller's stream)
     bool profiling = false;
     struct Span { hipEvent_t a, b; int slot; };

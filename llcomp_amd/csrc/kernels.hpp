@@ -29,14 +29,16 @@ bool model_is_fused(const Geometry& g);
 hipError_t launch_model_rows_fwd(const Geometry& g, const uint8_t* d_px, uint16_t* d_lanes, hipStream_t stream);  // 16-bit symbols
 hipError_t launch_model_rows_inv(const Geometry& g, const int16_t* d_lanes, uint8_t* d_px, hipStream_t stream);
 
-// 1-row slices keep their (three) contexts in registers; only taller slices need the per-slice tables in HBM.
+// 1-row slices keep their (three) contexts in LDS, and so does a launch with one slice per wavefront (the whole 63 KB
+// table); only the other launches need the per-slice tables in HBM.
 bool rows_mode(const Geometry& g);
 bool slices_need_state_tables(const Geometry& g);
 
 // One lane per slice: binarisation + adaptive states + range encoder.  llcomp.hpp:33-89, 166-206, 283-293, 439-449.
 //   d_sym     : symbols in LANE ORDER: u32 (ctx | residual << 16), or the 16-bit form of the fused path when
 //               model_is_fused(g)
-//   d_states  : u64[n_slices][kContexts], zeroed by the caller (8 state bytes per context)
+//   d_states  : u64[n_slices][kContexts], zeroed by the caller (8 state bytes per context); unused unless
+//               slices_need_state_tables(g)
 //   d_scratch : the slices' streams in stream lane order ; d_slice_len : u32[n_slices]
 hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* d_states, uint8_t* d_scratch,
                                 uint32_t* d_slice_len, uint32_t* d_status, hipStream_t stream);

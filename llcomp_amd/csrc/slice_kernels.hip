@@ -284,7 +284,17 @@ __device__ __forceinline__ void enc_finish(RangeEnc& e) {  // llcomp.hpp:75-81
 
 // Lane-per-slice encoder.  ROWS: every slice is one row high (register-resident states).  `lpw` = slices per
 // wavefront (1..64).
-template <int NCH, bool ROWS, typename SYM>
+// LDSTAB: one slice per wavefront (a lone whole-image stream, a handful of big tiles) -- its 63 KB state table fits in
+// LDS, which takes the HBM round trip of every context fetch off the serial chain.
+extern __shared__ __attribute__((aligned(8))) unsigned char dyn_lds[];
+template <bool LDSTAB>
+__device__ __forceinline__ void clear_lds_states() {
+    if constexpr (LDSTAB) {
+        unsigned long long* t = reinterpret_cast<unsigned long long*>(dyn_lds);
+        for (uint32_t i = threadIdx.x; i < uint32_t(kContexts); i += blockDim.x) t[i] = 0;
+    }
+}
+template <int NCH, bool ROWS, typename SYM, bool LDSTAB = false>
 __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const uint32_t lpw,
                                                       const SYM* __restrict__ sym, uint64_t* __restrict__ states,
                                                       uint8_t* __restrict__ scratch, uint32_t* __restrict__ slice_len,
@@ -292,6 +302,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     __shared__ entry_t tab[128];
     __shared__ __attribute__((aligned(16))) uint8_t ring[kRingBytes * 64];
     __shared__ unsigned long long rowbank[ROWS ? 3 * 64 : 1];
+    clear_lds_states<LDSTAB>();
     load_table(tab);
     const uint32_t id = blockIdx.x * lpw + threadIdx.x;
     if (threadIdx.x >= lpw || id >= g.n_slices) return;
@@ -346,7 +357,9 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     } else {
         // Everything the coder needs is known up front: the symbol two samples ahead and the state bank one sample
         // ahead are in flight while a sample is coded (forwarded when consecutive samples share a context).
-        uint64_t* banks = states + size_t(id) * kContexts;
+        uint64_t* banks;
+        if constexpr (LDSTAB) banks = reinterpret_cast<uint64_t*>(dyn_lds);
+        else banks = states + size_t(id) * kContexts;
         uint32_t fk = 0;
         auto fetch = [&]() -> uint32_t { return p0[size_t(fk++) * GW]; };
         uint32_t s0 = fetch();
@@ -571,7 +584,7 @@ __device__ __forceinline__ bool dec_sample(RangeDec& d, uint32_t (&bank)[2], con
     return ok;
 }
 
-template <int NCH, bool ROWS>
+template <int NCH, bool ROWS, bool LDSTAB = false>
 __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const uint32_t lpw_and_flags,
                                                       const uint8_t* __restrict__ units,
                                                       const uint32_t* __restrict__ slice_len,
@@ -579,6 +592,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                                                       uint32_t* status) {
     __shared__ entry_t tab[128];
     __shared__ unsigned long long rowbank[ROWS ? 3 * 64 : 1];
+    clear_lds_states<LDSTAB>();
     load_table(tab);
     const uint32_t lpw = lpw_and_flags & 0xFF;
     const bool replay_always = (lpw_and_flags >> 8) & 1;  // test hook: send every sample through the checked replay too
@@ -647,7 +661,9 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
     } else {
         // Neighbours of the row above rotate through registers (tl <- t <- tr); the two values the NEXT pixel needs
         // from memory (top-right, top-top) are loaded while the current one decodes.
-        uint64_t* banks = states + size_t(id) * kContexts;
+        uint64_t* banks;
+        if constexpr (LDSTAB) banks = reinterpret_cast<uint64_t*>(dyn_lds);
+        else banks = states + size_t(id) * kContexts;
         const ptrdiff_t up = ptrdiff_t(r.sw) * NCH * GW;  // one slice row back, in lane-order elements
         for (uint32_t y = 0; y < r.sh; ++y) {
             int16_t* row = p0 + ptrdiff_t(y) * up;
@@ -716,26 +732,44 @@ uint32_t lanes_per_wave(const Geometry& g) {
 
 }  // namespace
 
-#define LLMI_DISPATCH_SLICE(nch, rows, CALL)                                      \
-    switch ((nch) * 2 + ((rows) ? 1 : 0)) {                                       \
-        case 2: { constexpr int C = 1; constexpr bool R = false; CALL; } break;   \
-        case 3: { constexpr int C = 1; constexpr bool R = true; CALL; } break;    \
-        case 4: { constexpr int C = 2; constexpr bool R = false; CALL; } break;   \
-        case 5: { constexpr int C = 2; constexpr bool R = true; CALL; } break;    \
-        case 6: { constexpr int C = 3; constexpr bool R = false; CALL; } break;   \
-        case 7: { constexpr int C = 3; constexpr bool R = true; CALL; } break;    \
-        case 8: { constexpr int C = 4; constexpr bool R = false; CALL; } break;   \
-        case 9: { constexpr int C = 4; constexpr bool R = true; CALL; } break;    \
-        default: return hipErrorInvalidValue;                                     \
+// (channels per slice, 1-row slices, state table in LDS) -> template instance
+#define LLMI_DISPATCH_SLICE(nch, rows, lds, ...)                                                             \
+    switch ((nch) * 4 + ((rows) ? 2 : 0) + ((lds) ? 1 : 0)) {                                                 \
+        case 4: { constexpr int C = 1; constexpr bool R = false; constexpr bool T = false; __VA_ARGS__; } break;    \
+        case 5: { constexpr int C = 1; constexpr bool R = false; constexpr bool T = true; __VA_ARGS__; } break;     \
+        case 6: { constexpr int C = 1; constexpr bool R = true; constexpr bool T = false; __VA_ARGS__; } break;     \
+        case 8: { constexpr int C = 2; constexpr bool R = false; constexpr bool T = false; __VA_ARGS__; } break;    \
+        case 9: { constexpr int C = 2; constexpr bool R = false; constexpr bool T = true; __VA_ARGS__; } break;     \
+        case 10: { constexpr int C = 2; constexpr bool R = true; constexpr bool T = false; __VA_ARGS__; } break;    \
+        case 12: { constexpr int C = 3; constexpr bool R = false; constexpr bool T = false; __VA_ARGS__; } break;   \
+        case 13: { constexpr int C = 3; constexpr bool R = false; constexpr bool T = true; __VA_ARGS__; } break;    \
+        case 14: { constexpr int C = 3; constexpr bool R = true; constexpr bool T = false; __VA_ARGS__; } break;    \
+        case 16: { constexpr int C = 4; constexpr bool R = false; constexpr bool T = false; __VA_ARGS__; } break;   \
+        case 17: { constexpr int C = 4; constexpr bool R = false; constexpr bool T = true; __VA_ARGS__; } break;    \
+        case 18: { constexpr int C = 4; constexpr bool R = true; constexpr bool T = false; __VA_ARGS__; } break;    \
+        default: return hipErrorInvalidValue;                                                               \
     }
 
-// LLCOMP_MI_NOROWS=1 (tests / debugging) sends 1-row slices through the general table-in-HBM kernels as well.
+// LLCOMP_MI_NOROWS=1 (tests / debugging) sends 1-row slices through the general table-per-slice kernels as well.
 bool rows_mode(const Geometry& g) {
     if (g.tile_h != 1) return false;
     const char* e = std::getenv("LLCOMP_MI_NOROWS");
     return !(e && e[0] == '1');
 }
-bool slices_need_state_tables(const Geometry& g) { return !rows_mode(g); }
+// One slice per wavefront: the table of that slice lives in LDS.  LLCOMP_MI_NOLDSTAB=1 (tests) keeps it in HBM.
+bool states_in_lds(const Geometry& g) {
+    if (rows_mode(g) || lanes_per_wave(g) != 1) return false;
+    const char* e = std::getenv("LLCOMP_MI_NOLDSTAB");
+    return !(e && e[0] == '1');
+}
+bool slices_need_state_tables(const Geometry& g) { return !rows_mode(g) && !states_in_lds(g); }
+
+constexpr size_t kLdsTableBytes = size_t(kContexts) * 8;
+template <typename K>
+hipError_t allow_big_lds(K kernel) {  // more than the default 64 KB of LDS per block (static + dynamic)
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               int(kLdsTableBytes));
+}
 
 hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* d_states, uint8_t* d_scratch,
                                 uint32_t* d_slice_len, uint32_t* d_status, hipStream_t stream) {
@@ -746,9 +780,16 @@ hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* 
             g, lpw, static_cast<const uint16_t*>(d_sym), d_states, d_scratch, d_slice_len, d_status);
         return hipGetLastError();
     }
-    LLMI_DISPATCH_SLICE(g.nch, rows_mode(g),
-                        (k_encode_slices<C, R, uint32_t><<<dim3(blocks), dim3(64), 0, stream>>>(
-                            g, lpw, static_cast<const uint32_t*>(d_sym), d_states, d_scratch, d_slice_len, d_status)));
+    const bool lds = states_in_lds(g);
+    LLMI_DISPATCH_SLICE(g.nch, rows_mode(g), lds, {
+        auto kernel = k_encode_slices<C, R, uint32_t, T>;
+        if (T) {
+            const hipError_t e = allow_big_lds(kernel);
+            if (e != hipSuccess) return e;
+        }
+        kernel<<<dim3(blocks), dim3(64), T ? kLdsTableBytes : 0, stream>>>(
+            g, lpw, static_cast<const uint32_t*>(d_sym), d_states, d_scratch, d_slice_len, d_status);
+    });
     return hipGetLastError();
 }
 
@@ -758,9 +799,16 @@ hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_units, const
     const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
     const char* fr = std::getenv("LLCOMP_MI_FORCE_REPLAY");  // tests: exercise the decoder's rollback + checked replay
     const uint32_t arg = lpw | ((fr && fr[0] == '1') ? 0x100u : 0u);
-    LLMI_DISPATCH_SLICE(g.nch, rows_mode(g),
-                        (k_decode_slices<C, R><<<dim3(blocks), dim3(64), 0, stream>>>(
-                            g, arg, d_units, d_slice_len, d_states, d_rec, d_status)));
+    const bool lds = states_in_lds(g);
+    LLMI_DISPATCH_SLICE(g.nch, rows_mode(g), lds, {
+        auto kernel = k_decode_slices<C, R, T>;
+        if (T) {
+            const hipError_t e = allow_big_lds(kernel);
+            if (e != hipSuccess) return e;
+        }
+        kernel<<<dim3(blocks), dim3(64), T ? kLdsTableBytes : 0, stream>>>(g, arg, d_units, d_slice_len, d_states,
+                                                                          d_rec, d_status);
+    });
     return hipGetLastError();
 }
 

@@ -323,6 +323,24 @@ def test_one_row_slices_through_both_kernel_families(mi, orc, monkeypatch):
             assert np.array_equal(mi.decompress_image(s).pixels, img)
 
 
+def test_state_table_in_lds_or_hbm_same_bytes(mi, orc, monkeypatch):
+    """With one slice per wavefront (a lone legacy stream, a few big tiles) the 63 KB state table of the slice lives in
+    LDS; LLCOMP_MI_NOLDSTAB=1 keeps it in HBM like every multi-lane launch.  Same bytes either way, all channel counts."""
+    for c in (1, 2, 3, 4):
+        img = make_image("g3", 97, 41, c)
+        img[:, 40:] = make_image("mid", 57, 41, c)
+        legacy = orc.compress_image(img)
+        tiled = orc.compress_sliced(img, 50, 21, False)
+        for off in ("0", "1"):
+            monkeypatch.setenv("LLCOMP_MI_NOLDSTAB", off)
+            s = mi.compress_image(img, 97, 41, c)
+            assert s == legacy
+            assert np.array_equal(mi.decompress_image(s).pixels, img)
+            t = mi.compress_image(img, 97, 41, c, format=mi.FORMAT_SLICED, tile_w=50, tile_h=21, planar=False)
+            assert t == tiled
+            assert np.array_equal(mi.decompress_image(t).pixels, img)
+
+
 def test_decoder_rollback_and_checked_replay(mi, orc, monkeypatch):
     """The decoder's fast path never checks its input window; a sample that outruns the window is rolled back and
     replayed with per-step refills.  That almost never happens on real data, so LLCOMP_MI_FORCE_REPLAY=1 sends EVERY
