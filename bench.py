@@ -20,7 +20,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 W4K, H4K, C4K = 3840, 2160, 3
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -28,17 +27,17 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 def make_frames(content, frames, rank):
     import numpy as np
-    import orc as orc_mod
+    from llcomp_amd import synth
 
     out = np.empty((frames, H4K, W4K, C4K), dtype=np.uint8)
     for i in range(frames):
         seed = 1234 + rank * frames + i
         if content == "g3":
-            out[i] = orc_mod.gen_g3(W4K, H4K, C4K, seed=seed)
+            out[i] = synth.gen_g3(W4K, H4K, C4K, seed=seed)
         elif content == "g2":
-            out[i] = np.roll(orc_mod.gen_g2(W4K, H4K, C4K), (seed - 1234) * 5, axis=1)
+            out[i] = np.roll(synth.gen_g2(W4K, H4K, C4K), (seed - 1234) * 5, axis=1)
         else:
-            out[i] = orc_mod.gen_mid(W4K, H4K, C4K, seed=seed)
+            out[i] = synth.gen_mid(W4K, H4K, C4K, seed=seed)
     return out
 
 
@@ -47,6 +46,8 @@ def cpu_baseline(content, tile_w, tile_h, planar):
     llcomp.hpp compiled in place (oracle/_ref, whole-image stream: O2 encode + unmodified decompressImage);
     kind 'port' = the plain-C restatement (same sliced container as the GPU produces)."""
     import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))  # the checker: imported by this leg of the bench only
     import orc as orc_mod
 
     img = make_frames(content, 1, 0)[0]

@@ -2,18 +2,20 @@
 // binary models and the 16-bit carry-propagating range coder (llcomp.hpp:33-127, 166-247, 283-293, 439-449,
 // 486-530), one LANE per slice, 1..64 independent slices per wavefront, all lanes in lockstep per coding phase.
 //
-// What shapes the code (measured with rocprofv3 SQ counters, profiles/):
-//   * a lone wavefront issues one instruction every ~4.4 cycles, so the cost of a bin is its INSTRUCTION COUNT;
-//     the renormalisation of the decoder is branch-free, its input bytes come from a 64-bit register window that
-//     is topped up once per sample, the encoder's output bytes go to a small per-lane LDS ring that is flushed
-//     16 bytes at a time;
+// What shapes the code (measured with rocprofv3 SQ counters, profiles/; DESIGN.md section 4):
+//   * the kernels are instruction-issue bound, so the cost of a bin is its INSTRUCTION COUNT (and which of them are
+//     4-cycle operations): the coded bit is kept in VCC so that selects are 2-cycle v_cndmask_e32, the decoder refills
+//     from a 64-bit register window inside one exec-masked region and tops the window up once per sample, the
+//     encoder renormalises in 7 instructions with eager carry propagation, its output bytes go to a per-lane LDS ring
+//     that is flushed 16 bytes at a time;
 //   * the model table lives in LDS as 8-byte entries {P, next0, next1, P(next0), P(next1)}: the 8 entries of a
 //     context are requested together when the context is known, and inside a run of bins on one slot (unary
 //     exponent tail, mantissa tail) the next probability is already in registers while the successor's entry is
 //     still on its way, so LDS latency stays off the range-coder recurrence;
 //   * 1-row slices (tile_h == 1) can only ever reach 3 contexts (llcomp.hpp:417-429 with h == 0: hash =
-//     605*quant5(L-l)), so their 24 state bytes stay in registers and the kernel touches no state memory at all;
-//     taller slices keep a private 63 KB table (u64 per context) in HBM, fetched one context per sample.
+//     605*quant5(L-l)), so their 24 state bytes stay in LDS and the kernel touches no state memory in HBM at all;
+//     taller slices keep a private 63 KB table (u64 per context) in HBM, fetched one context per sample -- or in
+//     LDS when a wavefront carries a single slice (LDSTAB).
 #include <algorithm>
 #include <cstdlib>
 

@@ -25,52 +25,11 @@ def _p(a, t):
     return a.ctypes.data_as(t)
 
 
-# ---- deterministic input generators shared by fixtures, tests and bench -------------
-def gen_g1(w, h, c):
-    y, x, k = np.meshgrid(np.arange(h), np.arange(w), np.arange(c), indexing="ij")
-    return ((x * 7 + y * 13 + k * 37 + ((x * y) & 3) * 5) & 0xFF).astype(np.uint8)
+# ---- deterministic input generators: llcomp_amd/synth.py (re-exported for the fixtures and tests) ----------
+import sys as _sys
 
-
-def gen_g2(w, h, c):
-    y, x, k = np.meshgrid(np.arange(h), np.arange(w), np.arange(c), indexing="ij")
-    return ((x + y + 37 * k) & 0xFF).astype(np.uint8)
-
-
-def gen_g3(w, h, c, seed=1234):
-    """std::mt19937(seed), one draw per sample in (y,x,k) order, & 0xFF (numpy's MT19937 is the same
-    generator; random_raw yields the same 32-bit outputs as std::mt19937::operator())."""
-    from numpy.random import MT19937
-
-    bg = MT19937()
-    # seed exactly like std::mt19937(seed): the classic init_genrand recurrence
-    st = np.zeros(624, dtype=np.uint32)
-    st[0] = seed & 0xFFFFFFFF
-    for i in range(1, 624):
-        st[i] = (1812433253 * (int(st[i - 1]) ^ (int(st[i - 1]) >> 30)) + i) & 0xFFFFFFFF
-    bg.state = {"bit_generator": "MT19937", "state": {"key": st, "pos": 624}}
-    raw = bg.random_raw(w * h * c)
-    return (raw & 0xFF).astype(np.uint8).reshape(h, w, c)
-
-
-def gen_mid(w, h, c, seed=7):
-    """mid-entropy integer pattern: G2 gradient + small LCG dither in [-8,7] (no floating point)."""
-    n = w * h * c
-    a = np.arange(n, dtype=np.uint64)
-    # closed-form-free LCG via vectorised hash of the index (splitmix-like, integer only)
-    z = (a + np.uint64(seed)) * np.uint64(0x9E3779B97F4A7C15)
-    z ^= z >> np.uint64(30)
-    z *= np.uint64(0xBF58476D1CE4E5B9)
-    z ^= z >> np.uint64(27)
-    d = ((z >> np.uint64(60)).astype(np.int64) - 8).reshape(h, w, c)
-    return ((gen_g2(w, h, c).astype(np.int64) + d) & 0xFF).astype(np.uint8)
-
-
-def gen_checker(w, h, c):
-    y, x, k = np.meshgrid(np.arange(h), np.arange(w), np.arange(c), indexing="ij")
-    return (((x + y + k) & 1) * 255).astype(np.uint8)
-
-
-GENERATORS = {"g1": gen_g1, "g2": gen_g2, "g3": gen_g3, "mid": gen_mid, "checker": gen_checker}
+_sys.path.insert(0, os.path.dirname(_HERE))
+from llcomp_amd.synth import GENERATORS, gen_checker, gen_g1, gen_g2, gen_g3, gen_mid  # noqa: E402,F401
 
 
 def fnv1a64(b: bytes) -> int:

@@ -14,7 +14,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
 def main():
@@ -30,7 +29,7 @@ def main():
     import torch.distributed as dist
 
     import llcomp_amd as mi
-    import orc as orc_mod
+    from llcomp_amd import synth as orc_mod
     from llcomp_amd import sharding
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))

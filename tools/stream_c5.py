@@ -14,7 +14,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 W, H, C = 3840, 2160, 3
 
 
@@ -31,7 +30,7 @@ def main():
     import torch
 
     import llcomp_amd as mi
-    import orc as orc_mod
+    from llcomp_amd import synth as orc_mod
 
     B = args.batch
     nb = args.frames // B
