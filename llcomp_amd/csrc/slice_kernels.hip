@@ -113,12 +113,14 @@ __device__ __forceinline__ entry_t entry_at(const entry_t* tab, uint32_t nx) {
 // `pos` starts at -1: the reference emits nothing for its first renormalisation (outstanding_byte == -1); here a dummy
 // byte goes to position -1 instead, which is the same thing without the special case.
 struct RangeEnc {
-    uint32_t low, range;
-    uint32_t held;    // the byte held back, 0..255
+    uint32_t low;     // bits 0..15: the reference's low; bits 16..23: the byte held back (its outstanding_byte), so a
+                      // carry out of the low 16 bits lands in the held byte by itself; bit 24: that byte overflowed
+    uint32_t range;
     int32_t pos;      // bytes produced so far
     int32_t flushed;  // bytes already stored to HBM (multiple of 16)
     uint8_t* ring8;   // the block's LDS staging area; this lane's 32-byte ring starts at ring8[slot]
     uint32_t slot;    // lane * 32
+    uint32_t ring_lds;  // LDS byte address of ring8[0] (for the one store that is issued by hand)
     uint8_t* out;     // this lane's first 16-byte unit in the stream lane order array
     int32_t cap;
     uint32_t shift;   // lane_shift
@@ -160,23 +162,20 @@ __device__ __forceinline__ void enc_carry_back(RangeEnc& e) {
         if (v != 0xFF) break;
     }
 }
-// low = (low & 0xFF) << 8 as one SDWA shift (hipcc: shift + and)
-__device__ __forceinline__ uint32_t low_byte_up(uint32_t low) {
-    uint32_t r;
-    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
-        : "=v"(r) : "v"(8u), "v"(low));
-    return r;
-}
 // Renormalisation (body of the reference's `while (range < 0x100)`: one step always suffices because range >= 7 after
-// put() and == 0xFF in finish()).  One exec-masked region for the lanes that renormalise.
+// put() and == 0xFF in finish()).  One exec-masked region for the lanes that renormalise: five instructions and a store.
+// The held byte is stored straight out of bits 16..23 of `low` (ds_write_b8_d16_hi), then the 16 low bits move up by 8:
+// the old bits 8..15 become the new held byte.
 __device__ __forceinline__ void enc_renorm(RangeEnc& e) {
     if (e.range < 0x100) {
-        const uint32_t b = e.held + (e.low >> 16);  // held + carry
-        ring_at(e, uint32_t(e.pos)) = uint8_t(b);
-        if (__builtin_expect(b > 0xFF, 0)) enc_carry_back(e);
+        uint32_t idx;
+        asm volatile("v_and_or_b32 %0, %1, 31, %2\n\t"
+                     "ds_write_b8_d16_hi %0, %3"
+                     : "=&v"(idx) : "v"(e.pos), "v"(e.slot + e.ring_lds), "v"(e.low) : "memory");
+        if (__builtin_expect(e.low > 0xFFFFFFu, 0)) enc_carry_back(e);  // held was 0xFF and a carry arrived
         ++e.pos;
-        e.held = __builtin_amdgcn_ubfe(e.low, 8, 8);
-        e.low = low_byte_up(e.low);
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+            : "=v"(e.low) : "v"(8u), "v"(e.low));  // (low & 0xFFFF) << 8
         e.range <<= 8;
     }
 }
@@ -302,7 +301,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
                                                       uint8_t* __restrict__ scratch, uint32_t* __restrict__ slice_len,
                                                       uint32_t* status) {
     __shared__ entry_t tab[128];
-    __shared__ __attribute__((aligned(16))) uint8_t ring[kRingBytes * 64];
+    __shared__ __attribute__((aligned(32))) uint8_t ring[kRingBytes * 64];
     __shared__ unsigned long long rowbank[ROWS ? 3 * 64 : 1];
     clear_lds_states<LDSTAB>();
     load_table(tab);
@@ -310,10 +309,11 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     if (threadIdx.x >= lpw || id >= g.n_slices) return;
     const SliceRect r = slice_rect(g, id);
     RangeEnc e;
-    e.low = 0; e.range = 0xFF00; e.held = 0;  // llcomp.hpp:35 (held: see RangeEnc)
+    e.low = 0; e.range = 0xFF00;  // llcomp.hpp:35 (held byte: see RangeEnc)
     e.pos = -1; e.flushed = 0;
     e.ring8 = ring;
     e.slot = threadIdx.x * kRingBytes;
+    e.ring_lds = uint32_t(uintptr_t((__attribute__((address_space(3))) uint8_t*)ring));
     e.out = scratch + ((((size_t(id >> g.lane_shift) * (g.slice_cap >> 4)) << g.lane_shift) + (id & ((1u << g.lane_shift) - 1))) << 4);
     e.cap = int32_t(g.slice_cap);
     e.shift = g.lane_shift;
