@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
 // slice read as 0 (llcomp.hpp:475-479).
 struct RangeDec {
     uint32_t low, range;
-    uint32_t wlo, whi;      // window, LSB first; bits above `nb` bytes are zero
+    unsigned long long win; // window, LSB first (next byte = win & 0xFF); bits above `nb` bytes are zero
     int32_t nb;             // valid bytes in the window
     uint32_t nxt;           // prefetched dword that follows the window
     const uint32_t* group;  // WAVE-UNIFORM: first dword of this lane group in the stream lane order array
@@ -426,8 +426,7 @@ __device__ __forceinline__ void dec_append(RangeDec& d) {  // requires 0 <= nb <
     const uint32_t ready = consume_here(d.nxt);
     // window |= ready << (8 * nb): one 64-bit shift (0, 8, 16, 24 or 32 bits) and two ORs
     const unsigned long long t = (unsigned long long)ready << (8u * uint32_t(d.nb));
-    d.wlo |= uint32_t(t);
-    d.whi |= uint32_t(t >> 32);
+    d.win |= t;
     d.nb += 4;
     dec_prefetch(d, d.kn++);
 }
@@ -437,22 +436,26 @@ __device__ __forceinline__ void dec_open(RangeDec& d, const uint32_t* group, uin
     d.shift = shift;
     d.kmax1 = (len + 3) >> 2;
     dec_prefetch(d, 0);
-    d.wlo = d.nxt;
-    d.whi = 0;
+    d.win = d.nxt;
     d.nb = 4;
     dec_prefetch(d, 1);
     d.kn = 2;
     dec_append(d);
     d.range = 0xFF00;  // llcomp.hpp:93-96: low = first two bytes
-    d.low = ((d.wlo & 0xFF) << 8) | ((d.wlo >> 8) & 0xFF);
-    d.wlo = __builtin_amdgcn_alignbit(d.whi, d.wlo, 16);
-    d.whi >>= 16;
+    d.low = ((uint32_t(d.win) & 0xFF) << 8) | ((uint32_t(d.win) >> 8) & 0xFF);
+    d.win >>= 16;
     d.nb -= 2;
 }
 // CHECKED == false is the fast path: it never looks at the fill level of the window.  The kernel tops the window up to
 // >= 5 bytes before every sample and afterwards looks at `nb` once: a negative value means the sample consumed more
 // bytes than the window held (possible, a sample can take up to 13 bytes, but rare); the coder state is then rolled
 // back and the sample is decoded again with CHECKED == true, which refills inside the step.
+// window >>= 8 as ONE 64-bit shift (hipcc splits it into v_perm + v_lshr)
+__device__ __forceinline__ unsigned long long window_next(unsigned long long w) {
+    unsigned long long r;
+    asm("v_lshrrev_b64 %0, 8, %1" : "=v"(r) : "v"(w));
+    return r;
+}
 template <bool CHECKED>
 __device__ __forceinline__ bool dec_core(RangeDec& d, uint32_t P) {  // llcomp.hpp:98-121, branch-free refill
     if (CHECKED && d.nb <= 0) dec_append(d);
@@ -468,9 +471,8 @@ __device__ __forceinline__ bool dec_core(RangeDec& d, uint32_t P) {  // llcomp.h
     // add/sub/and/or/mov and shifts by a constant take 2; the branch-free form of this block cost eight 4-cycle ops.)
     if (d.range < 0x100) {
         d.range <<= 8;
-        d.low = (d.low << 8) | (d.wlo & 0xFF);  // low < range < 0x100 here
-        d.wlo = (d.wlo >> 8) | (d.whi << 24);
-        d.whi >>= 8;
+        d.low = (d.low << 8) | (uint32_t(d.win) & 0xFF);  // low < range < 0x100 here
+        d.win = window_next(d.win);
         d.nb -= 1;
     }
     return bit;
@@ -495,9 +497,8 @@ __device__ __forceinline__ uint32_t dec_step_acc(RangeDec& d, uint32_t P, entry_
         : "vcc");
     if (d.range < 0x100) {  // refill: see dec_core
         d.range <<= 8;
-        d.low = (d.low << 8) | (d.wlo & 0xFF);
-        d.wlo = (d.wlo >> 8) | (d.whi << 24);
-        d.whi >>= 8;
+        d.low = (d.low << 8) | (uint32_t(d.win) & 0xFF);
+        d.win = window_next(d.win);
         d.nb -= 1;
     }
     return nx;
@@ -575,11 +576,12 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, uint32_t (&bank)[2], c
 // One sample: fast path first, checked replay when the window ran dry (or the fast path saw nonsense because of it).
 __device__ __forceinline__ bool dec_sample(RangeDec& d, uint32_t (&bank)[2], const entry_t* tab, bool hot, bool replay_always,
                                            uint32_t& v) {
-    const uint32_t s_low = d.low, s_range = d.range, s_wlo = d.wlo, s_whi = d.whi, s_b0 = bank[0], s_b1 = bank[1];
+    const uint32_t s_low = d.low, s_range = d.range, s_b0 = bank[0], s_b1 = bank[1];
+    const unsigned long long s_win = d.win;
     const int32_t s_nb = d.nb;
     bool ok = hot ? dec_residual<true, false>(d, bank, tab, v) : dec_residual<false, false>(d, bank, tab, v);
     if (__builtin_expect(!ok || d.nb < 0 || replay_always, 0)) {
-        d.low = s_low; d.range = s_range; d.wlo = s_wlo; d.whi = s_whi; d.nb = s_nb;
+        d.low = s_low; d.range = s_range; d.win = s_win; d.nb = s_nb;
         bank[0] = s_b0; bank[1] = s_b1;
         ok = dec_residual<false, true>(d, bank, tab, v);
     }
