@@ -395,11 +395,12 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
 // ================================================ DECODER ========================================================
 // Range decoder of one lane (llcomp.hpp:91-127).  The stream is consumed through a 64-bit register window (next byte
 // = window & 0xFF) that is topped up with aligned dword loads, one dword prefetched ahead; bytes past the end of the
-// slice read as 0 (llcomp.hpp:475-479).
+// slice read as 0 (llcomp.hpp:475-479).  The fill level is not counted: a SENTINEL 1 bit sits right above the valid
+// bytes (bit 8 * valid), so consuming a byte is just the shift, "at most 3 bytes left" is `high dword == 0`, and
+// "consumed more than there was" is `window == 0` (the sentinel itself was shifted out).
 struct RangeDec {
     uint32_t low, range;
-    unsigned long long win; // window, LSB first (next byte = win & 0xFF); bits above `nb` bytes are zero
-    int32_t nb;             // valid bytes in the window
+    unsigned long long win; // window, LSB first (next byte = win & 0xFF), sentinel bit above the valid bytes
     uint32_t nxt;           // prefetched dword that follows the window
     const uint32_t* group;  // WAVE-UNIFORM: first dword of this lane group in the stream lane order array
     uint32_t lane_dw;       // this lane's dword offset inside a row of units (lane * 4)
@@ -408,6 +409,7 @@ struct RangeDec {
                             // of the stream inside the last dword) reads zero, as llcomp.hpp:475-479 wants
     uint32_t kn;            // next dword to prefetch
 };
+__device__ __forceinline__ bool window_low(const RangeDec& d) { return uint32_t(d.win >> 32) == 0; }  // <= 3 bytes
 // issues the load of dword k.  UNCONDITIONAL (index clamped to the zero dword behind the stream) so that its result
 // lands directly in the loop-carried register -- a conditional load ends in a register copy and hipcc waits vmcnt(0)
 // for that copy right after the issue; 32-bit offset from a wave-uniform base = one global_load with an SGPR base.
@@ -422,12 +424,12 @@ __device__ __forceinline__ uint32_t consume_here(uint32_t v) {
     asm volatile("" : "+v"(v) : : "memory");
     return v;
 }
-__device__ __forceinline__ void dec_append(RangeDec& d) {  // requires 0 <= nb <= 4
+__device__ __forceinline__ void dec_append(RangeDec& d) {  // requires window_low(d) and win != 0
     const uint32_t ready = consume_here(d.nxt);
-    // window |= ready << (8 * nb): one 64-bit shift (0, 8, 16, 24 or 32 bits) and two ORs
-    const unsigned long long t = (unsigned long long)ready << (8u * uint32_t(d.nb));
-    d.win |= t;
-    d.nb += 4;
+    // the sentinel (bit sh = 0, 8, 16 or 24 of the low dword) is replaced by the new dword with a sentinel above it
+    const uint32_t sh = 31u - uint32_t(__builtin_clz(uint32_t(d.win)));
+    const uint32_t rest = uint32_t(d.win) ^ (1u << sh);  // (the high dword is zero here)
+    d.win = ((0x100000000ull | ready) << sh) | rest;
     dec_prefetch(d, d.kn++);
 }
 __device__ __forceinline__ void dec_open(RangeDec& d, const uint32_t* group, uint32_t lane_dw, uint32_t shift, uint32_t len) {
@@ -436,20 +438,19 @@ __device__ __forceinline__ void dec_open(RangeDec& d, const uint32_t* group, uin
     d.shift = shift;
     d.kmax1 = (len + 3) >> 2;
     dec_prefetch(d, 0);
-    d.win = d.nxt;
-    d.nb = 4;
+    const uint32_t first = d.nxt;
     dec_prefetch(d, 1);
-    d.kn = 2;
-    dec_append(d);
+    const unsigned long long both = first | ((unsigned long long)d.nxt << 32);
+    dec_prefetch(d, 2);
+    d.kn = 3;
     d.range = 0xFF00;  // llcomp.hpp:93-96: low = first two bytes
-    d.low = ((uint32_t(d.win) & 0xFF) << 8) | ((uint32_t(d.win) >> 8) & 0xFF);
-    d.win >>= 16;
-    d.nb -= 2;
+    d.low = ((first & 0xFF) << 8) | ((first >> 8) & 0xFF);
+    d.win = (both >> 16) | (1ull << 48);  // six bytes left
 }
 // CHECKED == false is the fast path: it never looks at the fill level of the window.  The kernel tops the window up to
-// >= 5 bytes before every sample and afterwards looks at `nb` once: a negative value means the sample consumed more
-// bytes than the window held (possible, a sample can take up to 13 bytes, but rare); the coder state is then rolled
-// back and the sample is decoded again with CHECKED == true, which refills inside the step.
+// >= 4 bytes before every sample and afterwards looks at it once: an empty window (the sentinel is gone) means the
+// sample consumed more bytes than the window held (possible, a sample can take up to 13 bytes, but rare); the coder
+// state is then rolled back and the sample is decoded again with CHECKED == true, which refills inside the step.
 // window >>= 8 as ONE 64-bit shift (hipcc splits it into v_perm + v_lshr)
 __device__ __forceinline__ unsigned long long window_next(unsigned long long w) {
     unsigned long long r;
@@ -458,7 +459,7 @@ __device__ __forceinline__ unsigned long long window_next(unsigned long long w) 
 }
 template <bool CHECKED>
 __device__ __forceinline__ bool dec_core(RangeDec& d, uint32_t P) {  // llcomp.hpp:98-121, branch-free refill
-    if (CHECKED && d.nb <= 0) dec_append(d);
+    if (CHECKED && d.win <= 1) dec_append(d);  // no byte left
     const uint32_t r1 = __umul24(d.range, P) >> 8;
     const uint32_t r0 = d.range - r1;
     uint32_t diff;
@@ -473,7 +474,6 @@ __device__ __forceinline__ bool dec_core(RangeDec& d, uint32_t P) {  // llcomp.h
         d.range <<= 8;
         d.low = (d.low << 8) | (uint32_t(d.win) & 0xFF);  // low < range < 0x100 here
         d.win = window_next(d.win);
-        d.nb -= 1;
     }
     return bit;
 }
@@ -482,7 +482,7 @@ __device__ __forceinline__ bool dec_core(RangeDec& d, uint32_t P) {  // llcomp.h
 // Returns the half of entry `cur` that belongs to the decoded bit.
 template <bool CHECKED>
 __device__ __forceinline__ uint32_t dec_step_acc(RangeDec& d, uint32_t P, entry_t cur, uint32_t& w) {
-    if (CHECKED && d.nb <= 0) dec_append(d);
+    if (CHECKED && d.win <= 1) dec_append(d);  // no byte left
     const uint32_t r1 = __umul24(d.range, P) >> 8;
     const uint32_t r0 = d.range - r1;
     uint32_t diff, nx;
@@ -499,7 +499,6 @@ __device__ __forceinline__ uint32_t dec_step_acc(RangeDec& d, uint32_t P, entry_
         d.range <<= 8;
         d.low = (d.low << 8) | (uint32_t(d.win) & 0xFF);
         d.win = window_next(d.win);
-        d.nb -= 1;
     }
     return nx;
 }
@@ -578,10 +577,9 @@ __device__ __forceinline__ bool dec_sample(RangeDec& d, uint32_t (&bank)[2], con
                                            uint32_t& v) {
     const uint32_t s_low = d.low, s_range = d.range, s_b0 = bank[0], s_b1 = bank[1];
     const unsigned long long s_win = d.win;
-    const int32_t s_nb = d.nb;
     bool ok = hot ? dec_residual<true, false>(d, bank, tab, v) : dec_residual<false, false>(d, bank, tab, v);
-    if (__builtin_expect(!ok || d.nb < 0 || replay_always, 0)) {
-        d.low = s_low; d.range = s_range; d.win = s_win; d.nb = s_nb;
+    if (__builtin_expect(!ok || d.win == 0 || replay_always, 0)) {
+        d.low = s_low; d.range = s_range; d.win = s_win;
         bank[0] = s_b0; bank[1] = s_b1;
         ok = dec_residual<false, true>(d, bank, tab, v);
     }
@@ -634,7 +632,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
         for (uint32_t x = 0; x < r.sw; ++x) {
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
-                if (d.nb <= 4) dec_append(d);
+                if (window_low(d)) dec_append(d);
                 gbase[held_off] = int16_t(held_val);
                 const int lv = l[k];                 // x == 0: 128
                 const int Lv = x > 1 ? L[k] : lv;    // llcomp.hpp:496
@@ -689,7 +687,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 }
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
-                    if (d.nb <= 4) dec_append(d);
+                    if (window_low(d)) dec_append(d);
                     const Hood n = apply_borders(l[k], L[k], t[k], tl[k], tr[k], T[k], x, y, r.sw);
                     int ctx = context_hash(n);
                     const bool neg = ctx < 0;  // llcomp.hpp:511-515
