@@ -55,6 +55,18 @@ __device__ __forceinline__ void set_slot_state(uint32_t (&bank)[2], uint32_t ns)
     constexpr int W = SLOT >> 2, SH = (SLOT & 3) * 8;
     bank[W] = (bank[W] & ~(0xFFu << SH)) | (ns << SH);
 }
+// The 8 state bytes of the context being coded (slot k = byte k).  For 1-row slices they live in LDS ([context][lane]):
+// a new state is then ONE byte store and the words below are a read-only copy; otherwise the words are updated and
+// written back by the caller.
+struct Bank {
+    uint32_t w[2];
+    uint8_t* lds;
+};
+template <int SLOT, bool INLDS>
+__device__ __forceinline__ void put_state(Bank& b, uint32_t ns) {  // ns: new state in byte 0
+    if constexpr (INLDS) b.lds[SLOT] = uint8_t(ns);
+    else set_slot_state<SLOT>(b.w, ns & 0xFF);
+}
 // successor state / successor probability of entry e for the coded bit
 __device__ __forceinline__ uint32_t prob_of(entry_t e) { return byte_of(uint32_t(e), 2); }
 // half of the entry that belongs to the coded bit: byte0 = successor state, byte1 = its probability
@@ -141,7 +153,8 @@ __device__ __forceinline__ void enc_flush16(RangeEnc& e) {
     const uint32_t* w = reinterpret_cast<const uint32_t*>(e.ring8 + (e.slot | (uint32_t(e.flushed) & 16)));
     uint4 v;
     v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
-    if (e.flushed + 16 <= e.cap) *reinterpret_cast<uint4*>(unit_byte(e, uint32_t(e.flushed))) = v;
+    // `flushed` is a multiple of 16: its unit starts (flushed << lane_shift) bytes after the lane's first unit
+    if (e.flushed + 16 <= e.cap) *reinterpret_cast<uint4*>(e.out + (size_t(uint32_t(e.flushed)) << e.shift)) = v;
     e.flushed += 16;
 }
 // rare: +1 into the bytes before position `pos` (the byte at `pos` itself just wrapped from 0xFF to 0x00)
@@ -212,15 +225,15 @@ __device__ __forceinline__ uint32_t enc_step_msb(RangeEnc& e, uint32_t P, uint32
     return nx;
 }
 // a slot that is coded at most once per sample; the bit as a mask (all ones / zero) ...
-template <int SLOT>
-__device__ __forceinline__ void enc_once_m(RangeEnc& e, uint32_t (&bank)[2], const Entries& E, uint32_t m) {
+template <int SLOT, bool INLDS>
+__device__ __forceinline__ void enc_once_m(RangeEnc& e, Bank& bank, const Entries& E, uint32_t m) {
     enc_core(e, prob_of(E.get<SLOT>()), m);
-    set_slot_state<SLOT>(bank, successor_m(E.get<SLOT>(), m) & 0xFF);
+    put_state<SLOT, INLDS>(bank, successor_m(E.get<SLOT>(), m));
 }
 // ... or as a condition the caller branches on anyway: its compare leaves the bit in VCC, and all three selects are
 // issued before the renormalisation region so that they stay 2-cycle v_cndmask_e32
-template <int SLOT>
-__device__ __forceinline__ void enc_once(RangeEnc& e, uint32_t (&bank)[2], const Entries& E, bool bit) {
+template <int SLOT, bool INLDS>
+__device__ __forceinline__ void enc_once(RangeEnc& e, Bank& bank, const Entries& E, bool bit) {
     const entry_t en = E.get<SLOT>();
     const uint32_t r1 = __umul24(e.range, prob_of(en)) >> 8;
     const uint32_t r0 = e.range - r1;
@@ -228,26 +241,26 @@ __device__ __forceinline__ void enc_once(RangeEnc& e, uint32_t (&bank)[2], const
     e.range = bit ? r1 : r0;
     const uint32_t ns = successor(en, bit);
     enc_renorm(e);
-    set_slot_state<SLOT>(bank, ns & 0xFF);
+    put_state<SLOT, INLDS>(bank, ns);
 }
 
 // putSymbol<true,4,6,7> (llcomp.hpp:166-206).  All lanes walk the phases together, so the slot of every bin is a
 // compile-time constant.
-template <bool ALL>
-__device__ __forceinline__ void enc_residual(RangeEnc& e, uint32_t (&bank)[2], const entry_t* tab, int res) {
+template <bool ALL, bool INLDS>
+__device__ __forceinline__ void enc_residual(RangeEnc& e, Bank& bank, const entry_t* tab, int res) {
     Entries E;
-    fetch_slot0(E, bank, tab);
-    if (ALL) fetch_rest(E, bank, tab);
-    enc_once<0>(e, bank, E, res == 0);
+    fetch_slot0(E, bank.w, tab);
+    if (ALL) fetch_rest(E, bank.w, tab);
+    enc_once<0, INLDS>(e, bank, E, res == 0);
     if (res != 0) {
-        if (!ALL) fetch_rest(E, bank, tab);
+        if (!ALL) fetch_rest(E, bank.w, tab);
         const uint32_t a = uint32_t(res < 0 ? -res : res);
         const int ex = 31 - __clz(int(a));
-        enc_once<1>(e, bank, E, ex > 0);
+        enc_once<1, INLDS>(e, bank, E, ex > 0);
         if (ex > 0) {
-            enc_once<2>(e, bank, E, ex > 1);
+            enc_once<2, INLDS>(e, bank, E, ex > 1);
             if (ex > 1) {
-                enc_once<3>(e, bank, E, ex > 2);
+                enc_once<3, INLDS>(e, bank, E, ex > 2);
                 if (ex > 2) {  // unary tail on slot 4: (ex - 3) ones, then a zero
                     entry_t cur = E.e4;
                     uint32_t nx = uint32_t(cur) >> 8;  // byte 1 = probability of the current state
@@ -257,10 +270,10 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, uint32_t (&bank)[2], c
                         nx = enc_step_msb(e, (nx >> 8) & 0xFF, bits, cur);
                         cur = entry_at(tab, nx);
                     } while (bits != 0x80000000u);
-                    set_slot_state<4>(bank, nx & 0xFF);
+                    put_state<4, INLDS>(bank, nx);
                 }
             }
-            enc_once_m<5>(e, bank, E, uint32_t(__builtin_amdgcn_sbfe(int(a), uint32_t(ex - 1), 1u)));
+            enc_once_m<5, INLDS>(e, bank, E, uint32_t(__builtin_amdgcn_sbfe(int(a), uint32_t(ex - 1), 1u)));
             if (ex > 1) {  // mantissa tail on slot 6, MSB first
                 entry_t cur = E.e6;
                 uint32_t nx = uint32_t(cur) >> 8;
@@ -270,10 +283,10 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, uint32_t (&bank)[2], c
                     nx = enc_step_msb(e, (nx >> 8) & 0xFF, bits, cur);
                     cur = entry_at(tab, nx);
                 } while (bits != 0x80000000u);
-                set_slot_state<6>(bank, nx & 0xFF);
+                put_state<6, INLDS>(bank, nx);
             }
         }
-        enc_once_m<7>(e, bank, E, uint32_t(res >> 31));
+        enc_once_m<7, INLDS>(e, bank, E, uint32_t(res >> 31));
     }
 }
 
@@ -349,10 +362,9 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
             }
             unsigned long long* bp = &rowbank[cidx * 64 + threadIdx.x];
             const unsigned long long b64 = *bp;
-            uint32_t bank[2] = {uint32_t(b64), uint32_t(b64 >> 32)};
-            if (hot) enc_residual<true>(e, bank, tab, res); else enc_residual<false>(e, bank, tab, res);
+            Bank bank{{uint32_t(b64), uint32_t(b64 >> 32)}, reinterpret_cast<uint8_t*>(bp)};  // new states: byte stores
+            if (hot) enc_residual<true, true>(e, bank, tab, res); else enc_residual<false, true>(e, bank, tab, res);
             hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(res != 0)) >= __popcll(__ballot(true)));
-            *bp = (unsigned long long)bank[0] | ((unsigned long long)bank[1] << 32);
             s0 = s1;
             s1 = s2;
         }
@@ -372,10 +384,10 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
             const uint32_t ctx0 = s0 & 0xFFFF, ctx1 = s1 & 0xFFFF;
             const int res = int(s0) >> 16;
             uint64_t b1 = (i + 1 < total) ? banks[ctx1] : 0;
-            uint32_t bank[2] = {uint32_t(b0), uint32_t(b0 >> 32)};
-            if (hot) enc_residual<true>(e, bank, tab, res); else enc_residual<false>(e, bank, tab, res);
+            Bank bank{{uint32_t(b0), uint32_t(b0 >> 32)}, nullptr};
+            if (hot) enc_residual<true, false>(e, bank, tab, res); else enc_residual<false, false>(e, bank, tab, res);
             hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(res != 0)) >= __popcll(__ballot(true)));
-            b0 = uint64_t(bank[0]) | (uint64_t(bank[1]) << 32);
+            b0 = uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32);
             banks[ctx0] = b0;
             if (ctx1 == ctx0) b1 = b0;  // the prefetched copy is stale: forward
             b0 = b1;
@@ -502,30 +514,30 @@ __device__ __forceinline__ uint32_t dec_step_acc(RangeDec& d, uint32_t P, entry_
     }
     return nx;
 }
-template <int SLOT, bool CHECKED>
-__device__ __forceinline__ bool dec_once(RangeDec& d, uint32_t (&bank)[2], const Entries& E) {
+template <int SLOT, bool CHECKED, bool INLDS>
+__device__ __forceinline__ bool dec_once(RangeDec& d, Bank& bank, const Entries& E) {
     const bool bit = dec_core<CHECKED>(d, prob_of(E.get<SLOT>()));
-    set_slot_state<SLOT>(bank, next_state(E.get<SLOT>(), bit));
+    put_state<SLOT, INLDS>(bank, successor(E.get<SLOT>(), bit));
     return bit;
 }
 // getSymbol<true,4,6,7> (llcomp.hpp:219-247).  Returns false on "Invalid exponent".  Arithmetic modulo 2^32.
-template <bool ALL, bool CHECKED>
-__device__ __forceinline__ bool dec_residual(RangeDec& d, uint32_t (&bank)[2], const entry_t* tab, uint32_t& out) {
+template <bool ALL, bool CHECKED, bool INLDS>
+__device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entry_t* tab, uint32_t& out) {
     Entries E;
-    fetch_slot0(E, bank, tab);
-    if (ALL) fetch_rest(E, bank, tab);
-    if (dec_once<0, CHECKED>(d, bank, E)) {
+    fetch_slot0(E, bank.w, tab);
+    if (ALL) fetch_rest(E, bank.w, tab);
+    if (dec_once<0, CHECKED, INLDS>(d, bank, E)) {
         out = 0;
         return true;
     }
-    if (!ALL) fetch_rest(E, bank, tab);
+    if (!ALL) fetch_rest(E, bank.w, tab);
     int ex = 0;
     bool ok = true;
-    if (dec_once<1, CHECKED>(d, bank, E)) {
+    if (dec_once<1, CHECKED, INLDS>(d, bank, E)) {
         ex = 1;
-        if (dec_once<2, CHECKED>(d, bank, E)) {
+        if (dec_once<2, CHECKED, INLDS>(d, bank, E)) {
             ex = 2;
-            if (dec_once<3, CHECKED>(d, bank, E)) {
+            if (dec_once<3, CHECKED, INLDS>(d, bank, E)) {
                 entry_t cur = E.e4;
                 uint32_t nx = uint32_t(cur) >> 8;  // byte 1 = probability of the current state (entry_lo byte 2)
                 int n = 0;  // bins of the unary tail: n - 1 ones and the closing zero
@@ -541,7 +553,7 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, uint32_t (&bank)[2], c
                 // fast path: no per-step limit -- the run ends by itself once the window holds only zeros; a run
                 // longer than 31 is "Invalid exponent" (llcomp.hpp:230-235) and is confirmed by the checked replay
                 if (ex > 31) ok = false;
-                set_slot_state<4>(bank, nx & 0xFF);
+                put_state<4, INLDS>(bank, nx);
             }
         }
     }
@@ -551,7 +563,7 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, uint32_t (&bank)[2], c
     uint32_t w = 1;
     const uint32_t ones = (1u << ex) - 1;
     if (ex > 0) {
-        w += w + uint32_t(!dec_once<5, CHECKED>(d, bank, E));
+        w += w + uint32_t(!dec_once<5, CHECKED, INLDS>(d, bank, E));
         if (ex > 1) {
             entry_t cur = E.e6;
             uint32_t nx = uint32_t(cur) >> 8;
@@ -563,25 +575,28 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, uint32_t (&bank)[2], c
                 nx = dec_step_acc<CHECKED>(d, (nx >> 8) & 0xFF, cur, w);
                 cur = entry_at(tab, nx);
             } while (w < limit);
-            set_slot_state<6>(bank, nx & 0xFF);
+            put_state<6, INLDS>(bank, nx);
         }
     }
     uint32_t v = w ^ ones;
-    if (dec_once<7, CHECKED>(d, bank, E)) v = 0u - v;
+    if (dec_once<7, CHECKED, INLDS>(d, bank, E)) v = 0u - v;
     out = v;
     return true;
 }
 
 // One sample: fast path first, checked replay when the window ran dry (or the fast path saw nonsense because of it).
-__device__ __forceinline__ bool dec_sample(RangeDec& d, uint32_t (&bank)[2], const entry_t* tab, bool hot, bool replay_always,
+template <bool INLDS>
+__device__ __forceinline__ bool dec_sample(RangeDec& d, Bank& bank, const entry_t* tab, bool hot, bool replay_always,
                                            uint32_t& v) {
-    const uint32_t s_low = d.low, s_range = d.range, s_b0 = bank[0], s_b1 = bank[1];
+    const uint32_t s_low = d.low, s_range = d.range, s_b0 = bank.w[0], s_b1 = bank.w[1];
     const unsigned long long s_win = d.win;
-    bool ok = hot ? dec_residual<true, false>(d, bank, tab, v) : dec_residual<false, false>(d, bank, tab, v);
+    bool ok = hot ? dec_residual<true, false, INLDS>(d, bank, tab, v) : dec_residual<false, false, INLDS>(d, bank, tab, v);
     if (__builtin_expect(!ok || d.win == 0 || replay_always, 0)) {
         d.low = s_low; d.range = s_range; d.win = s_win;
-        bank[0] = s_b0; bank[1] = s_b1;
-        ok = dec_residual<false, true>(d, bank, tab, v);
+        bank.w[0] = s_b0; bank.w[1] = s_b1;
+        if constexpr (INLDS)  // the fast path has already stored new states: put the old ones back
+            *reinterpret_cast<unsigned long long*>(bank.lds) = (unsigned long long)s_b0 | ((unsigned long long)s_b1 << 32);
+        ok = dec_residual<false, true, INLDS>(d, bank, tab, v);
     }
     return ok;
 }
@@ -642,15 +657,14 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 const uint32_t cidx = min(aq, 1u) + (aq > 3 ? 1u : 0u);  // |quant5(L - l)|
                 unsigned long long* bp = &rowbank[cidx * 64 + threadIdx.x];
                 const unsigned long long b64 = *bp;
-                uint32_t bank[2] = {uint32_t(b64), uint32_t(b64 >> 32)};
+                Bank bank{{uint32_t(b64), uint32_t(b64 >> 32)}, reinterpret_cast<uint8_t*>(bp)};
                 uint32_t v;
-                const bool ok = dec_sample(d, bank, tab, hot, replay_always, v);
+                const bool ok = dec_sample<true>(d, bank, tab, hot, replay_always, v);
                 if (!ok) {
                     atomicOr(status, kStBadExponent);
                     return;
                 }
                 hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true)));
-                *bp = (unsigned long long)bank[0] | ((unsigned long long)bank[1] << 32);
                 if (neg) v = 0u - v;
                 const int val = int(int16_t(uint32_t(lv) + v));
                 held_val = val;
@@ -693,15 +707,15 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                     const bool neg = ctx < 0;  // llcomp.hpp:511-515
                     if (neg) ctx = -ctx;
                     const uint64_t b64 = banks[ctx];
-                    uint32_t bank[2] = {uint32_t(b64), uint32_t(b64 >> 32)};
+                    Bank bank{{uint32_t(b64), uint32_t(b64 >> 32)}, nullptr};
                     uint32_t v;
-                    const bool ok = dec_sample(d, bank, tab, hot, replay_always, v);
+                    const bool ok = dec_sample<false>(d, bank, tab, hot, replay_always, v);
                     if (!ok) {
                         atomicOr(status, kStBadExponent);
                         return;  // this lane's slice is unusable; the whole call reports the error
                     }
                     hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true)));
-                    banks[ctx] = uint64_t(bank[0]) | (uint64_t(bank[1]) << 32);
+                    banks[ctx] = uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32);
                     if (neg) v = 0u - v;
                     const int val = int(int16_t(uint32_t(predict(n)) + v));
                     q[k * GW] = int16_t(val);
