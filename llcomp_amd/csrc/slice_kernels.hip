@@ -185,7 +185,12 @@ __device__ __forceinline__ void enc_renorm(RangeEnc& e) {
         asm volatile("v_and_or_b32 %0, %1, 31, %2\n\t"
                      "ds_write_b8_d16_hi %0, %3"
                      : "=&v"(idx) : "v"(e.pos), "v"(e.slot + e.ring_lds), "v"(e.low) : "memory");
-        if (__builtin_expect(e.low > 0xFFFFFFu, 0)) enc_carry_back(e);  // held was 0xFF and a carry arrived
+        // held was 0xFF and a carry arrived: rare, so the test is a wave-uniform branch (no exec bookkeeping when no
+        // lane needs it)
+        const bool wrapped = e.low > 0xFFFFFFu;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(wrapped) != 0, 0)) {
+            if (wrapped) enc_carry_back(e);
+        }
         ++e.pos;
         asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
             : "=v"(e.low) : "v"(8u), "v"(e.low));  // (low & 0xFFFF) << 8
@@ -208,17 +213,18 @@ __device__ __forceinline__ uint32_t successor_m(entry_t e, uint32_t m) {  // suc
 // One bin of a run on one slot (unary tail, mantissa tail): codes the top bit of `bits`, shifts `bits` left and returns
 // the half of entry `cur` that belongs to the coded bit.  The shift is an add with carry-out, so the bit arrives in VCC
 // and the three selects are 2-cycle v_cndmask_e32 (a mask in a VGPR costs a 4-cycle v_bfi per select).
-__device__ __forceinline__ uint32_t enc_step_msb(RangeEnc& e, uint32_t P, uint32_t& bits, entry_t cur) {
-    const uint32_t r1 = __umul24(e.range, P) >> 8;
-    const uint32_t r0 = e.range - r1;
-    uint32_t add, nx;
+__device__ __forceinline__ uint32_t enc_step_msb(RangeEnc& e, uint32_t prev, uint32_t& bits, entry_t cur) {
+    uint32_t add, nx, r1, r0;
+    // (the shift goes first: the three instructions between it and the first select cover the VCC hazard, no s_nop)
     asm("v_add_co_u32_e32 %[bits], vcc, %[bits], %[bits]\n\t"
-        "s_nop 1\n\t"
+        "v_mul_u32_u24_sdwa %[r1], %[prev], %[range] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_e32 %[r1], 8, %[r1]\n\t"
+        "v_sub_u32_e32 %[r0], %[range], %[r1]\n\t"
         "v_cndmask_b32_e32 %[add], 0, %[r0], vcc\n\t"
         "v_cndmask_b32_e32 %[range], %[r0], %[r1], vcc\n\t"
         "v_cndmask_b32_e32 %[nx], %[lo], %[hi], vcc"
-        : [bits] "+v"(bits), [add] "=&v"(add), [range] "=&v"(e.range), [nx] "=v"(nx)
-        : [r0] "v"(r0), [r1] "v"(r1), [lo] "v"(uint32_t(cur)), [hi] "v"(uint32_t(cur >> 32))
+        : [bits] "+v"(bits), [add] "=&v"(add), [range] "+v"(e.range), [nx] "=v"(nx), [r1] "=&v"(r1), [r0] "=&v"(r0)
+        : [prev] "v"(prev), [lo] "v"(uint32_t(cur)), [hi] "v"(uint32_t(cur >> 32))  // byte 1 of prev = probability
         : "vcc");
     e.low += add;
     enc_renorm(e);
@@ -267,7 +273,7 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, Bank& bank, const entr
                     // the bins left-aligned -- (ex - 3) ones, a zero -- followed by a sentinel 1 (as in the mantissa loop)
                     uint32_t bits = ((0xFFFFFFFCu << (ex - 3)) ^ 0xFFFFFFFDu) << (33 - ex);
                     do {
-                        nx = enc_step_msb(e, (nx >> 8) & 0xFF, bits, cur);
+                        nx = enc_step_msb(e, nx, bits, cur);
                         cur = entry_at(tab, nx);
                     } while (bits != 0x80000000u);
                     put_state<4, INLDS>(bank, nx);
@@ -280,7 +286,7 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, Bank& bank, const entr
                 // remaining mantissa bits left-aligned, followed by a sentinel 1: the loop needs no counter
                 uint32_t bits = ((a << 1) | 1u) << (32 - ex);
                 do {
-                    nx = enc_step_msb(e, (nx >> 8) & 0xFF, bits, cur);
+                    nx = enc_step_msb(e, nx, bits, cur);
                     cur = entry_at(tab, nx);
                 } while (bits != 0x80000000u);
                 put_state<6, INLDS>(bank, nx);
