@@ -213,20 +213,24 @@ __device__ __forceinline__ uint32_t successor_m(entry_t e, uint32_t m) {  // suc
 // One bin of a run on one slot (unary tail, mantissa tail): codes the top bit of `bits`, shifts `bits` left and returns
 // the half of entry `cur` that belongs to the coded bit.  The shift is an add with carry-out, so the bit arrives in VCC
 // and the three selects are 2-cycle v_cndmask_e32 (a mask in a VGPR costs a 4-cycle v_bfi per select).
-__device__ __forceinline__ uint32_t enc_step_msb(RangeEnc& e, uint32_t prev, uint32_t& bits, entry_t cur) {
-    uint32_t add, nx, r1, r0;
-    // (the shift goes first: the three instructions between it and the first select cover the VCC hazard, no s_nop)
+__device__ __forceinline__ uint32_t enc_step_msb(RangeEnc& e, uint32_t& bits, entry_t cur) {
+    uint32_t nx = uint32_t(cur), r1;
+    unsigned long long saved_exec;
+    // Every lane takes the bit-0 outcome (range -= r1, successor = low half of the entry); the lanes whose bit is 1
+    // then patch it up under exec = VCC: low += r0, range = r1, successor = high half.  Seven vector instructions; the
+    // two scalar ones ride along for free (the kernels are bound by VALU issue).
     asm("v_add_co_u32_e32 %[bits], vcc, %[bits], %[bits]\n\t"
-        "v_mul_u32_u24_sdwa %[r1], %[prev], %[range] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+        "v_mul_u32_u24_sdwa %[r1], %[nx], %[range] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n\t"
         "v_lshrrev_b32_e32 %[r1], 8, %[r1]\n\t"
-        "v_sub_u32_e32 %[r0], %[range], %[r1]\n\t"
-        "v_cndmask_b32_e32 %[add], 0, %[r0], vcc\n\t"
-        "v_cndmask_b32_e32 %[range], %[r0], %[r1], vcc\n\t"
-        "v_cndmask_b32_e32 %[nx], %[lo], %[hi], vcc"
-        : [bits] "+v"(bits), [add] "=&v"(add), [range] "+v"(e.range), [nx] "=v"(nx), [r1] "=&v"(r1), [r0] "=&v"(r0)
-        : [prev] "v"(prev), [lo] "v"(uint32_t(cur)), [hi] "v"(uint32_t(cur >> 32))  // byte 1 of prev = probability
+        "v_sub_u32_e32 %[range], %[range], %[r1]\n\t"
+        "s_and_saveexec_b64 %[save], vcc\n\t"
+        "v_add_u32_e32 %[low], %[low], %[range]\n\t"
+        "v_mov_b32_e32 %[range], %[r1]\n\t"
+        "v_mov_b32_e32 %[nx], %[hi]\n\t"
+        "s_mov_b64 exec, %[save]"
+        : [bits] "+v"(bits), [range] "+v"(e.range), [low] "+v"(e.low), [nx] "+v"(nx), [r1] "=&v"(r1), [save] "=&s"(saved_exec)
+        : [hi] "v"(uint32_t(cur >> 32))  // byte 2 of the entry's low half = probability of its own state
         : "vcc");
-    e.low += add;
     enc_renorm(e);
     return nx;
 }
@@ -269,11 +273,11 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, Bank& bank, const entr
                 enc_once<3, INLDS>(e, bank, E, ex > 2);
                 if (ex > 2) {  // unary tail on slot 4: (ex - 3) ones, then a zero
                     entry_t cur = E.e4;
-                    uint32_t nx = uint32_t(cur) >> 8;  // byte 1 = probability of the current state
+                    uint32_t nx;
                     // the bins left-aligned -- (ex - 3) ones, a zero -- followed by a sentinel 1 (as in the mantissa loop)
                     uint32_t bits = ((0xFFFFFFFCu << (ex - 3)) ^ 0xFFFFFFFDu) << (33 - ex);
                     do {
-                        nx = enc_step_msb(e, nx, bits, cur);
+                        nx = enc_step_msb(e, bits, cur);
                         cur = entry_at(tab, nx);
                     } while (bits != 0x80000000u);
                     put_state<4, INLDS>(bank, nx);
@@ -282,11 +286,11 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, Bank& bank, const entr
             enc_once_m<5, INLDS>(e, bank, E, uint32_t(__builtin_amdgcn_sbfe(int(a), uint32_t(ex - 1), 1u)));
             if (ex > 1) {  // mantissa tail on slot 6, MSB first
                 entry_t cur = E.e6;
-                uint32_t nx = uint32_t(cur) >> 8;
+                uint32_t nx;
                 // remaining mantissa bits left-aligned, followed by a sentinel 1: the loop needs no counter
                 uint32_t bits = ((a << 1) | 1u) << (32 - ex);
                 do {
-                    nx = enc_step_msb(e, nx, bits, cur);
+                    nx = enc_step_msb(e, bits, cur);
                     cur = entry_at(tab, nx);
                 } while (bits != 0x80000000u);
                 put_state<6, INLDS>(bank, nx);
