@@ -240,18 +240,31 @@ __device__ __forceinline__ void enc_once_m(RangeEnc& e, Bank& bank, const Entrie
     enc_core(e, prob_of(E.get<SLOT>()), m);
     put_state<SLOT, INLDS>(bank, successor_m(E.get<SLOT>(), m));
 }
-// ... or as a condition the caller branches on anyway: its compare leaves the bit in VCC, and all three selects are
-// issued before the renormalisation region so that they stay 2-cycle v_cndmask_e32
+// ... or as a condition.  With the states in LDS every lane first takes the bit-0 outcome (range -= r1, successor =
+// low half of the entry, stored straight away); the lanes whose bit is 1 then patch up inside one exec-masked region:
+// low += r0, range = r1, store the other successor.  Five vector instructions instead of seven selects and adds.
 template <int SLOT, bool INLDS>
 __device__ __forceinline__ void enc_once(RangeEnc& e, Bank& bank, const Entries& E, bool bit) {
     const entry_t en = E.get<SLOT>();
     const uint32_t r1 = __umul24(e.range, prob_of(en)) >> 8;
-    const uint32_t r0 = e.range - r1;
-    e.low += bit ? r0 : 0u;
-    e.range = bit ? r1 : r0;
-    const uint32_t ns = successor(en, bit);
-    enc_renorm(e);
-    put_state<SLOT, INLDS>(bank, ns);
+    if constexpr (INLDS) {
+        e.range -= r1;
+        put_state<SLOT, true>(bank, uint32_t(en));
+        if (bit) {
+            asm volatile("" : "+v"(e.low));  // (keeps hipcc from turning this region back into selects)
+            e.low += e.range;
+            e.range = r1;
+            put_state<SLOT, true>(bank, uint32_t(en >> 32));
+        }
+        enc_renorm(e);
+    } else {
+        const uint32_t r0 = e.range - r1;
+        e.low += bit ? r0 : 0u;
+        e.range = bit ? r1 : r0;
+        const uint32_t ns = successor(en, bit);
+        enc_renorm(e);
+        put_state<SLOT, false>(bank, ns);
+    }
 }
 
 // putSymbol<true,4,6,7> (llcomp.hpp:166-206).  All lanes walk the phases together, so the slot of every bin is a
