@@ -492,6 +492,14 @@ __device__ __forceinline__ unsigned long long window_next(unsigned long long w) 
     asm("v_lshrrev_b64 %0, 8, %1" : "=v"(r) : "v"(w));
     return r;
 }
+// Refill inside ONE exec-masked region with constant shift amounts (llcomp.hpp:115-120).
+__device__ __forceinline__ void dec_refill(RangeDec& d) {
+    if (d.range < 0x100) {
+        d.range <<= 8;
+        d.low = (d.low << 8) | (uint32_t(d.win) & 0xFF);  // low < range < 0x100 here
+        d.win = window_next(d.win);
+    }
+}
 template <bool CHECKED>
 __device__ __forceinline__ bool dec_core(RangeDec& d, uint32_t P) {  // llcomp.hpp:98-121, branch-free refill
     if (CHECKED && d.win <= 1) dec_append(d);  // no byte left
@@ -505,11 +513,7 @@ __device__ __forceinline__ bool dec_core(RangeDec& d, uint32_t P) {  // llcomp.h
     // Refill inside ONE exec-masked region with constant shift amounts.  (Measured on gfx950, tools/ubench: shifts by a
     // register, v_cndmask with an SGPR mask, v_perm, v_alignbit, v_cmp all take 4 cycles per wavefront, plain
     // add/sub/and/or/mov and shifts by a constant take 2; the branch-free form of this block cost eight 4-cycle ops.)
-    if (d.range < 0x100) {
-        d.range <<= 8;
-        d.low = (d.low << 8) | (uint32_t(d.win) & 0xFF);  // low < range < 0x100 here
-        d.win = window_next(d.win);
-    }
+    dec_refill(d);
     return bit;
 }
 // dec_core for a run of bins on one slot whose bits are gathered in `w` (inverted: see dec_residual): the borrow of the
@@ -539,9 +543,29 @@ __device__ __forceinline__ uint32_t dec_step_acc(RangeDec& d, uint32_t P, entry_
 }
 template <int SLOT, bool CHECKED, bool INLDS>
 __device__ __forceinline__ bool dec_once(RangeDec& d, Bank& bank, const Entries& E) {
-    const bool bit = dec_core<CHECKED>(d, prob_of(E.get<SLOT>()));
-    put_state<SLOT, INLDS>(bank, successor(E.get<SLOT>(), bit));
-    return bit;
+    const entry_t en = E.get<SLOT>();
+    if constexpr (INLDS) {
+        // every lane takes the bit-0 outcome (range = r0, low stays, successor = low half of the entry, stored straight
+        // away); the lanes that decode a 1 patch up inside one exec-masked region (see enc_once)
+        if (CHECKED && d.win <= 1) dec_append(d);
+        const uint32_t r1 = __umul24(d.range, prob_of(en)) >> 8;
+        d.range -= r1;
+        put_state<SLOT, true>(bank, uint32_t(en));
+        uint32_t diff;
+        const bool bit = !__builtin_usub_overflow(d.low, d.range, &diff);
+        if (bit) {
+            asm volatile("" : "+v"(diff));  // (keeps hipcc from turning this region back into selects)
+            d.low = diff;
+            d.range = r1;
+            put_state<SLOT, true>(bank, uint32_t(en >> 32));
+        }
+        dec_refill(d);
+        return bit;
+    } else {
+        const bool bit = dec_core<CHECKED>(d, prob_of(en));
+        put_state<SLOT, false>(bank, successor(en, bit));
+        return bit;
+    }
 }
 // getSymbol<true,4,6,7> (llcomp.hpp:219-247).  Returns false on "Invalid exponent".  Arithmetic modulo 2^32.
 template <bool ALL, bool CHECKED, bool INLDS>
