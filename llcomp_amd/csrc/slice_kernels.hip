@@ -585,21 +585,32 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entr
         if (dec_once<2, CHECKED, INLDS>(d, bank, E)) {
             ex = 2;
             if (dec_once<3, CHECKED, INLDS>(d, bank, E)) {
+                // Unary tail on slot 4.  The lanes that stay in the loop are exactly the lanes that decoded a 1, so the
+                // loop's own exec mask does the selecting: every lane takes the bit-0 outcome (range = r0, low stays,
+                // successor = low half of the entry), a lane that decodes a 0 leaves, the others patch up (low = diff,
+                // range = r1), refill and move on to the high half's successor.  The refill of the closing bin
+                // happens once, behind the loop.
                 entry_t cur = E.e4;
-                uint32_t nx = uint32_t(cur) >> 8;  // byte 1 = probability of the current state (entry_lo byte 2)
                 int n = 0;  // bins of the unary tail: n - 1 ones and the closing zero
-                bool b;
-                do {
-                    b = dec_core<CHECKED>(d, (nx >> 8) & 0xFF);
-                    nx = successor(cur, b);
-                    cur = entry_at(tab, nx);
+                for (;;) {
+                    if (CHECKED && d.win <= 1) dec_append(d);
+                    const uint32_t r1 = __umul24(d.range, prob_of(cur)) >> 8;
+                    d.range -= r1;
                     ++n;
+                    uint32_t diff;
+                    if (__builtin_usub_overflow(d.low, d.range, &diff)) break;
+                    d.low = diff;
+                    d.range = r1;
                     if (CHECKED && n > 29) break;  // exponent would exceed 31
-                } while (b);
+                    dec_refill(d);
+                    cur = entry_at(tab, uint32_t(cur >> 32));
+                }
+                dec_refill(d);
                 ex = 2 + n;
                 // fast path: no per-step limit -- the run ends by itself once the window holds only zeros; a run
                 // longer than 31 is "Invalid exponent" (llcomp.hpp:230-235) and is confirmed by the checked replay
                 if (ex > 31) ok = false;
+                const uint32_t nx = uint32_t(cur);
                 put_state<4, INLDS>(bank, nx);
             }
         }
