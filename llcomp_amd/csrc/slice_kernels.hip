@@ -284,16 +284,26 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, Bank& bank, const entr
             enc_once<2, INLDS>(e, bank, E, ex > 1);
             if (ex > 1) {
                 enc_once<3, INLDS>(e, bank, E, ex > 2);
-                if (ex > 2) {  // unary tail on slot 4: (ex - 3) ones, then a zero
+                if (ex > 2) {
+                    // Unary tail on slot 4: (ex - 3) ones, then a zero.  The lanes that stay in the loop are exactly
+                    // the lanes that code a 1, so the loop's own exec mask does the selecting (see the decoder): every
+                    // lane takes the bit-0 outcome (range -= r1), a lane whose run is over leaves, the others add r0
+                    // to low, take r1 as the range, renormalise and move on to the high half's successor.  The
+                    // iteration index is wave-uniform: "is this bin a one" is a single compare.
                     entry_t cur = E.e4;
-                    uint32_t nx;
-                    // the bins left-aligned -- (ex - 3) ones, a zero -- followed by a sentinel 1 (as in the mantissa loop)
-                    uint32_t bits = ((0xFFFFFFFCu << (ex - 3)) ^ 0xFFFFFFFDu) << (33 - ex);
-                    do {
-                        nx = enc_step_msb(e, bits, cur);
-                        cur = entry_at(tab, nx);
-                    } while (bits != 0x80000000u);
-                    put_state<4, INLDS>(bank, nx);
+                    const uint32_t ones = uint32_t(ex - 3);
+                    uint32_t r1 = __umul24(e.range, prob_of(cur)) >> 8;
+                    e.range -= r1;
+                    for (uint32_t i = 0; i < ones; ++i) {  // (rotated: one compare per bin)
+                        e.low += e.range;
+                        e.range = r1;
+                        enc_renorm(e);
+                        cur = entry_at(tab, uint32_t(cur >> 32));
+                        r1 = __umul24(e.range, prob_of(cur)) >> 8;
+                        e.range -= r1;
+                    }
+                    enc_renorm(e);
+                    put_state<4, INLDS>(bank, uint32_t(cur));
                 }
             }
             enc_once_m<5, INLDS>(e, bank, E, uint32_t(__builtin_amdgcn_sbfe(int(a), uint32_t(ex - 1), 1u)));
