@@ -214,25 +214,26 @@ __device__ __forceinline__ uint32_t successor_m(entry_t e, uint32_t m) {  // suc
 // the half of entry `cur` that belongs to the coded bit.  The shift is an add with carry-out, so the bit arrives in VCC
 // and the three selects are 2-cycle v_cndmask_e32 (a mask in a VGPR costs a 4-cycle v_bfi per select).
 __device__ __forceinline__ uint32_t enc_step_msb(RangeEnc& e, uint32_t& bits, entry_t cur) {
-    uint32_t nx = uint32_t(cur), r1;
+    uint32_t off, r1;  // off: table offset (state * 8) of the successor
     unsigned long long saved_exec;
     // Every lane takes the bit-0 outcome (range -= r1, successor = low half of the entry); the lanes whose bit is 1
-    // then patch it up under exec = VCC: low += r0, range = r1, successor = high half.  Seven vector instructions; the
+    // then patch it up under exec = VCC: low += r0, range = r1, successor = high half.  Eight vector instructions; the
     // two scalar ones ride along for free (the kernels are bound by VALU issue).
     asm("v_add_co_u32_e32 %[bits], vcc, %[bits], %[bits]\n\t"
-        "v_mul_u32_u24_sdwa %[r1], %[nx], %[range] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+        "v_mul_u32_u24_sdwa %[r1], %[lo], %[range] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n\t"
         "v_lshrrev_b32_e32 %[r1], 8, %[r1]\n\t"
         "v_sub_u32_e32 %[range], %[range], %[r1]\n\t"
+        "v_lshlrev_b32_sdwa %[off], %[three], %[lo] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
         "s_and_saveexec_b64 %[save], vcc\n\t"
         "v_add_u32_e32 %[low], %[low], %[range]\n\t"
         "v_mov_b32_e32 %[range], %[r1]\n\t"
-        "v_mov_b32_e32 %[nx], %[hi]\n\t"
+        "v_lshlrev_b32_sdwa %[off], %[three], %[hi] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
         "s_mov_b64 exec, %[save]"
-        : [bits] "+v"(bits), [range] "+v"(e.range), [low] "+v"(e.low), [nx] "+v"(nx), [r1] "=&v"(r1), [save] "=&s"(saved_exec)
-        : [hi] "v"(uint32_t(cur >> 32))  // byte 2 of the entry's low half = probability of its own state
+        : [bits] "+v"(bits), [range] "+v"(e.range), [low] "+v"(e.low), [off] "=&v"(off), [r1] "=&v"(r1), [save] "=&s"(saved_exec)
+        : [lo] "v"(uint32_t(cur)), [hi] "v"(uint32_t(cur >> 32)), [three] "v"(3u)  // byte 2 of lo = probability of this state
         : "vcc");
     enc_renorm(e);
-    return nx;
+    return off;
 }
 // a slot that is coded at most once per sample; the bit as a mask (all ones / zero) ...
 template <int SLOT, bool INLDS>
@@ -313,10 +314,10 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, Bank& bank, const entr
                 // remaining mantissa bits left-aligned, followed by a sentinel 1: the loop needs no counter
                 uint32_t bits = ((a << 1) | 1u) << (32 - ex);
                 do {
-                    nx = enc_step_msb(e, bits, cur);
-                    cur = entry_at(tab, nx);
+                    nx = enc_step_msb(e, bits, cur);  // successor's table offset
+                    cur = *reinterpret_cast<const entry_t*>(reinterpret_cast<const char*>(tab) + nx);
                 } while (bits != 0x80000000u);
-                put_state<6, INLDS>(bank, nx);
+                put_state<6, INLDS>(bank, nx >> 3);
             }
         }
         enc_once_m<7, INLDS>(e, bank, E, uint32_t(res >> 31));
