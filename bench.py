@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--interleaved", action="store_true", help="channels interleaved in one slice instead of per-channel planes")
     ap.add_argument("--streams", type=int, default=3, help="split the frames of a step over this many HIP streams (codec objects)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the extra one-pipeline-at-a-time launches behind the timed region (profiler runs)")
     args = ap.parse_args()
 
     import numpy as np
@@ -175,7 +176,7 @@ def main():
     # The same launches once more with every pipeline ALONE on the GPU (outside the timed region): per-launch durations
     # without the other streams' kernels beside them, reported next to the live ones (roofline.isolated).
     iso, iso_enc, iso_dec = {}, 0, 0
-    if S > 1:
+    if S > 1 and not args.no_isolated:
         for p in parts:
             c, st = p["codec"], p["stream"].cuda_stream
             px, out = d_px[p["lo"]:p["lo"] + p["n"]], d_out[p["lo"]:p["lo"] + p["n"]]
