@@ -437,19 +437,21 @@ __global__ __launch_bounds__(256) void k_from_lane_order(const Geometry g, const
 // ---- fused stage A for planar 1-row slices (tile_h == 1, planar) -------------------------------------------------------
 // The headline configuration.  One block = one lane group (64 consecutive slice ids = ~64/C tiles x C channel planes)
 // x 64 consecutive samples: the pixel runs of those tiles are staged raw in LDS (coalesced reads of 66*C bytes each),
-// every thread then models samples of its lane and the block writes 16-bit symbols straight in lane order,
-// so the image-order symbol array and the transpose pass disappear.  With h == 0 in llcomp.hpp:417-429 the context is
+// every thread then walks 8 consecutive PIXELS of one tile (one colour transform per pixel, all C symbols of it),
+// the symbols meet in an LDS tile [sample][lane] and leave as whole 128-byte rows of the lane-order array, so the
+// image-order symbol array and the transpose pass disappear.  With h == 0 in llcomp.hpp:417-429 the context is
 // 605*quant5(L - l) and the prediction is l.
 template <int C>
-__device__ __forceinline__ int rct_channel(const uint8_t* p, int ch) {  // one colour-transformed channel of a pixel
+__device__ __forceinline__ void rct_pixel(const uint8_t* p, int (&v)[C]) {  // llcomp.hpp:396-414, all channels of a pixel
     if constexpr (C >= 3) {
         const int g = p[1], cb = int(p[2]) - g, cr = int(p[0]) - g;
-        if (ch == 0) return cr;
-        if (ch == 2) return cb;
-        if (ch == 1) return g + (cb + cr) / 4;  // truncating division, llcomp.hpp:402
-        return p[3];
+        v[0] = cr;
+        v[1] = g + (cb + cr) / 4;  // truncating division, llcomp.hpp:402
+        v[2] = cb;
+        if constexpr (C == 4) v[3] = p[3];
     } else {
-        return p[ch];
+#pragma unroll
+        for (int k = 0; k < C; ++k) v[k] = p[k];
     }
 }
 struct RowTile {
@@ -475,12 +477,14 @@ __global__ __launch_bounds__(256) void k_model_rows_fwd(const Geometry g, const 
     constexpr int K = 64, RUN = (K + 2) * C, TPG = 64 / C + 2;
     constexpr int RUNW = (RUN + 3) / 4 + 1;  // dwords that cover a run at any byte alignment
     __shared__ uint32_t raw[TPG][RUNW + 1];
+    __shared__ __attribute__((aligned(4))) uint16_t otile[K][64 + 2];  // symbols [sample][group-relative lane]
     __shared__ RowTile tiles[TPG];
     const uint32_t chunks = (g.tile_w + K - 1) / K;
     const uint32_t group = blockIdx.x / chunks, k0 = (blockIdx.x - group * chunks) * K;
     const uint32_t gw = 1u << g.lane_shift;
     const uint32_t first_id = group << g.lane_shift;
     const uint32_t end_id = first_id + gw < g.n_slices ? first_id + gw : g.n_slices;
+    // every tile with at least one channel plane in this group (the planes outside it belong to the neighbours)
     const uint32_t first_tile = first_id / C, ntiles = (end_id - 1) / C - first_tile + 1;
     load_row_tiles<C>(g, first_tile, ntiles, tiles);
     __syncthreads();
@@ -494,31 +498,61 @@ __global__ __launch_bounds__(256) void k_model_rows_fwd(const Geometry g, const 
                          ? *reinterpret_cast<const uint32_t*>(px + al) : 0u;
     }
     __syncthreads();
-    const uint32_t j = threadIdx.x & 63, b = threadIdx.x >> 6;
-    const uint32_t id = first_id + j;
-    if (j >= gw || id >= end_id) return;
-    const uint32_t tt = id / C - first_tile, ch = id - (id / C) * C;
-    const uint32_t sw = tiles[tt].sw;
-    const uint32_t skew = uint32_t(((long long)tiles[tt].base + (long long)(int(k0) - 2) * C) & 3);
-    const uint8_t* run = reinterpret_cast<const uint8_t*>(&raw[tt][0]) + skew;  // byte 0 = pixel k0-2
-    // this thread: samples k0 + 16*b + i, i = 0..15, walking left to right so l and L come from registers
-    const uint32_t kb = k0 + 16 * b;
-    if (kb >= sw) return;
-    const uint8_t* p = run + (16 * b + 2) * C;
-    int l = kb > 0 ? rct_channel<C>(p - C, ch) : 128;            // llcomp.hpp:417
-    int L = kb > 1 ? rct_channel<C>(p - 2 * C, ch) : l;          // llcomp.hpp:419
-    uint16_t* out = lanes + lane_order_index(g, id, kb);
-    const uint32_t n = sw - kb < 16 ? sw - kb : 16;
-    for (uint32_t i = 0; i < n; ++i, p += C) {
-        const int cur = rct_channel<C>(p, ch);
-        const int Lq = (kb + i) > 1 ? L : l;
-        const int q = quant5(Lq - l);
-        int res = cur - l;
-        if (q < 0) res = -res;  // llcomp.hpp:433-436
-        // 16-bit symbol of the fused path: bits 12..13 = |quant5| (context 0 / 605 / 1210), bits 0..11 = residual
-        out[size_t(i) << g.lane_shift] = uint16_t(((q < 0 ? -q : q) << 12) | (res & 0xFFF));
-        L = l;
-        l = cur;
+    // this thread: pixels k0 + 8*q + i, i = 0..7, of tile tt, walking left to right so l and L come from registers
+    const uint32_t q = threadIdx.x & 7;
+    for (uint32_t tt = threadIdx.x >> 3; tt < ntiles; tt += 32) {  // one pass for 3 and 4 channels (<= 23 tiles)
+        const uint32_t sw = tiles[tt].sw;
+        const uint32_t kb = k0 + 8 * q;
+        if (kb < sw) {
+            const uint32_t skew = uint32_t(((long long)tiles[tt].base + (long long)(int(k0) - 2) * C) & 3);
+            const uint8_t* p = reinterpret_cast<const uint8_t*>(&raw[tt][0]) + skew + (8 * q + 2) * C;  // pixel kb
+            int l[C], L[C], cur[C];
+            if (kb > 0) rct_pixel<C>(p - C, l);  // llcomp.hpp:417
+            else {
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) l[ch] = 128;
+            }
+            if (kb > 1) rct_pixel<C>(p - 2 * C, L);  // llcomp.hpp:419
+            else {
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) L[ch] = l[ch];
+            }
+            // group-relative lane of this tile's channel 0 (negative / beyond gw: that plane is another group's)
+            const int col0 = int((first_tile + tt) * C) - int(first_id);
+            const uint32_t n = sw - kb < 8 ? sw - kb : 8;
+            for (uint32_t i = 0; i < n; ++i, p += C) {
+                rct_pixel<C>(p, cur);
+                const bool has_L = (kb + i) > 1;
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    const int dq = has_L ? L[ch] - l[ch] : 0;
+                    const uint32_t aq = uint32_t(dq < 0 ? -dq : dq);
+                    const uint32_t cidx = min(aq, 1u) + (aq > 3 ? 1u : 0u);  // |quant5(L - l)|: context 0 / 605 / 1210
+                    int res = cur[ch] - l[ch];
+                    if (dq < 0) res = -res;  // llcomp.hpp:433-436
+                    // 16-bit symbol of the fused path: bits 12..13 = |quant5|, bits 0..11 = residual
+                    const int col = col0 + ch;
+                    if (col >= 0 && col < int(gw)) otile[8 * q + i][col] = uint16_t((cidx << 12) | (uint32_t(res) & 0xFFF));
+                    L[ch] = l[ch];
+                    l[ch] = cur[ch];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // rows of the lane-order array: sample k0 + kk of the group's lanes = one contiguous 2*gw-byte piece
+    if (g.lane_shift == 6) {
+        for (uint32_t i = threadIdx.x; i < uint32_t(K) * 32; i += 256) {
+            const uint32_t kk = i >> 5, d = i & 31, k = k0 + kk;
+            if (k < g.tile_w)
+                *reinterpret_cast<uint32_t*>(lanes + lane_order_index(g, first_id + 2 * d, k)) =
+                    *reinterpret_cast<const uint32_t*>(&otile[kk][2 * d]);
+        }
+    } else {  // fewer than 64 slices in total: narrow group, plain element stores
+        for (uint32_t i = threadIdx.x; i < uint32_t(K) * gw; i += 256) {
+            const uint32_t kk = i / gw, col = i - kk * gw, k = k0 + kk;
+            if (k < g.tile_w && first_id + col < end_id) lanes[lane_order_index(g, first_id + col, k)] = otile[kk][col];
+        }
     }
 }
 

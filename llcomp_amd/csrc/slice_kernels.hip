@@ -71,7 +71,6 @@ __device__ __forceinline__ void put_state(Bank& b, uint32_t ns) {  // ns: new st
 __device__ __forceinline__ uint32_t prob_of(entry_t e) { return byte_of(uint32_t(e), 2); }
 // half of the entry that belongs to the coded bit: byte0 = successor state, byte1 = its probability
 __device__ __forceinline__ uint32_t successor(entry_t e, bool bit) { return bit ? uint32_t(e >> 32) : uint32_t(e); }
-__device__ __forceinline__ uint32_t next_state(entry_t e, bool bit) { return successor(e, bit) & 0xFF; }
 
 // The 8 entries of one context.  `all` = request slots 1..7 together with slot 0 (worth it when most residuals
 // are non-zero); otherwise they are requested after the zero flag turned out 0.
