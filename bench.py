@@ -215,14 +215,15 @@ def main():
         algo = (raw_bytes + stream_bytes) // S
         achieved = algo / (dom_ms * 1e-3) / 1e9
         traffic = None  # HBM-side bytes per launch from committed rocprofv3 PMC passes of THIS configuration
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_default_traffic.json")))
-            same = all(tj["config"].get(k) == v for k, v in (("frames_per_step_per_gpu", F), ("tile_w", args.tile_w), ("tile_h", args.tile_h),
-                                                            ("planar", planar), ("content", args.content), ("streams", S)))
-            if same and world == 1:
-                traffic = tj["per_launch"][dom]["hbm_bytes_corrected"]
-        except (OSError, KeyError, ValueError):
-            pass
+        for name in ("r01_default_traffic.json", "r01_single_stream_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                same = all(tj["config"].get(k) == v for k, v in (("frames_per_step_per_gpu", F), ("tile_w", args.tile_w), ("tile_h", args.tile_h),
+                                                                ("planar", planar), ("content", args.content), ("streams", S)))
+                if same and world == 1 and traffic is None:
+                    traffic = tj["per_launch"][dom]["hbm_bytes_corrected"]
+            except (OSError, KeyError, ValueError):
+                pass
         isolated = None
         if iso:
             iso_ms = iso[dom] / max(1, iso_enc if dom == "k_encode_slices" else iso_dec)
