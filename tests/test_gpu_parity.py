@@ -341,6 +341,39 @@ def test_state_table_in_lds_or_hbm_same_bytes(mi, orc, monkeypatch):
             assert np.array_equal(mi.decompress_image(t).pixels, img)
 
 
+def test_host_calls_are_reentrant(mi, orc):
+    """the host-buffer calls are re-entrant.  Four threads encode and decode different images at the
+    same time (ctypes drops the GIL inside the library; idle codec objects are shared through a locked cache)."""
+    import threading
+
+    jobs = []
+    for i in range(8):
+        rng = np.random.default_rng(100 + i)
+        w, h, c = int(rng.integers(40, 200)), int(rng.integers(8, 60)), int(rng.integers(1, 5))
+        img = rng.integers(0, 256, size=(h, w, c), dtype=np.uint8)
+        tw = int(rng.integers(16, w + 1))
+        jobs.append((img, w, h, c, tw, orc.compress_sliced(img, tw, 1, True), orc.compress_image(img)))
+    errors = []
+
+    def work(k):
+        try:
+            for rep in range(3):
+                for img, w, h, c, tw, want_sliced, want_legacy in jobs[k::4]:
+                    s = mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=1, planar=True)
+                    assert s == want_sliced
+                    assert np.array_equal(mi.decompress_image(s).pixels, img)
+                    assert mi.compress_image(img, w, h, c) == want_legacy
+        except Exception as e:  # noqa: BLE001 -- reported below, in the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_decoder_rollback_and_checked_replay(mi, orc, monkeypatch):
     """The decoder's fast path never checks its input window; a sample that outruns the window is rolled back and
     replayed with per-step refills.  That almost never happens on real data, so LLCOMP_MI_FORCE_REPLAY=1 sends EVERY
