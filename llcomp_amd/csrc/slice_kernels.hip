@@ -295,10 +295,12 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, Bank& bank, const entr
                     uint32_t r1 = __umul24(e.range, prob_of(cur)) >> 8;
                     e.range -= r1;
                     for (uint32_t i = 0; i < ones; ++i) {  // (rotated: one compare per bin)
+                        // the successor on a 1 is known before this bin is coded: its entry is requested first and has
+                        // the whole renormalisation to arrive (the state chain does not depend on low / range)
+                        cur = entry_at(tab, uint32_t(cur >> 32));
                         e.low += e.range;
                         e.range = r1;
                         enc_renorm(e);
-                        cur = entry_at(tab, uint32_t(cur >> 32));
                         r1 = __umul24(e.range, prob_of(cur)) >> 8;
                         e.range -= r1;
                     }
