@@ -321,7 +321,7 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, Bank& bank, const entr
                 put_state<6, INLDS>(bank, nx >> 3);
             }
         }
-        enc_once_m<7, INLDS>(e, bank, E, uint32_t(res >> 31));
+        enc_once<7, INLDS>(e, bank, E, res < 0);
     }
 }
 
