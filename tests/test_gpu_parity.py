@@ -300,6 +300,17 @@ def test_cli_roundtrip_matches_reference_behaviour(mi, orc, tmp_path):
     raw = zlib.decompress(idat)
     rows = np.frombuffer(raw, np.uint8).reshape(47, 1 + 61 * 3)
     assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:].reshape(47, 61, 3), img)
+    # the PNG llcompd wrote goes back in through llcompc's own PNG reader: same stream as from the PPM
+    (tmp_path / "b.png").write_bytes(png)
+    assert subprocess.run([exe_c, str(tmp_path / "b.png")]).returncode == 0
+    assert (tmp_path / "b.png.llcomp").read_bytes() == stream
+    # a PNG as an encoder would write it (dynamic Huffman blocks, Paeth rows), RGBA
+    rgba = make_image("mid", 40, 33, 4)
+    from test_cli_image_io import make_png
+
+    (tmp_path / "c.png").write_bytes(make_png(rgba, 6, filters=(4, 1, 3), level=9))
+    assert subprocess.run([exe_c, str(tmp_path / "c.png")]).returncode == 0
+    assert (tmp_path / "c.png.llcomp").read_bytes() == orc.compress_image(rgba)
     # sliced container through the CLI, damaged input -> exit code 1 with the reference's message
     assert subprocess.run([exe_c, str(ppm), "--sliced", "16x1"]).returncode == 0
     assert (tmp_path / "a.ppm.llcomp").read_bytes() == orc.compress_sliced(img, 16, 1, True)

@@ -1,12 +1,16 @@
 // image_io.hpp -- the image file I/O the reference delegates to stb (not vendored, not installed, no network):
-// a reader for binary PNM/PAM (P5 grey, P6 RGB, P7 with 1..4 channels, maxval 255) and a writer for PNG with
-// stored (uncompressed) deflate blocks.  Plays the role of stbi_load (llcompc.cpp:25) / stbi_write_png
-// (llcompd.cpp:29); it is host glue of the CLIs, not part of the coding path.
+// readers for binary PNM/PAM (P5 grey, P6 RGB, P7 with 1..4 channels, maxval 255) and for PNG (8 bits per channel,
+// grey / RGB / palette / alpha, non-interlaced; own inflate), and a writer for PNG with stored (uncompressed) deflate
+// blocks.  Plays the role of stbi_load (llcompc.cpp:25) / stbi_write_png (llcompd.cpp:29); it is host glue of the
+// CLIs, not part of the coding path.  Channel counts follow stb: grey 1, grey+alpha 2, RGB / palette 3, RGBA 4, and
+// a tRNS chunk adds the alpha channel.
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -56,13 +60,235 @@ inline std::string load_pnm(const std::string& path, std::vector<uint8_t>& px, i
         }
         // read_token consumed exactly one whitespace after ENDHDR
     } else {
-        return "unknown image type (binary PGM/PPM/PAM only: stb_image is not available)";
+        return "unknown image type (PNG or binary PGM/PPM/PAM: stb_image is not available)";
     }
     if (w <= 0 || h <= 0 || c < 1 || c > 4 || maxval != 255) return "unsupported PNM geometry (8-bit, 1..4 channels)";
     px.resize(size_t(w) * h * c);
     in.read(reinterpret_cast<char*>(px.data()), std::streamsize(px.size()));
     if (size_t(in.gcount()) != px.size()) return "truncated pixel data";
     return "";
+}
+
+// ---- inflate (RFC 1951) + zlib wrapper (RFC 1950), for the PNG reader ----------------------------------------------
+struct BitReader {
+    const uint8_t* p;
+    size_t n, pos = 0;
+    uint32_t acc = 0;
+    int have = 0;
+    bool fail = false;
+    uint32_t bits(int k) {  // k <= 16, LSB first
+        while (have < k) {
+            if (pos >= n) { fail = true; return 0; }
+            acc |= uint32_t(p[pos++]) << have;
+            have += 8;
+        }
+        const uint32_t v = acc & ((1u << k) - 1);
+        acc >>= k;
+        have -= k;
+        return v;
+    }
+    void align() { acc = 0; have = 0; }
+};
+struct Huffman {  // canonical code, decoded bit by bit (RFC 1951 3.2.2)
+    uint16_t count[16] = {0}, symbol[320] = {0};
+    bool build(const uint8_t* len, int n) {
+        for (int i = 0; i < 16; ++i) count[i] = 0;
+        for (int i = 0; i < n; ++i) count[len[i]]++;
+        int left = 1;
+        for (int l = 1; l < 16; ++l) {
+            left = (left << 1) - count[l];
+            if (left < 0) return false;  // over-subscribed
+        }
+        uint16_t offs[16];
+        offs[1] = 0;
+        for (int l = 1; l < 15; ++l) offs[l + 1] = uint16_t(offs[l] + count[l]);
+        for (int i = 0; i < n; ++i)
+            if (len[i]) symbol[offs[len[i]]++] = uint16_t(i);
+        return true;
+    }
+    int decode(BitReader& br) const {
+        int code = 0, first = 0, index = 0;
+        for (int l = 1; l < 16; ++l) {
+            code |= int(br.bits(1));
+            if (br.fail) return -1;
+            const int c = count[l];
+            if (code - c < first) return symbol[index + (code - first)];
+            index += c;
+            first += c;
+            first <<= 1;
+            code <<= 1;
+        }
+        return -1;
+    }
+};
+inline bool inflate_zlib(const std::vector<uint8_t>& z, std::vector<uint8_t>& out, size_t expect) {
+    if (z.size() < 6 || (z[0] & 0x0F) != 8 || ((unsigned(z[0]) << 8) | z[1]) % 31 != 0 || (z[1] & 0x20)) return false;
+    BitReader br{z.data() + 2, z.size() - 2};
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    out.clear();
+    out.reserve(expect);
+    for (bool last = false; !last;) {
+        last = br.bits(1) != 0;
+        const uint32_t type = br.bits(2);
+        if (br.fail) return false;
+        if (type == 0) {
+            br.align();
+            if (br.pos + 4 > br.n) return false;
+            const uint32_t len = br.p[br.pos] | (uint32_t(br.p[br.pos + 1]) << 8);
+            const uint32_t nlen = br.p[br.pos + 2] | (uint32_t(br.p[br.pos + 3]) << 8);
+            br.pos += 4;
+            if ((len ^ 0xFFFF) != nlen || br.pos + len > br.n) return false;
+            out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
+            br.pos += len;
+            continue;
+        }
+        if (type == 3) return false;
+        Huffman lit, dist;
+        uint8_t len[320];
+        if (type == 1) {
+            for (int i = 0; i < 288; ++i) len[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+            lit.build(len, 288);
+            for (int i = 0; i < 30; ++i) len[i] = 5;
+            dist.build(len, 30);
+        } else {
+            const int nlen = int(br.bits(5)) + 257, ndist = int(br.bits(5)) + 1, ncode = int(br.bits(4)) + 4;
+            if (br.fail || nlen > 286 || ndist > 30) return false;
+            static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            uint8_t cl[19] = {0};
+            for (int i = 0; i < ncode; ++i) cl[order[i]] = uint8_t(br.bits(3));
+            Huffman code;
+            if (br.fail || !code.build(cl, 19)) return false;
+            for (int i = 0; i < nlen + ndist;) {
+                const int sym = code.decode(br);
+                if (sym < 0) return false;
+                if (sym < 16) { len[i++] = uint8_t(sym); continue; }
+                int rep, val = 0;
+                if (sym == 16) {
+                    if (i == 0) return false;
+                    val = len[i - 1];
+                    rep = 3 + int(br.bits(2));
+                } else if (sym == 17) rep = 3 + int(br.bits(3));
+                else rep = 11 + int(br.bits(7));
+                if (br.fail || i + rep > nlen + ndist) return false;
+                while (rep--) len[i++] = uint8_t(val);
+            }
+            if (len[256] == 0 || !lit.build(len, nlen) || !dist.build(len + nlen, ndist)) return false;
+        }
+        for (;;) {
+            int sym = lit.decode(br);
+            if (sym < 0) return false;
+            if (sym < 256) { out.push_back(uint8_t(sym)); continue; }
+            if (sym == 256) break;
+            sym -= 257;
+            if (sym >= 29) return false;
+            const size_t n = lbase[sym] + br.bits(lext[sym]);
+            const int ds = dist.decode(br);
+            if (ds < 0 || ds >= 30) return false;
+            const size_t d = dbase[ds] + br.bits(dext[ds]);
+            if (br.fail || d > out.size()) return false;
+            for (size_t k = 0; k < n; ++k) out.push_back(out[out.size() - d]);
+        }
+        if (out.size() > expect + 64) return false;  // more than the picture can hold: damaged
+    }
+    return true;
+}
+
+// PNG, 8 bits per channel, non-interlaced.  Returns an empty string on success, else the failure reason.
+inline std::string load_png(const std::string& path, std::vector<uint8_t>& px, int& w, int& h, int& c) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return "can't fopen";
+    std::vector<uint8_t> f((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (f.size() < 8 || std::memcmp(f.data(), sig, 8) != 0) return "bad png sig";
+    auto be32 = [&](size_t o) { return (uint32_t(f[o]) << 24) | (uint32_t(f[o + 1]) << 16) | (uint32_t(f[o + 2]) << 8) | f[o + 3]; };
+    std::vector<uint8_t> idat, plte, trns;
+    int depth = 0, ctype = -1, interlace = 0;
+    w = h = 0;
+    for (size_t o = 8; o + 12 <= f.size();) {
+        const uint32_t n = be32(o);
+        if (o + 12 + size_t(n) > f.size()) return "corrupt PNG chunk";
+        const std::string type(reinterpret_cast<const char*>(&f[o + 4]), 4);
+        const uint8_t* body = &f[o + 8];
+        if (type == "IHDR" && n == 13) {
+            w = int(be32(o + 8)); h = int(be32(o + 12));
+            depth = body[8]; ctype = body[9]; interlace = body[12];
+        } else if (type == "PLTE") plte.assign(body, body + n);
+        else if (type == "tRNS") trns.assign(body, body + n);
+        else if (type == "IDAT") idat.insert(idat.end(), body, body + n);
+        else if (type == "IEND") break;
+        o += 12 + size_t(n);
+    }
+    if (w <= 0 || h <= 0 || ctype < 0) return "no IHDR";
+    if (depth != 8) return "unsupported PNG bit depth (8 bits per channel only)";
+    if (interlace) return "interlaced PNG is not supported";
+    int fc;  // channels in the file
+    switch (ctype) {
+        case 0: fc = 1; break;
+        case 2: fc = 3; break;
+        case 3: fc = 1; break;
+        case 4: fc = 2; break;
+        case 6: fc = 4; break;
+        default: return "bad PNG colour type";
+    }
+    if (ctype == 3 && plte.size() < 3) return "missing PLTE";
+    const size_t row = size_t(w) * fc;
+    if (uint64_t(w) * uint64_t(h) * 4 >= (1ull << 31)) return "too large";
+    std::vector<uint8_t> raw;
+    if (!inflate_zlib(idat, raw, (row + 1) * size_t(h)) || raw.size() < (row + 1) * size_t(h)) return "bad zlib stream";
+    std::vector<uint8_t> img(row * size_t(h));
+    for (int y = 0; y < h; ++y) {  // undo the row filters (PNG spec 9.2)
+        const uint8_t* src = &raw[(row + 1) * size_t(y)];
+        uint8_t* cur = &img[row * size_t(y)];
+        const uint8_t* up = y ? cur - row : nullptr;
+        const int ft = src[0];
+        if (ft > 4) return "bad PNG filter";
+        for (size_t i = 0; i < row; ++i) {
+            const int a = i >= size_t(fc) ? cur[i - fc] : 0, b = up ? up[i] : 0, cc = (up && i >= size_t(fc)) ? up[i - fc] : 0;
+            int pred = 0;
+            if (ft == 1) pred = a;
+            else if (ft == 2) pred = b;
+            else if (ft == 3) pred = (a + b) >> 1;
+            else if (ft == 4) {
+                const int pp = a + b - cc, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - cc);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : cc);
+            }
+            cur[i] = uint8_t(src[1 + i] + pred);
+        }
+    }
+    // to the channel layout stb would hand over
+    const bool pal = ctype == 3;
+    const bool key = !pal && !trns.empty() && (ctype == 0 || ctype == 2);
+    c = pal ? (trns.empty() ? 3 : 4) : fc + (key ? 1 : 0);
+    px.resize(size_t(w) * h * c);
+    const size_t npx = size_t(w) * h;
+    for (size_t i = 0; i < npx; ++i) {
+        uint8_t* o = &px[i * c];
+        if (pal) {
+            const size_t idx = img[i];
+            for (int k = 0; k < 3; ++k) o[k] = idx * 3 + k < plte.size() ? plte[idx * 3 + k] : 0;
+            if (c == 4) o[3] = idx < trns.size() ? trns[idx] : 255;
+        } else {
+            for (int k = 0; k < fc; ++k) o[k] = img[i * fc + k];
+            if (key) {  // colour key: 16-bit samples in tRNS, the low byte counts at depth 8
+                bool same = trns.size() >= size_t(2 * fc);
+                for (int k = 0; same && k < fc; ++k) same = trns[2 * k + 1] == o[k];
+                o[fc] = same ? 0 : 255;
+            }
+        }
+    }
+    return "";
+}
+
+// stbi_load's role: PNG or binary PNM/PAM by signature.
+inline std::string load_image(const std::string& path, std::vector<uint8_t>& px, int& w, int& h, int& c) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return "can't fopen";
+    const int first = in.get();
+    in.close();
+    return first == 0x89 ? load_png(path, px, w, h, c) : load_pnm(path, px, w, h, c);
 }
 
 inline uint32_t crc32(const uint8_t* p, size_t n, uint32_t crc = 0) {

@@ -3,7 +3,7 @@
 // Compressor front end on libllcomp_mi.so with the observable behaviour of the reference tool
 // (/root/reference/llcompc.cpp:14-43): exactly one required positional argument, output written next to the input as
 // "<image>.llcomp", exit status 1 for usage, unreadable image or unwritable output, 0 otherwise.  stb_image is neither
-// vendored nor installed, so the image reader is tools/image_io.hpp (binary PGM / PPM / PAM).  Without options the
+// vendored nor installed, so the image reader is tools/image_io.hpp (PNG, binary PGM / PPM / PAM).  Without options the
 // stream is the reference's own format; --sliced selects the parallel container.
 #include <cstdio>
 #include <exception>
@@ -35,7 +35,7 @@ bool parse_flags(int argc, char** argv, llcomp::Options& opt) {
 int compress_file(const std::string& image_path, const llcomp::Options& opt) {
     std::vector<uint8_t> pixels;
     int w = 0, h = 0, c = 0;
-    if (const std::string reason = image_io::load_pnm(image_path, pixels, w, h, c); !reason.empty()) {
+    if (const std::string reason = image_io::load_image(image_path, pixels, w, h, c); !reason.empty()) {
         std::fprintf(stderr, "Error loading image: %s\n", reason.c_str());
         return cli::kFailed;
     }
