@@ -30,6 +30,15 @@ struct llcomp_mi_codec {
     uint64_t* d_total_tmp = nullptr;
     uint64_t* d_block_sums = nullptr;  // scan scratch
     uint64_t workspace_bytes = 0;
+    // staging for the host-buffer calls (llcomp_mi_encode / llcomp_mi_decode), kept with the cached object so that a call
+    // does not pay for five hipMalloc / hipFree pairs
+    uint8_t* io_px = nullptr;
+    uint8_t* io_payload = nullptr;
+    uint32_t* io_len = nullptr;
+    uint64_t* io_total = nullptr;
+    uint32_t* io_status = nullptr;
+    uint64_t io_payload_cap = 0;
+    uint64_t io_bytes = 0;  // all of the above, for the idle-cache budget
     bool need_states = true;  // false when the states live in LDS (1-row slices; one slice per wavefront)
     // optional per-kernel timing (hipEvents on the caller's stream)
     bool profiling = false;
@@ -170,6 +179,11 @@ void llcomp_mi_codec_destroy(llcomp_mi_codec* k) {
     (void)hipFree(k->d_offsets);
     (void)hipFree(k->d_total_tmp);
     (void)hipFree(k->d_block_sums);
+    (void)hipFree(k->io_px);
+    (void)hipFree(k->io_payload);
+    (void)hipFree(k->io_len);
+    (void)hipFree(k->io_total);
+    (void)hipFree(k->io_status);
     for (auto& sp : k->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     delete k;
 }
@@ -327,7 +341,7 @@ struct CodecCache {
         {
             std::lock_guard<std::mutex> lock(mu);
             idle.push_back({k, ++clock});
-            auto bytes = [&]() { uint64_t b = 0; for (auto& it : idle) b += it.k->workspace_bytes; return b; };
+            auto bytes = [&]() { uint64_t b = 0; for (auto& it : idle) b += it.k->workspace_bytes + it.k->io_bytes; return b; };
             while (idle.size() > kMaxIdle || (idle.size() > 1 && bytes() > kMaxIdleBytes)) {
                 size_t oldest = 0;
                 for (size_t i = 1; i < idle.size(); ++i) if (idle[i].stamp < idle[oldest].stamp) oldest = i;
@@ -356,6 +370,25 @@ int acquire_codec(llcomp_mi_codec** out, int32_t device, uint32_t w, uint32_t h,
 extern "C" {
 
 // ---- host-buffer API --------------------------------------------------------------------------------------------
+// staging buffers of the host-buffer calls: allocated on first use, the payload buffer grown on demand
+static bool ensure_io(llcomp_mi_codec* k, uint64_t payload_cap) {
+    const Geometry& g = k->g;
+    const uint64_t raw = uint64_t(g.w) * g.h * g.c * g.frames;
+    if (!k->io_px && hipMalloc(reinterpret_cast<void**>(&k->io_px), raw) != hipSuccess) return false;
+    if (!k->io_len && hipMalloc(reinterpret_cast<void**>(&k->io_len), uint64_t(g.n_slices) * 4) != hipSuccess) return false;
+    if (!k->io_total && hipMalloc(reinterpret_cast<void**>(&k->io_total), 8) != hipSuccess) return false;
+    if (!k->io_status && hipMalloc(reinterpret_cast<void**>(&k->io_status), 4) != hipSuccess) return false;
+    if (k->io_payload_cap < payload_cap) {
+        (void)hipFree(k->io_payload);
+        k->io_payload = nullptr;
+        k->io_payload_cap = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&k->io_payload), payload_cap) != hipSuccess) return false;
+        k->io_payload_cap = payload_cap;
+    }
+    k->io_bytes = raw + uint64_t(g.n_slices) * 4 + 12 + k->io_payload_cap;
+    return true;
+}
+
 int llcomp_mi_encode(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, const llcomp_mi_opts* opts, uint8_t** out,
                      size_t* out_len) {
     if (!px || !out || !out_len) return LLCOMP_MI_BAD_ARGS;
@@ -384,30 +417,20 @@ int llcomp_mi_encode(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, cons
     const Geometry& g = k->g;
     const uint64_t raw = uint64_t(w) * h * c;
     const uint64_t max_payload = llcomp_mi_codec_max_payload_bytes(k);
-    uint8_t* d_px = nullptr;
-    uint8_t* d_payload = nullptr;
-    uint32_t* d_len = nullptr;
-    uint64_t* d_total = nullptr;
-    uint32_t* d_status = nullptr;
     uint8_t* host = nullptr;
     int rc = LLCOMP_MI_OK;
-    auto cleanup = [&]() {
-        (void)hipFree(d_px); (void)hipFree(d_payload); (void)hipFree(d_len); (void)hipFree(d_total); (void)hipFree(d_status);
-        codec_cache().give(k);
-    };
-    auto fail = [&](int code) { cleanup(); std::free(host); return code; };
-    if (hipMalloc(reinterpret_cast<void**>(&d_px), raw) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_len), uint64_t(g.n_slices) * 4) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_total), 8) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_status), 4) != hipSuccess)
-        return fail(LLCOMP_MI_NOMEM);
-    if (hipMemcpy(d_px, px, raw, hipMemcpyHostToDevice) != hipSuccess) return fail(LLCOMP_MI_HIP_ERROR);
+    auto fail = [&](int code) { codec_cache().give(k); std::free(host); return code; };
     // first try with room for 2x raw (incompressible noise needs ~1.25x), then the proven worst case
     uint64_t cap = std::min<uint64_t>(max_payload, 2 * raw + 64ull * g.n_slices + 4096);
+    if (!ensure_io(k, cap)) return fail(LLCOMP_MI_NOMEM);
+    uint8_t* const d_px = k->io_px;
+    uint32_t* const d_len = k->io_len;
+    uint64_t* const d_total = k->io_total;
+    uint32_t* const d_status = k->io_status;
+    if (hipMemcpy(d_px, px, raw, hipMemcpyHostToDevice) != hipSuccess) return fail(LLCOMP_MI_HIP_ERROR);
     uint64_t total = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (hipMalloc(reinterpret_cast<void**>(&d_payload), cap) != hipSuccess) return fail(LLCOMP_MI_NOMEM);
-        rc = llcomp_mi_codec_encode(k, d_px, d_payload, cap, d_len, d_total, d_status, nullptr);
+        rc = llcomp_mi_codec_encode(k, d_px, k->io_payload, cap, d_len, d_total, d_status, nullptr);
         if (rc) return fail(rc);
         uint32_t bits = 0;
         if (hipStreamSynchronize(nullptr) != hipSuccess) return fail(LLCOMP_MI_HIP_ERROR);
@@ -416,13 +439,13 @@ int llcomp_mi_encode(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, cons
             return fail(LLCOMP_MI_HIP_ERROR);
         rc = status_from_bits(bits);
         if (rc == LLCOMP_MI_OUTPUT_OVERFLOW && cap < max_payload) {
-            (void)hipFree(d_payload);
-            d_payload = nullptr;
             cap = max_payload;
+            if (!ensure_io(k, cap)) return fail(LLCOMP_MI_NOMEM);
             continue;
         }
         break;
     }
+    uint8_t* const d_payload = k->io_payload;
     if (rc) return fail(rc);
     const size_t head = legacy ? 6 : size_t(LLCOMP_MI_SLICED_HEADER_BYTES) + 4 * size_t(g.n_slices);
     host = static_cast<uint8_t*>(std::malloc(head + total + 1));
@@ -435,7 +458,7 @@ int llcomp_mi_encode(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, cons
             return fail(LLCOMP_MI_HIP_ERROR);  // slice table is little-endian u32 on both sides
     }
     if (total && hipMemcpy(host + head, d_payload, total, hipMemcpyDeviceToHost) != hipSuccess) return fail(LLCOMP_MI_HIP_ERROR);
-    cleanup();
+    codec_cache().give(k);
     *out = host;
     *out_len = head + total;
     return LLCOMP_MI_OK;
@@ -453,21 +476,13 @@ int llcomp_mi_decode(const uint8_t* data, size_t len, int32_t device, uint8_t** 
     const Geometry& g = k->g;
     const uint64_t raw = uint64_t(info.width) * info.height * info.channels;
     const uint64_t payload_bytes = len - info.payload_offset;
-    uint8_t* d_px = nullptr;
-    uint8_t* d_payload = nullptr;
-    uint32_t* d_len = nullptr;
-    uint32_t* d_status = nullptr;
     uint8_t* host = nullptr;
-    auto cleanup = [&]() {
-        (void)hipFree(d_px); (void)hipFree(d_payload); (void)hipFree(d_len); (void)hipFree(d_status);
-        codec_cache().give(k);
-    };
-    auto fail = [&](int code) { cleanup(); std::free(host); return code; };
-    if (hipMalloc(reinterpret_cast<void**>(&d_px), raw) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_payload), payload_bytes + 16) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_len), uint64_t(g.n_slices) * 4) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_status), 4) != hipSuccess)
-        return fail(LLCOMP_MI_NOMEM);
+    auto fail = [&](int code) { codec_cache().give(k); std::free(host); return code; };
+    if (!ensure_io(k, payload_bytes + 16)) return fail(LLCOMP_MI_NOMEM);
+    uint8_t* const d_px = k->io_px;
+    uint8_t* const d_payload = k->io_payload;
+    uint32_t* const d_len = k->io_len;
+    uint32_t* const d_status = k->io_status;
     if (payload_bytes && hipMemcpy(d_payload, data + info.payload_offset, payload_bytes, hipMemcpyHostToDevice) != hipSuccess)
         return fail(LLCOMP_MI_HIP_ERROR);
     if (info.format == LLCOMP_MI_FORMAT_LEGACY) {
@@ -485,7 +500,7 @@ int llcomp_mi_decode(const uint8_t* data, size_t len, int32_t device, uint8_t** 
     host = static_cast<uint8_t*>(std::malloc(raw ? raw : 1));
     if (!host) return fail(LLCOMP_MI_NOMEM);
     if (hipMemcpy(host, d_px, raw, hipMemcpyDeviceToHost) != hipSuccess) return fail(LLCOMP_MI_HIP_ERROR);
-    cleanup();
+    codec_cache().give(k);
     *px = host;
     *w = info.width;
     *h = info.height;
