@@ -9,9 +9,9 @@
 //     encoder renormalises in 7 instructions with eager carry propagation, its output bytes go to a per-lane LDS ring
 //     that is flushed 16 bytes at a time;
 //   * the model table lives in LDS as 8-byte entries {P, next0, next1, P(next0), P(next1)}: the 8 entries of a
-//     context are requested together when the context is known, and inside a run of bins on one slot (unary
-//     exponent tail, mantissa tail) the next probability is already in registers while the successor's entry is
-//     still on its way, so LDS latency stays off the range-coder recurrence;
+//     context are requested together when the context is known; the decoder's mantissa tail takes the probability
+//     of the next bin from the half-entry it just selected while the successor's entry is still on its way, and the
+//     encoder (whose bins are known in advance) requests a successor before it codes the bin that leads there;
 //   * 1-row slices (tile_h == 1) can only ever reach 3 contexts (llcomp.hpp:417-429 with h == 0: hash =
 //     605*quant5(L-l)), so their 24 state bytes stay in LDS and the kernel touches no state memory in HBM at all;
 //     taller slices keep a private 63 KB table (u64 per context) in HBM, fetched one context per sample -- or in
@@ -331,7 +331,7 @@ __device__ __forceinline__ void enc_finish(RangeEnc& e) {  // llcomp.hpp:75-81
     while (e.pos - e.flushed > 0) enc_flush16(e);  // tail: whole 16-byte groups, the slack is scratch
 }
 
-// Lane-per-slice encoder.  ROWS: every slice is one row high (register-resident states).  `lpw` = slices per
+// Lane-per-slice encoder.  ROWS: every slice is one row high (its three contexts' states live in LDS).  `lpw` = slices per
 // wavefront (1..64).
 // LDSTAB: one slice per wavefront (a lone whole-image stream, a handful of big tiles) -- its 63 KB state table fits in
 // LDS, which takes the HBM round trip of every context fetch off the serial chain.
@@ -861,7 +861,7 @@ hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* 
                                 uint32_t* d_slice_len, uint32_t* d_status, hipStream_t stream) {
     const uint32_t lpw = lanes_per_wave(g);
     const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
-    if (model_is_fused(g)) {  // planar 1-row slices: 16-bit symbols, always the register-resident kernel
+    if (model_is_fused(g)) {  // planar 1-row slices: 16-bit symbols, always the ROWS kernel
         k_encode_slices<1, true, uint16_t><<<dim3(blocks), dim3(64), 0, stream>>>(
             g, lpw, static_cast<const uint16_t*>(d_sym), d_states, d_scratch, d_slice_len, d_status);
         return hipGetLastError();
