@@ -36,6 +36,8 @@ def make_frames(content, frames, rank):
             out[i] = synth.gen_g3(W4K, H4K, C4K, seed=seed)
         elif content == "g2":
             out[i] = np.roll(synth.gen_g2(W4K, H4K, C4K), (seed - 1234) * 5, axis=1)
+        elif content == "nat":
+            out[i] = synth.gen_nat(W4K, H4K, C4K, seed=seed)
         else:
             out[i] = synth.gen_mid(W4K, H4K, C4K, seed=seed)
     return out
@@ -79,7 +81,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=32, help="4K frames per step per GPU")
-    ap.add_argument("--content", default="g3", choices=["g3", "g2", "mid"])
+    ap.add_argument("--content", default="g3", choices=["g3", "g2", "mid", "nat"])
     ap.add_argument("--tile-w", type=int, default=480)
     ap.add_argument("--tile-h", type=int, default=1)
     ap.add_argument("--interleaved", action="store_true", help="channels interleaved in one slice instead of per-channel planes")

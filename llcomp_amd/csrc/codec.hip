@@ -24,7 +24,7 @@ struct llcomp_mi_codec {
     // workspace (all on `device`)
     void* d_sym_or_rec = nullptr;   // image order: encode u32 symbols per sample / decode int16 reconstructed samples
     void* d_lane_order = nullptr;   // the same data in lane order [group][k][64] for the serial kernels
-    uint64_t* d_states = nullptr;   // u64[n_slices][kContexts]
+    uint64_t* d_states = nullptr;   // u64[lane group][kContexts][lanes of the group]
     uint8_t* d_scratch = nullptr;   // slice streams in stream lane order: 16-byte units [group][unit][lane]
     uint64_t* d_offsets = nullptr;  // u64[n_slices + 1]
     uint64_t* d_total_tmp = nullptr;
@@ -151,7 +151,7 @@ int llcomp_mi_codec_create(llcomp_mi_codec** out, int32_t device, uint32_t frame
     k->device = dev;
     const uint64_t samples = uint64_t(frames) * w * h * c;
     k->need_states = slices_need_state_tables(g);
-    const uint64_t b_sym = samples * 4, b_states = k->need_states ? uint64_t(g.n_slices) * kContexts * 8 : 8,
+    const uint64_t b_sym = samples * 4, b_states = k->need_states ? (uint64_t(lane_groups(g)) * kContexts << g.lane_shift) * 8 : 8,
                    b_scratch = (uint64_t(lane_groups(g)) << g.lane_shift) * g.slice_cap, b_off = (uint64_t(g.n_slices) + 1) * 8;
     const uint64_t b_lanes = (uint64_t(lane_groups(g)) * slice_capacity_samples(g) << g.lane_shift) * 4;
     k->workspace_bytes = b_sym + b_lanes + b_states + b_scratch + b_off + 8;
@@ -214,7 +214,7 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
     HIP_TRY(hipMemsetAsync(d_status, 0, 4, s));
     {
         Timed t(k, s, 0);
-        if (k->need_states) HIP_TRY(hipMemsetAsync(k->d_states, 0, uint64_t(g.n_slices) * kContexts * 8, s));
+        if (k->need_states) HIP_TRY(hipMemsetAsync(k->d_states, 0, (uint64_t(lane_groups(g)) * kContexts << g.lane_shift) * 8, s));
     }
     {
         Timed t(k, s, 1);
@@ -253,7 +253,7 @@ int llcomp_mi_codec_decode(llcomp_mi_codec* k, const void* d_payload, uint64_t p
     HIP_TRY(hipMemsetAsync(d_status, 0, 4, s));
     {
         Timed t(k, s, 7);
-        if (k->need_states) HIP_TRY(hipMemsetAsync(k->d_states, 0, uint64_t(g.n_slices) * kContexts * 8, s));
+        if (k->need_states) HIP_TRY(hipMemsetAsync(k->d_states, 0, (uint64_t(lane_groups(g)) * kContexts << g.lane_shift) * 8, s));
     }
     {
         Timed t(k, s, 4);

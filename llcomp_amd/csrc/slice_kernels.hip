@@ -406,24 +406,32 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     } else {
         // Everything the coder needs is known up front: the symbol two samples ahead and the state bank one sample
         // ahead are in flight while a sample is coded (forwarded when consecutive samples share a context).
+        // state tables of a lane group in HBM: [context][lane], so that lanes which are in the same context at the same
+        // time (smooth content: most of them) share cache lines; LDSTAB: this slice's own table in LDS
         uint64_t* banks;
-        if constexpr (LDSTAB) banks = reinterpret_cast<uint64_t*>(dyn_lds);
-        else banks = states + size_t(id) * kContexts;
+        uint32_t bsh;  // log2 of the distance between consecutive contexts, in entries
+        if constexpr (LDSTAB) {
+            banks = reinterpret_cast<uint64_t*>(dyn_lds);
+            bsh = 0;
+        } else {
+            banks = states + ((size_t(id >> g.lane_shift) * kContexts) << g.lane_shift) + (id & ((1u << g.lane_shift) - 1));
+            bsh = g.lane_shift;
+        }
         uint32_t fk = 0;
         auto fetch = [&]() -> uint32_t { return p0[size_t(fk++) * GW]; };
         uint32_t s0 = fetch();
         uint32_t s1 = total > 1 ? fetch() : 0;
-        uint64_t b0 = banks[s0 & 0xFFFF];
+        uint64_t b0 = banks[size_t(s0 & 0xFFFF) << bsh];
         for (uint32_t i = 0; i < total; ++i) {
             const uint32_t s2 = i + 2 < total ? fetch() : 0;
             const uint32_t ctx0 = s0 & 0xFFFF, ctx1 = s1 & 0xFFFF;
             const int res = int(s0) >> 16;
-            uint64_t b1 = (i + 1 < total) ? banks[ctx1] : 0;
+            uint64_t b1 = (i + 1 < total) ? banks[size_t(ctx1) << bsh] : 0;
             Bank bank{{uint32_t(b0), uint32_t(b0 >> 32)}, nullptr};
             if (hot) enc_residual<true, false>(e, bank, tab, res); else enc_residual<false, false>(e, bank, tab, res);
             hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(res != 0)) >= __popcll(__ballot(true)));
             b0 = uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32);
-            banks[ctx0] = b0;
+            banks[size_t(ctx0) << bsh] = b0;
             if (ctx1 == ctx0) b1 = b0;  // the prefetched copy is stale: forward
             b0 = b1;
             if (e.pos - e.flushed >= 16) enc_flush16(e);
@@ -747,9 +755,15 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
     } else {
         // Neighbours of the row above rotate through registers (tl <- t <- tr); the two values the NEXT pixel needs
         // from memory (top-right, top-top) are loaded while the current one decodes.
-        uint64_t* banks;
-        if constexpr (LDSTAB) banks = reinterpret_cast<uint64_t*>(dyn_lds);
-        else banks = states + size_t(id) * kContexts;
+        uint64_t* banks;  // [context][lane] per lane group, see the encoder
+        uint32_t bsh;
+        if constexpr (LDSTAB) {
+            banks = reinterpret_cast<uint64_t*>(dyn_lds);
+            bsh = 0;
+        } else {
+            banks = states + ((size_t(id >> g.lane_shift) * kContexts) << g.lane_shift) + (id & ((1u << g.lane_shift) - 1));
+            bsh = g.lane_shift;
+        }
         const ptrdiff_t up = ptrdiff_t(r.sw) * NCH * GW;  // one slice row back, in lane-order elements
         for (uint32_t y = 0; y < r.sh; ++y) {
             int16_t* row = p0 + ptrdiff_t(y) * up;
@@ -776,7 +790,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                     int ctx = context_hash(n);
                     const bool neg = ctx < 0;  // llcomp.hpp:511-515
                     if (neg) ctx = -ctx;
-                    const uint64_t b64 = banks[ctx];
+                    const uint64_t b64 = banks[size_t(ctx) << bsh];
                     Bank bank{{uint32_t(b64), uint32_t(b64 >> 32)}, nullptr};
                     uint32_t v;
                     const bool ok = dec_sample<false>(d, bank, tab, hot, replay_always, v);
@@ -785,7 +799,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                         return;  // this lane's slice is unusable; the whole call reports the error
                     }
                     hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true)));
-                    banks[ctx] = uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32);
+                    banks[size_t(ctx) << bsh] = uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32);
                     if (neg) v = 0u - v;
                     const int val = int(int16_t(uint32_t(predict(n)) + v));
                     q[k * GW] = int16_t(val);

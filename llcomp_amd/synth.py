@@ -6,6 +6,7 @@ and the tools all draw their images from.  Pure numpy; no codec code and nothing
   g3       std::mt19937(seed), one draw per sample   -- noise, the incompressible extreme
   mid      g2 + a small integer dither in [-8, 7]
   checker  saturated 0 / 255 checkerboard
+  nat      photo-like: smooth low-frequency shading, blocky objects with hard edges, +-1 sensor-like noise
 """
 import numpy as np
 
@@ -54,4 +55,19 @@ def gen_checker(w, h, c):
     return (((x + y + k) & 1) * 255).astype(np.uint8)
 
 
-GENERATORS = {"g1": gen_g1, "g2": gen_g2, "g3": gen_g3, "mid": gen_mid, "checker": gen_checker}
+def gen_nat(w, h, c, seed=11):
+    """photo-like integer pattern: slow quadratic shading + 64-pixel blocks with hard edges + noise in [-1, 1]."""
+    x = np.arange(w, dtype=np.int32)[None, :, None]
+    y = np.arange(h, dtype=np.int32)[:, None, None]
+    k = np.arange(c, dtype=np.int32)[None, None, :]
+    shade = ((x * x) >> 12) + ((y * 3) >> 2) + 29 * k
+    blocks = 45 * (((x >> 6) * 7 + (y >> 6) * 13 + k) % 3)
+    z = (np.arange(w * h * c, dtype=np.uint32) + np.uint32(seed)) * np.uint32(0x9E3779B1)  # Knuth's multiplicative hash
+    z ^= z >> np.uint32(15)
+    z *= np.uint32(0x85EBCA6B)
+    noise = (z >> np.uint32(30)).astype(np.int32).reshape(h, w, c) - 1  # -1, 0, 1, 2
+    noise[noise == 2] = 0
+    return ((shade + blocks + noise) & 0xFF).astype(np.uint8)
+
+
+GENERATORS = {"g1": gen_g1, "g2": gen_g2, "g3": gen_g3, "mid": gen_mid, "checker": gen_checker, "nat": gen_nat}
