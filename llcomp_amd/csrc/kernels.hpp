@@ -37,7 +37,8 @@ bool slices_need_state_tables(const Geometry& g);
 // One lane per slice: binarisation + adaptive states + range encoder.  llcomp.hpp:33-89, 166-206, 283-293, 439-449.
 //   d_sym     : symbols in LANE ORDER: u32 (ctx | residual << 16), or the 16-bit form of the fused path when
 //               model_is_fused(g)
-//   d_states  : u64[n_slices][kContexts], zeroed by the caller (8 state bytes per context); unused unless
+//   d_states  : u64[lane group][kContexts][lanes of the group], zeroed by the caller (8 state bytes per context and
+//               slice); unused unless
 //               slices_need_state_tables(g)
 //   d_scratch : the slices' streams in stream lane order ; d_slice_len : u32[n_slices]
 hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* d_states, uint8_t* d_scratch,
