@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LLCOMP_MI_ABI_VERSION 1
+#define LLCOMP_MI_ABI_VERSION 2
 
 /* Wire formats.  LEGACY is the reference's own: [0x79][channels u8][width u16 LE][height u16 LE] + ONE
  * range-coded stream (llcomp.hpp:375-378); it is a single serial chain (one GPU lane).  SLICED is this
@@ -40,12 +40,13 @@ typedef enum llcomp_mi_status {
     LLCOMP_MI_BAD_MAGIC = 1,       /* reference throws "Invalid magic number"  (llcomp.hpp:465-467) */
     LLCOMP_MI_BAD_EXPONENT = 2,    /* reference throws "Invalid exponent"      (llcomp.hpp:232-234) */
     LLCOMP_MI_TRUNCATED = 3,       /* header or slice table longer than the data (reference: UB, D5) */
-    LLCOMP_MI_BAD_ARGS = 4,        /* null pointers, zero sizes, channels outside 1..4, bad opts */
+    LLCOMP_MI_BAD_ARGS = 4,        /* null pointers, zero sizes, unsupported channel count, bad opts */
     LLCOMP_MI_OUT_OF_RANGE = 5,    /* legacy format with w or h > 65535, or w*h*c >= 2^31 (reference: silent truncation, D4) */
     LLCOMP_MI_OUTPUT_OVERFLOW = 6, /* caller-provided output capacity too small (reference: heap overflow, D1) */
     LLCOMP_MI_HIP_ERROR = 7,
     LLCOMP_MI_NO_DEVICE = 8,
-    LLCOMP_MI_NOMEM = 9
+    LLCOMP_MI_NOMEM = 9,
+    LLCOMP_MI_BUSY = 10            /* streaming pipeline: every slot is occupied / the oldest job is still in flight */
 } llcomp_mi_status;
 
 typedef enum llcomp_mi_format { LLCOMP_MI_FORMAT_LEGACY = 0, LLCOMP_MI_FORMAT_SLICED = 1 } llcomp_mi_format;
@@ -68,8 +69,21 @@ int llcomp_mi_encode(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, cons
 int llcomp_mi_decode(const uint8_t* data, size_t len, int32_t device, uint8_t** px, uint32_t* w, uint32_t* h,
                      uint32_t* c);
 void llcomp_mi_free(void* p);
+/* The same two calls with CALLER-PROVIDED output buffers (nothing is allocated for the caller).  If the capacity is too
+ * small they return LLCOMP_MI_OUTPUT_OVERFLOW and report what it takes (*out_len; *w,*h,*c), and nothing is written.
+ * Every host-buffer call works on a private HIP stream (never the NULL stream); with input and output buffers from
+ * llcomp_mi_host_alloc (pinned memory) the PCIe copies are plain DMA, pageable buffers are staged by the HIP runtime. */
+int llcomp_mi_encode_into(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, const llcomp_mi_opts* opts, uint8_t* out,
+                          size_t out_cap, size_t* out_len);
+int llcomp_mi_decode_into(const uint8_t* data, size_t len, int32_t device, uint8_t* px, size_t px_cap, uint32_t* w,
+                          uint32_t* h, uint32_t* c);
+void* llcomp_mi_host_alloc(size_t bytes); /* pinned host memory, NULL on failure */
+void llcomp_mi_host_free(void* p);
 const char* llcomp_mi_strerror(int status);
 int llcomp_mi_abi_version(void);
+/* Test / tuning hooks (LLCOMP_MI_LPW, _LANE_SHIFT, _NOROWS, _NOLDSTAB, _FORCE_REPLAY; none changes an output byte) are
+ * read from the environment once per process; a test that changes them calls this to have them read again. */
+void llcomp_mi_reload_tuning(void);
 /* Number of usable HIP devices (0 when there is none; never fails). */
 int llcomp_mi_device_count(void);
 
@@ -115,15 +129,55 @@ int llcomp_mi_codec_decode(llcomp_mi_codec* codec, const void* d_payload, uint64
 /* Stage-A only (context + prediction model), for tests and profiling: d_sym u32[frames*h*w*c],
  * low 16 bits = folded context (0..7925), high 16 bits = folded residual (two's complement). */
 int llcomp_mi_codec_model(llcomp_mi_codec* codec, const void* d_px, void* d_sym, void* stream);
+/* Device-side concatenator (multi-GPU sharding: the gathering rank interleaves the ranks' packed payloads into image
+ * order): copies n_seg byte ranges src[src_off[i] .. +len[i]) -> dst[dst_off[i] .. +len[i]) in one launch.  All five
+ * pointers are device memory (offsets / lengths: u64[n_seg], computed on the GPU); any alignment; ranges must not overlap.
+ * max_len = an upper bound of the lengths (sizes the grid only); n_seg <= 65535.  Asynchronous on `stream`. */
+int llcomp_mi_device_copy_segments(const void* d_src, void* d_dst, const void* d_src_off, const void* d_dst_off,
+                                   const void* d_len, uint32_t n_seg, uint64_t max_len, void* stream);
 /* The u32 status word written by encode/decode holds bit flags (1 overflow, 2 bad exponent, 4 truncated);
  * this maps it to an llcomp_mi_status. */
 uint32_t llcomp_mi_status_from_bits(uint32_t bits);
 /* Per-kernel timing with hipEvents recorded on the caller's stream around each launch (bench.py's roofline leg).
  * get_profile drains the stream, adds up the milliseconds since the last call and resets:
- *   ms[0] state-table clear  ms[1] k_model_fwd  ms[2] k_encode_slices  ms[3] k_scan_lengths+k_pack_payload
- *   ms[4] k_scan_lengths (decode)  ms[5] k_decode_slices  ms[6] k_model_inv  ms[7] state-table clear (decode) */
+ *   ms[0] state-table clear  ms[1] stage A (k_model_*)  ms[2] k_encode_slices  ms[3] k_scan_groups + k_pack_payload
+ *   ms[4] k_group_sums + k_scan_groups + k_stage_streams (decode)  ms[5] k_decode_slices  ms[6] stage A inverse
+ *   ms[7] state-table clear (decode) */
 int llcomp_mi_codec_set_profiling(llcomp_mi_codec* codec, int enable);
 int llcomp_mi_codec_get_profile(llcomp_mi_codec* codec, double* ms8, uint32_t* n_encode, uint32_t* n_decode);
+
+/* ---- streaming pipeline: frames of one shape, host -> GPU -> host, several jobs in flight (BASELINE config 5) ------- */
+/* The reference codes one image in RAM per call (llcompc.cpp:25-41, llcompd.cpp:17-31); this is the same operation as a
+ * pipeline.  `depth` slots (1..16), each with its own codec object, HIP stream, HBM buffers and a pinned output buffer;
+ * a job is one frame (SLICED container).  submit_* returns at once: LLCOMP_MI_OK, or LLCOMP_MI_BUSY when every slot is
+ * occupied (back-pressure: take a result and release it).  `px` / `data` must stay valid until the job's result has
+ * been returned by llcomp_mi_stream_wait; pinned memory (llcomp_mi_host_alloc, or the `data` of an earlier result that
+ * has not been released) is copied by DMA while other jobs compute.  Results come back in submission order.  A
+ * container that needs more than 2x the raw size fails with OUTPUT_OVERFLOW (llcomp_mi_encode handles such a frame).
+ * One object is driven by one thread at a time (calls are serialised internally). */
+typedef struct llcomp_mi_stream llcomp_mi_stream;
+enum { LLCOMP_MI_JOB_ENCODE = 0, LLCOMP_MI_JOB_DECODE = 1 };
+typedef struct llcomp_mi_stream_result {
+    uint32_t slot;       /* hand back with llcomp_mi_stream_release when `data` is no longer needed */
+    uint32_t kind;       /* LLCOMP_MI_JOB_ENCODE: data = container, LLCOMP_MI_JOB_DECODE: data = h*w*c pixels */
+    int32_t status;      /* llcomp_mi_status of this job */
+    uint32_t reserved;
+    uint64_t tag;        /* the caller's tag from submit */
+    const uint8_t* data; /* pinned host memory owned by the stream object; NULL when status != OK */
+    uint64_t len;
+} llcomp_mi_stream_result;
+int llcomp_mi_stream_create(llcomp_mi_stream** stream, int32_t device, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w,
+                            uint32_t tile_h, uint32_t planar, uint32_t depth);
+void llcomp_mi_stream_destroy(llcomp_mi_stream* stream);
+uint64_t llcomp_mi_stream_container_capacity(const llcomp_mi_stream* stream); /* largest container a slot can return */
+int llcomp_mi_stream_submit_encode(llcomp_mi_stream* stream, const uint8_t* px, uint64_t tag);
+int llcomp_mi_stream_submit_decode(llcomp_mi_stream* stream, const uint8_t* data, size_t len, uint64_t tag);
+int llcomp_mi_stream_pending(llcomp_mi_stream* stream); /* jobs submitted and not yet returned by wait */
+/* LLCOMP_MI_OK when llcomp_mi_stream_wait would not block (or nothing is pending), LLCOMP_MI_BUSY otherwise. */
+int llcomp_mi_stream_poll(llcomp_mi_stream* stream);
+/* Blocks until the OLDEST pending job has finished and describes it; BAD_ARGS when nothing is pending. */
+int llcomp_mi_stream_wait(llcomp_mi_stream* stream, llcomp_mi_stream_result* result);
+int llcomp_mi_stream_release(llcomp_mi_stream* stream, uint32_t slot);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,8 @@ from ._lib import Info, Opts
 
 EXT = ".llcomp"
 FORMAT_LEGACY, FORMAT_SLICED = 0, 1
-(OK, BAD_MAGIC, BAD_EXPONENT, TRUNCATED, BAD_ARGS, OUT_OF_RANGE, OUTPUT_OVERFLOW, HIP_ERROR, NO_DEVICE, NOMEM) = range(10)
+(OK, BAD_MAGIC, BAD_EXPONENT, TRUNCATED, BAD_ARGS, OUT_OF_RANGE, OUTPUT_OVERFLOW, HIP_ERROR, NO_DEVICE, NOMEM, BUSY) = range(11)
+JOB_ENCODE, JOB_DECODE = 0, 1
 
 RawImage = namedtuple("RawImage", "pixels width height channels")
 
@@ -71,6 +72,116 @@ def decompress_image(data, *, device=-1):
     finally:
         L.llcomp_mi_free(px)
     return RawImage(pixels, w.value, h.value, c.value)
+
+
+def reload_tuning():
+    """Have the library read its test / tuning hooks (LLCOMP_MI_*) from the environment again."""
+    _lib.load().llcomp_mi_reload_tuning()
+
+
+class PinnedBuffer:
+    """Pinned host memory from llcomp_mi_host_alloc, exposed as a numpy uint8 array (`.array`): copies between it and
+    the GPU are plain DMA."""
+
+    def __init__(self, nbytes):
+        self._L = _lib.load()
+        self.nbytes = int(nbytes)
+        self.ptr = self._L.llcomp_mi_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise LlcompError(NOMEM)
+        self.array = np.ctypeslib.as_array(C.cast(self.ptr, _lib.u8p), shape=(max(self.nbytes, 1),))[: self.nbytes]
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            self._L.llcomp_mi_host_free(self.ptr)
+            self.ptr = None
+
+    __del__ = close
+
+
+def compress_image_into(rgb, width, height, channels, out, *, format=FORMAT_LEGACY, tile_w=0, tile_h=0, planar=False, device=-1):
+    """llcomp_mi_encode_into: `rgb` and `out` are numpy uint8 arrays owned by the caller (pinned: PinnedBuffer.array);
+    returns the container length.  Raises LlcompError(OUTPUT_OVERFLOW) with .needed set when `out` is too small."""
+    L = _lib.load()
+    o = Opts(C.sizeof(Opts), format, tile_w, tile_h, int(bool(planar)), device)
+    n = C.c_size_t()
+    rc = L.llcomp_mi_encode_into(rgb.ctypes.data, width, height, channels, C.byref(o), out.ctypes.data, out.size, C.byref(n))
+    if rc != OK:
+        e = LlcompError(rc)
+        e.needed = n.value
+        raise e
+    return n.value
+
+
+def decompress_image_into(data, out, *, device=-1):
+    """llcomp_mi_decode_into: `data` / `out` numpy uint8 arrays owned by the caller -> (width, height, channels)."""
+    L = _lib.load()
+    w, h, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = L.llcomp_mi_decode_into(data.ctypes.data, data.size, device, out.ctypes.data, out.size, C.byref(w), C.byref(h), C.byref(c))
+    if rc != OK:
+        e = LlcompError(rc)
+        e.shape = (w.value, h.value, c.value)
+        raise e
+    return w.value, h.value, c.value
+
+
+StreamJob = namedtuple("StreamJob", "slot kind status tag data")
+
+
+class Stream:
+    """Streaming pipeline (llcomp_mi_stream_*): frames of one shape, host -> GPU -> host, `depth` jobs in flight.
+    submit_* return False instead of blocking when every slot is occupied (back-pressure); wait() returns the oldest
+    job as StreamJob whose .data is a numpy view of the stream's pinned output buffer, valid until release(job)."""
+
+    def __init__(self, w, h, c, tile_w=0, tile_h=0, planar=True, depth=4, device=-1):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        _check(self._L.llcomp_mi_stream_create(C.byref(self._h), device, w, h, c, tile_w, tile_h, int(bool(planar)), depth))
+        self.shape = (h, w, c)
+        self.container_capacity = self._L.llcomp_mi_stream_container_capacity(self._h)
+
+    def close(self):
+        if self._h:
+            self._L.llcomp_mi_stream_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _submit(self, rc):
+        if rc == BUSY:
+            return False
+        _check(rc)
+        return True
+
+    def submit_encode(self, px, tag=0):
+        """px: numpy uint8 [h,w,c] (C-contiguous); must stay alive and unchanged until its result came back."""
+        assert px.flags["C_CONTIGUOUS"] and px.dtype == np.uint8 and px.size == self.shape[0] * self.shape[1] * self.shape[2]
+        return self._submit(self._L.llcomp_mi_stream_submit_encode(self._h, px.ctypes.data, tag))
+
+    def submit_decode(self, data, tag=0):
+        """data: numpy uint8 container (e.g. the .data of an encode job that has not been released yet)."""
+        assert data.flags["C_CONTIGUOUS"] and data.dtype == np.uint8
+        return self._submit(self._L.llcomp_mi_stream_submit_decode(self._h, data.ctypes.data, data.size, tag))
+
+    def pending(self):
+        return self._L.llcomp_mi_stream_pending(self._h)
+
+    def ready(self):
+        return self._L.llcomp_mi_stream_poll(self._h) == OK
+
+    def wait(self):
+        r = _lib.StreamResult()
+        _check(self._L.llcomp_mi_stream_wait(self._h, C.byref(r)))
+        data = None
+        if r.status == OK:
+            data = np.ctypeslib.as_array(C.cast(r.data, _lib.u8p), shape=(max(int(r.len), 1),))[: int(r.len)]
+            if r.kind == JOB_DECODE:
+                data = data.reshape(self.shape)
+        return StreamJob(r.slot, r.kind, r.status, r.tag, data)
+
+    def release(self, job):
+        _check(self._L.llcomp_mi_stream_release(self._h, job.slot))
 
 
 def probe(data):

@@ -16,6 +16,11 @@ SYMBOLS = [
     "llcomp_mi_codec_workspace_bytes", "llcomp_mi_codec_max_payload_bytes", "llcomp_mi_codec_encode",
     "llcomp_mi_codec_decode", "llcomp_mi_codec_model", "llcomp_mi_status_from_bits",
     "llcomp_mi_codec_set_profiling", "llcomp_mi_codec_get_profile",
+    "llcomp_mi_encode_into", "llcomp_mi_decode_into", "llcomp_mi_host_alloc", "llcomp_mi_host_free",
+    "llcomp_mi_reload_tuning", "llcomp_mi_device_copy_segments",
+    "llcomp_mi_stream_create", "llcomp_mi_stream_destroy", "llcomp_mi_stream_container_capacity",
+    "llcomp_mi_stream_submit_encode", "llcomp_mi_stream_submit_decode", "llcomp_mi_stream_pending",
+    "llcomp_mi_stream_poll", "llcomp_mi_stream_wait", "llcomp_mi_stream_release",
 ]
 
 u8p = C.POINTER(C.c_uint8)
@@ -30,6 +35,11 @@ class Info(C.Structure):
     _fields_ = [("format", C.c_uint32), ("channels", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
                 ("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("planar", C.c_uint32), ("n_slices", C.c_uint32),
                 ("table_offset", C.c_uint64), ("payload_offset", C.c_uint64)]
+
+
+class StreamResult(C.Structure):
+    _fields_ = [("slot", C.c_uint32), ("kind", C.c_uint32), ("status", C.c_int32), ("reserved", C.c_uint32),
+                ("tag", C.c_uint64), ("data", C.c_void_p), ("len", C.c_uint64)]
 
 
 _lib = None
@@ -107,5 +117,35 @@ def load():
     L.llcomp_mi_codec_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.llcomp_mi_codec_get_profile.restype = C.c_int
     L.llcomp_mi_codec_get_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.llcomp_mi_encode_into.restype = C.c_int
+    L.llcomp_mi_encode_into.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Opts), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.llcomp_mi_decode_into.restype = C.c_int
+    L.llcomp_mi_decode_into.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.llcomp_mi_host_alloc.restype = C.c_void_p
+    L.llcomp_mi_host_alloc.argtypes = [C.c_size_t]
+    L.llcomp_mi_host_free.restype = None
+    L.llcomp_mi_host_free.argtypes = [C.c_void_p]
+    L.llcomp_mi_device_copy_segments.restype = C.c_int
+    L.llcomp_mi_device_copy_segments.argtypes = [C.c_void_p] * 5 + [C.c_uint32, C.c_uint64, C.c_void_p]
+    L.llcomp_mi_reload_tuning.restype = None
+    L.llcomp_mi_reload_tuning.argtypes = []
+    L.llcomp_mi_stream_create.restype = C.c_int
+    L.llcomp_mi_stream_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32] + [C.c_uint32] * 7
+    L.llcomp_mi_stream_destroy.restype = None
+    L.llcomp_mi_stream_destroy.argtypes = [C.c_void_p]
+    L.llcomp_mi_stream_container_capacity.restype = C.c_uint64
+    L.llcomp_mi_stream_container_capacity.argtypes = [C.c_void_p]
+    L.llcomp_mi_stream_submit_encode.restype = C.c_int
+    L.llcomp_mi_stream_submit_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.llcomp_mi_stream_submit_decode.restype = C.c_int
+    L.llcomp_mi_stream_submit_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]
+    L.llcomp_mi_stream_pending.restype = C.c_int
+    L.llcomp_mi_stream_pending.argtypes = [C.c_void_p]
+    L.llcomp_mi_stream_poll.restype = C.c_int
+    L.llcomp_mi_stream_poll.argtypes = [C.c_void_p]
+    L.llcomp_mi_stream_wait.restype = C.c_int
+    L.llcomp_mi_stream_wait.argtypes = [C.c_void_p, C.POINTER(StreamResult)]
+    L.llcomp_mi_stream_release.restype = C.c_int
+    L.llcomp_mi_stream_release.argtypes = [C.c_void_p, C.c_uint32]
     _lib = L
     return L

@@ -1,0 +1,92 @@
+// codec_internal.hpp -- the codec object behind llcomp_mi_codec_* and the helpers the host-side translation units share
+// (codec.hip: device-resident batch codec; hostapi.hip: host-buffer drop-in calls; stream.hip: streaming pipeline).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "../../include/llcomp_mi.h"
+#include "geometry.hpp"
+#include "kernels.hpp"
+
+struct llcomp_mi_codec {
+    llcomp_mi::Geometry g{};
+    int device = 0;
+    // workspace (all on `device`)
+    void* d_sym_or_rec = nullptr;    // image order: encode u32 symbols per sample / decode int16 reconstructed samples
+    void* d_lane_order = nullptr;    // the same data in lane order [group][k][64] for the serial kernels
+    uint64_t* d_states = nullptr;    // u64[lane group][kContexts][lanes of the group]
+    uint8_t* d_scratch = nullptr;    // slice streams in stream lane order: 16-byte units [group][unit][lane]
+    uint64_t* d_group_off = nullptr; // u64[lane groups + 1]: payload offset of every lane group's first slice
+    uint64_t* d_total_tmp = nullptr;
+    uint64_t workspace_bytes = 0;
+    bool need_states = true;  // false when the states live in LDS (1-row slices; one slice per wavefront)
+    // optional per-kernel timing (hipEvents on the caller's stream)
+    bool profiling = false;
+    struct Span { hipEvent_t a, b; int slot; };
+    std::vector<Span> spans;
+    uint32_t n_encode = 0, n_decode = 0;
+};
+
+namespace llcomp_mi {
+
+#define LLMI_HIP_TRY(expr)                                \
+    do {                                                  \
+        hipError_t _e = (expr);                           \
+        if (_e != hipSuccess) return LLCOMP_MI_HIP_ERROR; \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) return;
+        ok = (dev == prev) || hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (ok && prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+int status_from_bits(uint32_t bits);
+Tuning current_tuning();  // environment hooks, read once per process (llcomp_mi_reload_tuning re-reads them)
+int resolve_device(int32_t device, int* out);
+// argument checks shared by every entry point that takes an image shape: BAD_ARGS for nonsense, OUT_OF_RANGE for sizes
+// the formats cannot express (reference: silent truncation / int overflow)
+int check_shape(uint32_t w, uint32_t h, uint32_t c, bool legacy);
+
+// One coding lane of the host-side calls: a codec object for ONE frame plus everything a host buffer needs on its way
+// through the GPU -- a private HIP stream (never the NULL stream: concurrent callers do not serialise device-wide),
+// the frame and the container in HBM laid out exactly as on the wire ([header][slice table][payload], so a container
+// crosses PCIe in ONE copy), and a pinned 16-byte mailbox for {payload bytes, status}.
+struct HostLane {
+    llcomp_mi_codec* k = nullptr;
+    hipStream_t stream = nullptr;
+    uint8_t* d_px = nullptr;
+    uint8_t* d_container = nullptr;  // [header][u32 length table (sliced only)][payload capacity]
+    uint32_t* d_len_legacy = nullptr;  // the legacy format has no table on the wire: its single length lives here
+    uint64_t* d_meta = nullptr;      // [0] payload bytes (u64)  [1] low dword: status bits of the last call
+    uint64_t* h_meta = nullptr;      // pinned mirror of d_meta
+    uint64_t payload_cap = 0;
+    uint32_t head_bytes = 0;         // 6 (legacy) or 24 + 4 * slices
+    bool legacy = false;
+    uint64_t bytes = 0;              // device bytes held (idle-cache budget)
+
+    uint32_t* d_len() const { return legacy ? d_len_legacy : reinterpret_cast<uint32_t*>(d_container + LLCOMP_MI_SLICED_HEADER_BYTES); }
+    uint8_t* d_payload() const { return d_container + head_bytes; }
+    uint64_t raw_bytes() const { return uint64_t(k->g.w) * k->g.h * k->g.c; }
+};
+// builds a lane for this shape on `dev` (geometry + tuning hooks are fixed here); payload capacity `cap` bytes
+int lane_create(HostLane** out, int dev, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar,
+                bool legacy, uint64_t payload_cap);
+int lane_grow(HostLane* l, uint64_t payload_cap);  // reallocates the container buffer (contents lost)
+void lane_destroy(HostLane* l);
+// enqueue on the lane's stream (asynchronous): frame in d_px -> container in d_container, {bytes, status} -> h_meta
+int lane_enqueue_encode(HostLane* l);
+// container in d_container (`len` bytes including the header) -> frame in d_px, status -> h_meta
+int lane_enqueue_decode(HostLane* l, uint64_t len);
+
+}  // namespace llcomp_mi

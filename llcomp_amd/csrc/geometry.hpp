@@ -16,6 +16,8 @@
 
 namespace llcomp_mi {
 
+constexpr uint32_t kMaxChannels = 4;  // channels per pixel the kernels are instantiated for
+
 struct Geometry {
     uint32_t frames, w, h, c;
     uint32_t tile_w, tile_h, planar;
@@ -26,7 +28,41 @@ struct Geometry {
     uint32_t nch;               // channels coded inside one slice: planar ? 1 : c
     uint32_t lane_shift;        // log2 of the lane-group width (64 lanes, fewer when there are fewer slices)
     uint32_t slice_samples;     // sample capacity of one slice: tile_w * tile_h * nch
+    uint32_t lpw;               // slices per wavefront = active lanes (a power of two <= the group width)
+    uint32_t flags;             // kernel family, fixed when the codec object is created (kGeo* below)
 };
+enum : uint32_t {
+    kGeoRows = 1u,         // 1-row slices: the three reachable contexts' states live in LDS
+    kGeoLdsTable = 2u,     // one slice per wavefront: its 63 KB state table lives in LDS
+    kGeoForceReplay = 4u,  // test hook: every decoded sample also goes through rollback + checked replay
+};
+
+// Test / tuning hooks.  They are read from the environment ONCE per process (codec.hip: current_tuning; a test that
+// changes them calls llcomp_mi_reload_tuning), they select the kernel family when a codec object is created, and none
+// of them changes a single output byte.
+struct Tuning {
+    int lane_shift = -1;       // LLCOMP_MI_LANE_SHIFT: force the lane-group width (0..6)
+    int lpw = 0;               // LLCOMP_MI_LPW: fewer active lanes per wavefront
+    bool norows = false;       // LLCOMP_MI_NOROWS=1: 1-row slices through the general table-per-slice kernels
+    bool noldstab = false;     // LLCOMP_MI_NOLDSTAB=1: single-slice launches keep their table in HBM
+    bool force_replay = false; // LLCOMP_MI_FORCE_REPLAY=1
+};
+inline Tuning tuning_from_env() {
+    Tuning t;
+    auto num = [](const char* name, long lo, long hi, int dflt) {
+        const char* e = std::getenv(name);
+        if (!e || !*e) return dflt;
+        const long v = std::strtol(e, nullptr, 10);
+        return (v >= lo && v <= hi) ? int(v) : dflt;
+    };
+    auto flag = [](const char* name) { const char* e = std::getenv(name); return e && e[0] == '1'; };
+    t.lane_shift = num("LLCOMP_MI_LANE_SHIFT", 0, 6, -1);
+    t.lpw = num("LLCOMP_MI_LPW", 1, 64, 0);
+    t.norows = flag("LLCOMP_MI_NOROWS");
+    t.noldstab = flag("LLCOMP_MI_NOLDSTAB");
+    t.force_replay = flag("LLCOMP_MI_FORCE_REPLAY");
+    return t;
+}
 
 // lane order: element k of slice `id` inside an array laid out [group][k][group width]
 LLMI_HD inline size_t lane_order_index(const Geometry& g, uint32_t id, uint32_t k) {
@@ -59,12 +95,7 @@ LLMI_HD inline SliceRect slice_rect(const Geometry& g, uint32_t id) {
 // Width of a lane group = slices per wavefront.  A wavefront owns whole rows of the lane-order arrays (rows shared
 // between wavefronts on different XCDs are false sharing across non-coherent L2s: measured 2x slower), so the only
 // knob for "few slices" is a narrower group: full 64-lane groups as soon as that still gives >= kMinWaves wavefronts.
-// LLCOMP_MI_LANE_SHIFT overrides (tuning / tests).
 inline uint32_t default_lane_shift(uint32_t n_slices) {
-    if (const char* e = std::getenv("LLCOMP_MI_LANE_SHIFT")) {
-        const long v = std::strtol(e, nullptr, 10);
-        if (v >= 0 && v <= 6) return uint32_t(v);
-    }
     constexpr uint32_t kMinWaves = 96;
     uint32_t s = 6;
     while (s > 0 && (n_slices >> s) < kMinWaves) --s;
@@ -72,8 +103,8 @@ inline uint32_t default_lane_shift(uint32_t n_slices) {
 }
 
 inline bool make_geometry(Geometry& g, uint32_t frames, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w,
-                          uint32_t tile_h, uint32_t planar) {
-    if (!frames || !w || !h || c < 1 || c > 4) return false;
+                          uint32_t tile_h, uint32_t planar, const Tuning& tune = Tuning{}) {
+    if (!frames || !w || !h || c < 1 || c > kMaxChannels) return false;
     if (tile_w == 0 || tile_w > w) tile_w = w;
     if (tile_h == 0 || tile_h > h) tile_h = h;
     const uint64_t samples = uint64_t(w) * h * c;
@@ -87,11 +118,24 @@ inline bool make_geometry(Geometry& g, uint32_t frames, uint32_t w, uint32_t h, 
     g.slices_per_frame = uint32_t(spf);
     g.n_slices = uint32_t(spf * frames);
     g.nch = g.planar ? 1 : c;
-    const uint64_t cap = (uint64_t(tile_w) * tile_h * g.nch * 13 + 32 + 15) & ~15ull;  // 13 B/sample bound + slack
-    if (cap >= (1ull << 32)) return false;
-    g.slice_cap = uint32_t(cap);
+    // 13 B/sample bound + slack.  A slice beyond 165 M samples (only a legacy whole-image stream can be that big) gets
+    // the largest capacity the kernels' 32-bit stream positions allow; real streams stay below 1.3 B/sample and an
+    // overflow would be reported, never written.
+    const uint64_t cap = (uint64_t(tile_w) * tile_h * g.nch * 13 + 32 + 15) & ~15ull;
+    g.slice_cap = uint32_t(cap < 0x7FFFFFF0ull ? cap : 0x7FFFFFF0ull);
     g.slice_samples = tile_w * tile_h * g.nch;
-    g.lane_shift = default_lane_shift(g.n_slices);
+    g.lane_shift = tune.lane_shift >= 0 ? uint32_t(tune.lane_shift) : default_lane_shift(g.n_slices);
+    const uint32_t gw = 1u << g.lane_shift;
+    g.lpw = gw;
+    if (tune.lpw >= 1) {  // rounded down to a power of two: a wavefront never straddles lane groups
+        uint32_t p = 1;
+        while (p * 2 <= uint32_t(tune.lpw) && p * 2 <= gw) p *= 2;
+        g.lpw = p;
+    }
+    g.flags = 0;
+    if (g.tile_h == 1 && !tune.norows) g.flags |= kGeoRows;
+    else if (g.lpw == 1 && !tune.noldstab) g.flags |= kGeoLdsTable;
+    if (tune.force_replay) g.flags |= kGeoForceReplay;
     return true;
 }
 

@@ -1,0 +1,317 @@
+// hostapi.hip -- host-buffer calls of libllcomp_mi.so: the drop-in for llcomp::compressImage / decompressImage
+// (/root/reference/llcomp.hpp:358, 461; callers llcompc.cpp:33, llcompd.cpp:26).
+//
+// A call takes a "lane" (codec_internal.hpp: codec object for one frame + private HIP stream + the frame and the container
+// in HBM in wire layout) from a small cache keyed by device + geometry, copies the input over PCIe, enqueues the kernels,
+// reads back {payload bytes, status} through a pinned mailbox and then the container / the pixels in ONE copy of the
+// exact size.  Nothing runs on the NULL stream and nothing synchronises the device: concurrent callers overlap.
+// With buffers from llcomp_mi_host_alloc (pinned) on both sides the copies are plain DMA; with pageable buffers the HIP
+// runtime stages them.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/llcomp_mi.h"
+#include "codec_internal.hpp"
+#include "container.hpp"
+
+using namespace llcomp_mi;
+
+namespace llcomp_mi {
+
+void lane_destroy(HostLane* l) {
+    if (!l) return;
+    {
+        DeviceGuard guard(l->k ? l->k->device : 0);
+        if (l->stream) (void)hipStreamSynchronize(l->stream);
+        (void)hipFree(l->d_px);
+        (void)hipFree(l->d_container);
+        (void)hipFree(l->d_len_legacy);
+        (void)hipFree(l->d_meta);
+        if (l->h_meta) (void)hipHostFree(l->h_meta);
+        if (l->stream) (void)hipStreamDestroy(l->stream);
+    }
+    llcomp_mi_codec_destroy(l->k);
+    delete l;
+}
+
+static int lane_write_header(HostLane* l) {
+    uint8_t head[LLCOMP_MI_SLICED_HEADER_BYTES];
+    const Geometry& g = l->k->g;
+    if (l->legacy) write_legacy_header(head, g.w, g.h, g.c);
+    else write_sliced_header(head, g);
+    LLMI_HIP_TRY(hipMemcpyAsync(l->d_container, head, l->legacy ? 6 : LLCOMP_MI_SLICED_HEADER_BYTES, hipMemcpyHostToDevice, l->stream));
+    LLMI_HIP_TRY(hipStreamSynchronize(l->stream));  // `head` lives on this stack frame
+    return LLCOMP_MI_OK;
+}
+
+int lane_grow(HostLane* l, uint64_t payload_cap) {
+    if (payload_cap <= l->payload_cap) return LLCOMP_MI_OK;
+    DeviceGuard guard(l->k->device);
+    if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
+    (void)hipStreamSynchronize(l->stream);
+    (void)hipFree(l->d_container);
+    l->d_container = nullptr;
+    l->bytes -= l->head_bytes + l->payload_cap;
+    l->payload_cap = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&l->d_container), l->head_bytes + payload_cap + 16) != hipSuccess) return LLCOMP_MI_NOMEM;
+    l->payload_cap = payload_cap;
+    l->bytes += l->head_bytes + payload_cap;
+    return lane_write_header(l);
+}
+
+int lane_create(HostLane** out, int dev, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar,
+                bool legacy, uint64_t payload_cap) {
+    *out = nullptr;
+    HostLane* l = new (std::nothrow) HostLane;
+    if (!l) return LLCOMP_MI_NOMEM;
+    l->legacy = legacy;
+    if (int rc = llcomp_mi_codec_create(&l->k, dev, 1, w, h, c, tile_w, tile_h, planar)) {
+        delete l;
+        return rc;
+    }
+    DeviceGuard guard(dev);
+    const Geometry& g = l->k->g;
+    l->head_bytes = legacy ? 6u : uint32_t(LLCOMP_MI_SLICED_HEADER_BYTES) + 4u * g.n_slices;
+    const uint64_t raw = l->raw_bytes();
+    const bool ok = guard.ok && hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) == hipSuccess &&
+                    hipMalloc(reinterpret_cast<void**>(&l->d_px), raw + 4) == hipSuccess &&
+                    hipMalloc(reinterpret_cast<void**>(&l->d_len_legacy), 4) == hipSuccess &&
+                    hipMalloc(reinterpret_cast<void**>(&l->d_meta), 16) == hipSuccess &&
+                    hipHostMalloc(reinterpret_cast<void**>(&l->h_meta), 16, hipHostMallocDefault) == hipSuccess;
+    if (!ok) {
+        lane_destroy(l);
+        return LLCOMP_MI_NOMEM;
+    }
+    l->bytes = raw + 24;
+    if (int rc = lane_grow(l, payload_cap)) {
+        lane_destroy(l);
+        return rc;
+    }
+    *out = l;
+    return LLCOMP_MI_OK;
+}
+
+int lane_enqueue_encode(HostLane* l) {
+    if (int rc = llcomp_mi_codec_encode(l->k, l->d_px, l->d_payload(), l->payload_cap, l->d_len(), l->d_meta, l->d_meta + 1, l->stream))
+        return rc;
+    LLMI_HIP_TRY(hipMemcpyAsync(l->h_meta, l->d_meta, 16, hipMemcpyDeviceToHost, l->stream));
+    return LLCOMP_MI_OK;
+}
+
+int lane_enqueue_decode(HostLane* l, uint64_t len) {
+    const uint64_t payload_bytes = len - l->head_bytes;
+    if (l->legacy) {
+        const uint32_t one = uint32_t(std::min<uint64_t>(payload_bytes, 0xFFFFFFFFull));
+        LLMI_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(l->d_len_legacy), int(one), 1, l->stream));
+    }
+    if (int rc = llcomp_mi_codec_decode(l->k, l->d_payload(), payload_bytes, l->d_len(), l->d_px, l->d_meta + 1, l->stream)) return rc;
+    LLMI_HIP_TRY(hipMemcpyAsync(l->h_meta, l->d_meta, 16, hipMemcpyDeviceToHost, l->stream));
+    return LLCOMP_MI_OK;
+}
+
+}  // namespace llcomp_mi
+
+namespace {
+
+// A lane holds GBs of workspace for a 4K frame; allocating it per call costs more than the coding.  A few idle ones are
+// kept, keyed by device + geometry (which includes the kernel family the tuning hooks selected when the lane was
+// made).  Never torn down at exit on purpose (the HIP runtime may already be gone by then).
+struct LaneCache {
+    struct Item { HostLane* l; uint64_t stamp; };
+    std::mutex mu;
+    std::vector<Item> idle;
+    uint64_t clock = 0;
+    static constexpr size_t kMaxIdle = 4;
+    static constexpr uint64_t kMaxIdleBytes = 12ull << 30;
+
+    HostLane* take(int dev, const Geometry& g, bool legacy) {
+        std::lock_guard<std::mutex> lock(mu);
+        for (size_t i = 0; i < idle.size(); ++i)
+            if (idle[i].l->k->device == dev && idle[i].l->legacy == legacy && std::memcmp(&idle[i].l->k->g, &g, sizeof(Geometry)) == 0) {
+                HostLane* l = idle[i].l;
+                idle.erase(idle.begin() + long(i));
+                return l;
+            }
+        return nullptr;
+    }
+    void give(HostLane* l) {
+        std::vector<HostLane*> drop;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            idle.push_back({l, ++clock});
+            auto bytes = [&]() { uint64_t b = 0; for (auto& it : idle) b += it.l->k->workspace_bytes + it.l->bytes; return b; };
+            while (idle.size() > kMaxIdle || (idle.size() > 1 && bytes() > kMaxIdleBytes)) {
+                size_t oldest = 0;
+                for (size_t i = 1; i < idle.size(); ++i) if (idle[i].stamp < idle[oldest].stamp) oldest = i;
+                drop.push_back(idle[oldest].l);
+                idle.erase(idle.begin() + long(oldest));
+            }
+        }
+        for (auto* d : drop) lane_destroy(d);
+    }
+};
+LaneCache& lane_cache() {
+    static LaneCache* c = new LaneCache;  // leaked deliberately
+    return *c;
+}
+
+int acquire_lane(HostLane** out, int32_t device, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar,
+                 bool legacy, uint64_t min_cap) {
+    Geometry g;
+    std::memset(&g, 0, sizeof(g));
+    if (!make_geometry(g, 1, w, h, c, tile_w, tile_h, planar, current_tuning())) return LLCOMP_MI_OUT_OF_RANGE;
+    int dev = 0;
+    if (int rc = resolve_device(device, &dev)) return rc;
+    if ((*out = lane_cache().take(dev, g, legacy))) return lane_grow(*out, min_cap);
+    return lane_create(out, dev, w, h, c, tile_w, tile_h, planar, legacy, min_cap);
+}
+
+struct LaneLease {  // returns the lane to the cache on every exit path
+    HostLane* l = nullptr;
+    ~LaneLease() { if (l) lane_cache().give(l); }
+};
+
+// encode into `out` (capacity out_cap) when out != nullptr, else into a malloc'ed buffer returned through *out_alloc
+int encode_common(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, const llcomp_mi_opts* opts, uint8_t* out, size_t out_cap,
+                  uint8_t** out_alloc, size_t* out_len) {
+    *out_len = 0;
+    llcomp_mi_opts o{};
+    o.struct_size = sizeof(o);
+    o.format = LLCOMP_MI_FORMAT_LEGACY;
+    o.device = -1;
+    if (opts) {
+        if (opts->struct_size != sizeof(llcomp_mi_opts)) return LLCOMP_MI_BAD_ARGS;
+        o = *opts;
+    }
+    if (o.format != LLCOMP_MI_FORMAT_LEGACY && o.format != LLCOMP_MI_FORMAT_SLICED) return LLCOMP_MI_BAD_ARGS;
+    const bool legacy = o.format == LLCOMP_MI_FORMAT_LEGACY;
+    if (int rc = check_shape(w, h, c, legacy)) return rc;
+    const uint32_t tile_w = legacy ? w : (o.tile_w == 0 || o.tile_w > w ? w : o.tile_w);
+    const uint32_t tile_h = legacy ? h : (o.tile_h == 0 || o.tile_h > h ? h : o.tile_h);
+    const uint32_t planar = legacy ? 0 : (o.planar ? 1 : 0);
+    const uint64_t raw = uint64_t(w) * h * c;
+
+    LaneLease lease;
+    // first try with room for 2x raw (incompressible noise needs ~1.25x), then the proven worst case
+    const uint64_t first_cap = 2 * raw + 64ull * llcomp_mi_slice_count(w, h, c, tile_w, tile_h, planar) + 4096;
+    if (int rc = acquire_lane(&lease.l, o.device, w, h, c, tile_w, tile_h, planar, legacy, 0)) return rc;
+    HostLane* l = lease.l;
+    const uint64_t max_payload = llcomp_mi_codec_max_payload_bytes(l->k);
+    if (int rc = lane_grow(l, std::min(first_cap, max_payload))) return rc;
+    DeviceGuard guard(l->k->device);
+    if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
+    LLMI_HIP_TRY(hipMemcpyAsync(l->d_px, px, raw, hipMemcpyHostToDevice, l->stream));
+    int rc = LLCOMP_MI_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if ((rc = lane_enqueue_encode(l))) return rc;
+        LLMI_HIP_TRY(hipStreamSynchronize(l->stream));
+        rc = status_from_bits(uint32_t(l->h_meta[1]));
+        if (rc == LLCOMP_MI_OUTPUT_OVERFLOW && l->payload_cap < max_payload) {
+            if (int rc2 = lane_grow(l, max_payload)) return rc2;
+            continue;
+        }
+        break;
+    }
+    if (rc) return rc;
+    const size_t n = size_t(l->head_bytes) + size_t(l->h_meta[0]);
+    *out_len = n;
+    uint8_t* dst = out;
+    if (!dst) {
+        dst = static_cast<uint8_t*>(std::malloc(n + 1));
+        if (!dst) return LLCOMP_MI_NOMEM;
+    } else if (n > out_cap) {
+        return LLCOMP_MI_OUTPUT_OVERFLOW;  // *out_len tells the caller what it takes
+    }
+    // header, slice table and payload sit in HBM exactly as on the wire (little-endian u32 on both sides): one copy
+    if (hipMemcpyAsync(dst, l->d_container, n, hipMemcpyDeviceToHost, l->stream) != hipSuccess ||
+        hipStreamSynchronize(l->stream) != hipSuccess) {
+        if (!out) std::free(dst);
+        return LLCOMP_MI_HIP_ERROR;
+    }
+    if (out_alloc) *out_alloc = dst;
+    return LLCOMP_MI_OK;
+}
+
+int decode_common(const uint8_t* data, size_t len, int32_t device, uint8_t* px, size_t px_cap, uint8_t** px_alloc, uint32_t* w,
+                  uint32_t* h, uint32_t* c) {
+    llcomp_mi_info info;
+    if (int rc = llcomp_mi_probe(data, len, &info)) return rc;
+    const bool legacy = info.format == LLCOMP_MI_FORMAT_LEGACY;
+    if (int rc = check_shape(info.width, info.height, info.channels, legacy)) return rc;
+    const uint64_t raw = uint64_t(info.width) * info.height * info.channels;
+    *w = info.width;
+    *h = info.height;
+    *c = info.channels;
+    if (px && raw > px_cap) return LLCOMP_MI_OUTPUT_OVERFLOW;  // dimensions are reported: the caller can size its buffer
+    LaneLease lease;
+    if (int rc = acquire_lane(&lease.l, device, info.width, info.height, info.channels, info.tile_w, info.tile_h, info.planar, legacy,
+                              len - info.payload_offset + 16))
+        return rc;
+    HostLane* l = lease.l;
+    DeviceGuard guard(l->k->device);
+    if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
+    // the container goes to HBM as it is: the slice table is read where it lies (offset 24, dword aligned)
+    LLMI_HIP_TRY(hipMemcpyAsync(l->d_container, data, len, hipMemcpyHostToDevice, l->stream));
+    if (int rc = lane_enqueue_decode(l, len)) return rc;
+    LLMI_HIP_TRY(hipStreamSynchronize(l->stream));
+    if (int rc = status_from_bits(uint32_t(l->h_meta[1]))) return rc;
+    uint8_t* dst = px;
+    if (!dst) {
+        dst = static_cast<uint8_t*>(std::malloc(raw ? raw : 1));
+        if (!dst) return LLCOMP_MI_NOMEM;
+    }
+    if (hipMemcpyAsync(dst, l->d_px, raw, hipMemcpyDeviceToHost, l->stream) != hipSuccess || hipStreamSynchronize(l->stream) != hipSuccess) {
+        if (!px) std::free(dst);
+        return LLCOMP_MI_HIP_ERROR;
+    }
+    if (px_alloc) *px_alloc = dst;
+    return LLCOMP_MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int llcomp_mi_encode(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, const llcomp_mi_opts* opts, uint8_t** out, size_t* out_len) {
+    if (!px || !out || !out_len) return LLCOMP_MI_BAD_ARGS;
+    *out = nullptr;
+    const int rc = encode_common(px, w, h, c, opts, nullptr, 0, out, out_len);
+    if (rc) *out_len = 0;
+    return rc;
+}
+
+int llcomp_mi_encode_into(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, const llcomp_mi_opts* opts, uint8_t* out,
+                          size_t out_cap, size_t* out_len) {
+    if (!px || !out || !out_len) return LLCOMP_MI_BAD_ARGS;
+    return encode_common(px, w, h, c, opts, out, out_cap, nullptr, out_len);
+}
+
+int llcomp_mi_decode(const uint8_t* data, size_t len, int32_t device, uint8_t** px, uint32_t* w, uint32_t* h, uint32_t* c) {
+    if (!data || !px || !w || !h || !c) return LLCOMP_MI_BAD_ARGS;
+    *px = nullptr;
+    return decode_common(data, len, device, nullptr, 0, px, w, h, c);
+}
+
+int llcomp_mi_decode_into(const uint8_t* data, size_t len, int32_t device, uint8_t* px, size_t px_cap, uint32_t* w, uint32_t* h,
+                          uint32_t* c) {
+    if (!data || !px || !w || !h || !c) return LLCOMP_MI_BAD_ARGS;
+    return decode_common(data, len, device, px, px_cap, nullptr, w, h, c);
+}
+
+void* llcomp_mi_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void llcomp_mi_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+}  // extern "C"

@@ -42,21 +42,27 @@ bool slices_need_state_tables(const Geometry& g);
 //               slices_need_state_tables(g)
 //   d_scratch : the slices' streams in stream lane order ; d_slice_len : u32[n_slices]
 hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* d_states, uint8_t* d_scratch,
-                                uint32_t* d_slice_len, uint32_t* d_status, hipStream_t stream);
-// Exclusive prefix sum of slice lengths (u64[n_slices+1]; last = total, also stored to d_total).
-// d_block_sums: scratch of scan_block_count(n) u64.
-uint32_t scan_block_count(uint32_t n);
-hipError_t launch_scan_lengths(const uint32_t* d_slice_len, uint32_t n, uint64_t* d_offsets, uint64_t* d_total,
-                               uint64_t* d_block_sums, hipStream_t stream);
+                                uint32_t* d_slice_len, uint64_t* d_group_off, uint32_t* d_status, hipStream_t stream);
+// Offsets of the slices in the packed payload: one exclusive prefix value per LANE GROUP, u64[lane_groups + 1] (the last
+// element and *d_total = sum of all lengths); pack / stage add the wave prefix of the group's own lengths.
+// launch_encode_slices leaves the group sums in d_group_off itself when encoder_writes_group_sums(g); otherwise (and
+// for decode, where the lengths come from outside) launch_group_sums computes them.  launch_scan_groups: sums -> offsets.
+bool encoder_writes_group_sums(const Geometry& g);
+hipError_t launch_group_sums(const Geometry& g, const uint32_t* d_slice_len, uint64_t* d_group_off, hipStream_t stream);
+hipError_t launch_scan_groups(const Geometry& g, uint64_t* d_group_off, uint64_t* d_total, hipStream_t stream);
 // Slice streams live in STREAM LANE ORDER for the serial kernels: 16-byte units [group][unit][lane], slice_cap/16 units
 // per slice (model_kernels.hip).  pack: that order -> payload (slices back to back, capacity payload_cap);
 // stage: payload -> that order.
 hipError_t launch_pack_payload(const Geometry& g, const uint8_t* d_units, const uint32_t* d_slice_len,
-                               const uint64_t* d_offsets, uint8_t* d_payload, uint64_t payload_cap,
+                               const uint64_t* d_group_off, uint8_t* d_payload, uint64_t payload_cap,
                                uint32_t* d_status, hipStream_t stream);
 hipError_t launch_stage_streams(const Geometry& g, const uint8_t* d_payload, uint64_t payload_bytes,
-                                const uint32_t* d_slice_len, const uint64_t* d_offsets, uint8_t* d_units,
+                                const uint32_t* d_slice_len, const uint64_t* d_group_off, uint8_t* d_units,
                                 uint32_t* d_status, hipStream_t stream);
+// n_seg byte ranges src[src_off[i] .. +len[i]) -> dst[dst_off[i] .. +len[i]) in one launch (offsets / lengths in HBM, any
+// alignment); max_len = an upper bound of the lengths (grid sizing only).  The device-side concatenator of the multi-GPU path.
+hipError_t launch_copy_segments(const uint8_t* d_src, uint8_t* d_dst, const uint64_t* d_src_off, const uint64_t* d_dst_off,
+                                const uint64_t* d_len, uint32_t n_seg, uint64_t max_len, hipStream_t stream);
 // One lane per slice: range decoder + adaptive states + context model on reconstructed samples.
 // llcomp.hpp:91-127, 219-247, 486-530.  d_rec int16 in LANE ORDER.
 // d_units: the slices' streams in stream lane order (launch_stage_streams).

@@ -9,8 +9,8 @@
 //                 the same two stages fused with the lane-order transpose for planar 1-row slices.
 //   k_to_lane_order / k_from_lane_order
 //                 64x64 LDS transposes between image order and the [group][k][lane] order of the serial kernels.
-//   k_scan_local / k_scan_blocks / k_scan_add
-//                 wave-prefix-sum of slice lengths.
+//   k_group_sums / k_scan_groups
+//                 prefix sum of the slice lengths, one value per lane group (the rest is a wave prefix in pack / stage).
 //   k_pack_payload / k_stage_streams
 //                 LDS-tile moves between the packed payload and the stream lane order the serial kernels use.
 // None of this is GEMM-shaped; there is no MFMA here on purpose.
@@ -166,14 +166,17 @@ __global__ __launch_bounds__(256) void k_model_inv(const Geometry g, const int16
     }
 }
 
-// ---- slice length scan + payload packing -------------------------------------------------------------------
-// Exclusive prefix sum of the slice lengths in three small launches (slices can number in the millions):
-//   k_scan_local  : every block of 256 threads scans kScanChunk = 4096 lengths (16 per thread, wave prefix via DPP
-//                   shuffles, 4 wave totals through LDS) -> block-local offsets + one total per block
-//   k_scan_blocks : one block scans the block totals (exclusive, in place) and writes the grand total
-//   k_scan_add    : offsets += their block's base; off[n] = total
-constexpr uint32_t kScanPerThread = 16, kScanThreads = 256, kScanChunk = kScanPerThread * kScanThreads;
-
+// ---- slice length scan ------------------------------------------------------------------------------------------------
+// The packed payload holds the slices back to back in slice order, so slice i starts at the sum of the lengths before
+// it.  pack / stage work on whole lane groups (64 consecutive slices) and find a slice's offset as
+//     group_off[group] + (wave prefix sum of the group's 64 lengths),
+// so only ONE value per lane group has to be scanned globally:
+//   * the encoder kernel leaves the sum of its wavefront's lengths behind for free (k_encode_slices, slice_kernels.hip);
+//     k_group_sums does the same for lengths that come from outside (decode; encode with fewer lanes per wavefront
+//     than the group is wide),
+//   * k_scan_groups -- ONE small block -- turns the <= tens of thousands of group sums into exclusive offsets.
+// (Round 1 scanned all 1.6 M slice lengths in three dependent launches; next to the other pipelines' slice kernels
+// each of them waited ~0.4 ms for a free wave slot, profiles/r01_default_kernel_stats.csv.)
 __device__ __forceinline__ unsigned long long wave_inclusive_scan(unsigned long long v, uint32_t lane) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -183,59 +186,48 @@ __device__ __forceinline__ unsigned long long wave_inclusive_scan(unsigned long 
     return v;
 }
 
-__global__ __launch_bounds__(kScanThreads) void k_scan_local(const uint32_t* __restrict__ len, uint32_t n,
-                                                             uint64_t* __restrict__ off,
-                                                             uint64_t* __restrict__ block_sum) {
-    __shared__ unsigned long long wave_sum[kScanThreads / 64];
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
-    uint32_t v[kScanPerThread];
-    unsigned long long mine = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < kScanPerThread; ++j) {
-        v[j] = base + j < n ? len[base + j] : 0;
-        mine += v[j];
-    }
-    const unsigned long long inc = wave_inclusive_scan(mine, lane);
-    if (lane == 63) wave_sum[wv] = inc;
-    __syncthreads();
-    unsigned long long run = inc - mine;
-    for (uint32_t k = 0; k < wv; ++k) run += wave_sum[k];
-#pragma unroll
-    for (uint32_t j = 0; j < kScanPerThread; ++j) {
-        if (base + j < n) off[base + j] = run;
-        run += v[j];
-    }
-    if (threadIdx.x == kScanThreads - 1) block_sum[blockIdx.x] = run;
+__global__ __launch_bounds__(256) void k_group_sums(const uint32_t* __restrict__ len, uint32_t n, uint32_t lane_shift,
+                                                    uint64_t* __restrict__ group_sum) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long v = i < n ? len[i] : 0;
+    for (uint32_t d = 1; d < (1u << lane_shift); d <<= 1) v += __shfl_xor(v, int(d), 64);  // groups are aligned pieces of a wave
+    if ((i & ((1u << lane_shift) - 1)) == 0 && i < n) group_sum[i >> lane_shift] = v;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_blocks(uint64_t* __restrict__ block_sum, uint32_t nb, uint64_t* total) {
-    __shared__ unsigned long long wave_sum[16];
+constexpr uint32_t kScanThreads = 256, kScanPerThread = 4;
+// in: sums[0 .. ng)   out: sums[g] = sum of the groups before g, sums[ng] = *total = sum of all
+__global__ __launch_bounds__(kScanThreads) void k_scan_groups(uint64_t* __restrict__ sums, uint32_t ng, uint64_t* total) {
+    __shared__ unsigned long long wave_sum[kScanThreads / 64];
     __shared__ unsigned long long carry;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < nb; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const unsigned long long v = i < nb ? block_sum[i] : 0;
-        const unsigned long long inc = wave_inclusive_scan(v, lane);
+    for (uint32_t base = 0; base < ng; base += kScanThreads * kScanPerThread) {
+        const uint32_t i0 = base + threadIdx.x * kScanPerThread;
+        unsigned long long v[kScanPerThread], mine = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kScanPerThread; ++j) {
+            v[j] = i0 + j < ng ? sums[i0 + j] : 0;
+            mine += v[j];
+        }
+        const unsigned long long inc = wave_inclusive_scan(mine, lane);
         if (lane == 63) wave_sum[wv] = inc;
         __syncthreads();
-        unsigned long long before = carry;
-        for (uint32_t k = 0; k < wv; ++k) before += wave_sum[k];
-        if (i < nb) block_sum[i] = before + inc - v;
+        unsigned long long run = carry + inc - mine;
+        for (uint32_t k = 0; k < wv; ++k) run += wave_sum[k];
+#pragma unroll
+        for (uint32_t j = 0; j < kScanPerThread; ++j) {
+            if (i0 + j < ng) sums[i0 + j] = run;
+            run += v[j];
+        }
         __syncthreads();
-        if (threadIdx.x == 1023) carry = before + inc;
+        if (threadIdx.x == kScanThreads - 1) carry = run;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = carry;
-}
-
-__global__ __launch_bounds__(256) void k_scan_add(uint64_t* __restrict__ off, uint32_t n,
-                                                  const uint64_t* __restrict__ block_sum, const uint64_t* total) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) off[i] += block_sum[i / kScanChunk];
-    if (i == n) off[n] = *total;
+    if (threadIdx.x == 0) {
+        sums[ng] = carry;
+        *total = carry;
+    }
 }
 
 // ---- slice streams: packed payload <-> stream lane order ---------------------------------------------------------------
@@ -260,15 +252,15 @@ struct GroupStreams {
     uint32_t max_len;
 };
 __device__ __forceinline__ void load_group_streams(const Geometry& g, uint32_t group, const uint32_t* slice_len,
-                                                   const uint64_t* off, uint64_t limit, uint32_t* status,
+                                                   const uint64_t* group_off, uint64_t limit, uint32_t* status,
                                                    uint32_t err_bit, GroupStreams& gs) {
     if (threadIdx.x < 64) {
         const uint32_t id = (group << g.lane_shift) + threadIdx.x;
-        uint32_t n = 0;
-        unsigned long long o = 0;
-        if (threadIdx.x < (1u << g.lane_shift) && id < g.n_slices) {
-            n = slice_len[id];
-            o = off[id];
+        const bool live = threadIdx.x < (1u << g.lane_shift) && id < g.n_slices;
+        uint32_t n = live ? slice_len[id] : 0;
+        // offset of the slice = offset of its lane group + the lengths of the group's slices before it
+        unsigned long long o = group_off[group] + wave_inclusive_scan(n, threadIdx.x) - n;
+        if (live) {
             if (o + n > limit) {  // the slice does not fit the payload (decode: table promises too much)
                 atomicOr(status, err_bit);
                 n = err_bit == kStOverflow ? 0u : (o < limit ? uint32_t(limit - o) : 0u);
@@ -354,6 +346,35 @@ __global__ __launch_bounds__(256) void k_stage_streams(const Geometry g, const u
                     make_uint4(tile[a][uu * 4 + 0], tile[a][uu * 4 + 1], tile[a][uu * 4 + 2], tile[a][uu * 4 + 3]);
         }
         __syncthreads();
+    }
+}
+
+// ---- byte segments: the device-side concatenator of the multi-GPU path ------------------------------------------------
+// A sharded image arrives on the gathering rank as one packed payload per rank; the container wants the slices in
+// image order, i.e. the ranks' pieces interleaved chunk by chunk (llcomp_amd/sharding.py).  One launch copies n_seg byte
+// ranges src[src_off[i] .. +len[i]) -> dst[dst_off[i] .. +len[i]); offsets and lengths live in HBM (they were computed
+// there), alignment is arbitrary.  blockIdx.y = segment, blockIdx.x strides over 16 KiB pieces of it.
+constexpr uint32_t kSegPieceDwords = 4096;
+__global__ __launch_bounds__(256) void k_copy_segments(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                       const uint64_t* __restrict__ src_off, const uint64_t* __restrict__ dst_off,
+                                                       const uint64_t* __restrict__ len) {
+    const uint64_t n = len[blockIdx.y];
+    const uint8_t* s = src + src_off[blockIdx.y];
+    uint8_t* d = dst + dst_off[blockIdx.y];
+    // dword stores want an aligned destination: up to 3 head bytes and up to 3 tail bytes go one by one
+    const uint64_t head = min(n, uint64_t((4 - (reinterpret_cast<uintptr_t>(d) & 3)) & 3));
+    const uint64_t ndw = (n - head) >> 2, tail = (n - head) & 3;
+    for (uint64_t j0 = uint64_t(blockIdx.x) * kSegPieceDwords; j0 < ndw; j0 += uint64_t(gridDim.x) * kSegPieceDwords) {
+        const uint64_t j1 = min(ndw, j0 + kSegPieceDwords);
+        for (uint64_t j = j0 + threadIdx.x; j < j1; j += 256) {
+            uint32_t w;
+            __builtin_memcpy(&w, s + head + 4 * j, 4);  // source alignment is arbitrary
+            *reinterpret_cast<uint32_t*>(d + head + 4 * j) = w;
+        }
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) d[threadIdx.x] = s[threadIdx.x];
+        if (threadIdx.x < tail) d[head + 4 * ndw + threadIdx.x] = s[head + 4 * ndw + threadIdx.x];
     }
 }
 
@@ -699,14 +720,23 @@ hipError_t launch_model_inv(const Geometry& g, const int16_t* d_rec, uint8_t* d_
     return hipGetLastError();
 }
 
-uint32_t scan_block_count(uint32_t n) { return (n + kScanChunk - 1) / kScanChunk; }
+hipError_t launch_group_sums(const Geometry& g, const uint32_t* d_slice_len, uint64_t* d_group_off, hipStream_t stream) {
+    k_group_sums<<<dim3((g.n_slices + 255) / 256), dim3(256), 0, stream>>>(d_slice_len, g.n_slices, g.lane_shift, d_group_off);
+    return hipGetLastError();
+}
 
-hipError_t launch_scan_lengths(const uint32_t* d_slice_len, uint32_t n, uint64_t* d_offsets, uint64_t* d_total,
-                               uint64_t* d_block_sums, hipStream_t stream) {
-    const uint32_t nb = scan_block_count(n);
-    k_scan_local<<<dim3(nb), dim3(kScanThreads), 0, stream>>>(d_slice_len, n, d_offsets, d_block_sums);
-    k_scan_blocks<<<dim3(1), dim3(1024), 0, stream>>>(d_block_sums, nb, d_total);
-    k_scan_add<<<dim3(n / 256 + 1), dim3(256), 0, stream>>>(d_offsets, n, d_block_sums, d_total);
+hipError_t launch_scan_groups(const Geometry& g, uint64_t* d_group_off, uint64_t* d_total, hipStream_t stream) {
+    k_scan_groups<<<dim3(1), dim3(kScanThreads), 0, stream>>>(d_group_off, lane_groups(g), d_total);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_segments(const uint8_t* d_src, uint8_t* d_dst, const uint64_t* d_src_off, const uint64_t* d_dst_off,
+                                const uint64_t* d_len, uint32_t n_seg, uint64_t max_len, hipStream_t stream) {
+    if (n_seg == 0) return hipSuccess;
+    if (n_seg > 65535) return hipErrorInvalidValue;
+    const uint64_t pieces = (max_len / 4 + kSegPieceDwords - 1) / kSegPieceDwords;
+    const uint32_t gx = uint32_t(std::min<uint64_t>(std::max<uint64_t>(pieces, 1), 1024));
+    k_copy_segments<<<dim3(gx, n_seg), dim3(256), 0, stream>>>(d_src, d_dst, d_src_off, d_dst_off, d_len);
     return hipGetLastError();
 }
 

@@ -17,7 +17,6 @@
 //     taller slices keep a private 63 KB table (u64 per context) in HBM, fetched one context per sample -- or in
 //     LDS when a wavefront carries a single slice (LDSTAB).
 #include <algorithm>
-#include <cstdlib>
 
 #include "device_common.hpp"
 #include "kernels.hpp"
@@ -347,10 +346,12 @@ template <int NCH, bool ROWS, typename SYM, bool LDSTAB = false>
 __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const uint32_t lpw,
                                                       const SYM* __restrict__ sym, uint64_t* __restrict__ states,
                                                       uint8_t* __restrict__ scratch, uint32_t* __restrict__ slice_len,
-                                                      uint32_t* status) {
+                                                      uint64_t* __restrict__ group_sum, uint32_t* status) {
     __shared__ entry_t tab[128];
     __shared__ __attribute__((aligned(32))) uint8_t ring[kRingBytes * 64];
     __shared__ unsigned long long rowbank[ROWS ? 3 * 64 : 1];
+    __shared__ unsigned long long wave_bytes;  // sum of this wavefront's stream lengths (see k_scan_groups)
+    if (threadIdx.x == 0) wave_bytes = 0;
     clear_lds_states<LDSTAB>();
     load_table(tab);
     const uint32_t id = blockIdx.x * lpw + threadIdx.x;
@@ -445,6 +446,13 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
         e.pos = e.cap;
     }
     slice_len[id] = uint32_t(e.pos);
+    // When a wavefront holds exactly one lane group (the normal case) it leaves the group's byte count behind: the
+    // global scan then runs over one value per group instead of one per slice.  The lanes have reconverged here; LDS
+    // operations of one wavefront execute in order, so lane 0 reads the finished sum.
+    if (group_sum) {
+        atomicAdd(&wave_bytes, (unsigned long long)uint32_t(e.pos));
+        if (threadIdx.x == 0) group_sum[blockIdx.x] = wave_bytes;
+    }
 }
 
 // ================================================ DECODER ========================================================
@@ -815,21 +823,6 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
     }
 }
 
-// Slices per wavefront = width of a lane group (Geometry::lane_shift): a wavefront owns whole rows of the lane-order
-// arrays.  LLCOMP_MI_LPW can force fewer active lanes (tests).
-uint32_t lanes_per_wave(const Geometry& g) {
-    const uint32_t gw = 1u << g.lane_shift;
-    if (const char* e = std::getenv("LLCOMP_MI_LPW")) {  // rounded down to a power of two: a wavefront never straddles groups
-        const long v = std::strtol(e, nullptr, 10);
-        if (v >= 1) {
-            uint32_t p = 1;
-            while (p * 2 <= uint32_t(v) && p * 2 <= gw) p *= 2;
-            return p;
-        }
-    }
-    return gw;
-}
-
 }  // namespace
 
 // (channels per slice, 1-row slices, state table in LDS) -> template instance
@@ -850,18 +843,10 @@ uint32_t lanes_per_wave(const Geometry& g) {
         default: return hipErrorInvalidValue;                                                               \
     }
 
-// LLCOMP_MI_NOROWS=1 (tests / debugging) sends 1-row slices through the general table-per-slice kernels as well.
-bool rows_mode(const Geometry& g) {
-    if (g.tile_h != 1) return false;
-    const char* e = std::getenv("LLCOMP_MI_NOROWS");
-    return !(e && e[0] == '1');
-}
-// One slice per wavefront: the table of that slice lives in LDS.  LLCOMP_MI_NOLDSTAB=1 (tests) keeps it in HBM.
-bool states_in_lds(const Geometry& g) {
-    if (rows_mode(g) || lanes_per_wave(g) != 1) return false;
-    const char* e = std::getenv("LLCOMP_MI_NOLDSTAB");
-    return !(e && e[0] == '1');
-}
+// Kernel family of a geometry (fixed in make_geometry, geometry.hpp): 1-row slices keep their three contexts in LDS,
+// a launch with one slice per wavefront keeps that slice's whole table in LDS, everything else needs tables in HBM.
+bool rows_mode(const Geometry& g) { return (g.flags & kGeoRows) != 0; }
+static bool states_in_lds(const Geometry& g) { return (g.flags & kGeoLdsTable) != 0; }
 bool slices_need_state_tables(const Geometry& g) { return !rows_mode(g) && !states_in_lds(g); }
 
 constexpr size_t kLdsTableBytes = size_t(kContexts) * 8;
@@ -871,13 +856,16 @@ hipError_t allow_big_lds(K kernel) {  // more than the default 64 KB of LDS per 
                                int(kLdsTableBytes));
 }
 
+bool encoder_writes_group_sums(const Geometry& g) { return g.lpw == (1u << g.lane_shift); }
+
 hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* d_states, uint8_t* d_scratch,
-                                uint32_t* d_slice_len, uint32_t* d_status, hipStream_t stream) {
-    const uint32_t lpw = lanes_per_wave(g);
+                                uint32_t* d_slice_len, uint64_t* d_group_off, uint32_t* d_status, hipStream_t stream) {
+    const uint32_t lpw = g.lpw;
     const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
+    uint64_t* const d_group_sum = encoder_writes_group_sums(g) ? d_group_off : nullptr;
     if (model_is_fused(g)) {  // planar 1-row slices: 16-bit symbols, always the ROWS kernel
         k_encode_slices<1, true, uint16_t><<<dim3(blocks), dim3(64), 0, stream>>>(
-            g, lpw, static_cast<const uint16_t*>(d_sym), d_states, d_scratch, d_slice_len, d_status);
+            g, lpw, static_cast<const uint16_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status);
         return hipGetLastError();
     }
     const bool lds = states_in_lds(g);
@@ -888,17 +876,16 @@ hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* 
             if (e != hipSuccess) return e;
         }
         kernel<<<dim3(blocks), dim3(64), T ? kLdsTableBytes : 0, stream>>>(
-            g, lpw, static_cast<const uint32_t*>(d_sym), d_states, d_scratch, d_slice_len, d_status);
+            g, lpw, static_cast<const uint32_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status);
     });
     return hipGetLastError();
 }
 
 hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_units, const uint32_t* d_slice_len,
                                 uint64_t* d_states, int16_t* d_rec, uint32_t* d_status, hipStream_t stream) {
-    const uint32_t lpw = lanes_per_wave(g);
+    const uint32_t lpw = g.lpw;
     const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
-    const char* fr = std::getenv("LLCOMP_MI_FORCE_REPLAY");  // tests: exercise the decoder's rollback + checked replay
-    const uint32_t arg = lpw | ((fr && fr[0] == '1') ? 0x100u : 0u);
+    const uint32_t arg = lpw | ((g.flags & kGeoForceReplay) ? 0x100u : 0u);  // tests: rollback + checked replay everywhere
     const bool lds = states_in_lds(g);
     LLMI_DISPATCH_SLICE(g.nch, rows_mode(g), lds, {
         auto kernel = k_decode_slices<C, R, T>;

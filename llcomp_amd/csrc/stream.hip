@@ -1,0 +1,268 @@
+// stream.hip -- streaming pipeline of libllcomp_mi.so (llcomp_mi_stream_*): many frames of one shape flow
+// host -> GPU -> host with several jobs in flight (BASELINE config 5).  The reference codes one image in
+// RAM per call (llcompc.cpp:25-41, llcompd.cpp:17-31); this is the same operation as a pipeline.
+//
+// `depth` slots, each a HostLane (codec object for one frame, private HIP stream, frame + container in HBM in wire
+// layout) plus a pinned output buffer.  A job is one frame:
+//   encode  H2D frame -> kernels -> D2H {payload bytes, status} (16 B, event e1) -> D2H container of the EXACT size (event e2)
+//   decode  H2D container -> kernels -> D2H frame + status (event e2)
+// The size of a container is known on the GPU only.  Nobody waits for it at submit time: the 16-byte mailbox copy is
+// queued behind the kernels and whoever enters the library next (submit, wait or poll) looks at the events of the
+// jobs in flight ("pump") and queues the container copies whose size has arrived.  With two or more slots busy the
+// copies of one job overlap the kernels of the others in both PCIe directions.
+// Back-pressure: submit returns LLCOMP_MI_BUSY when every slot is occupied (in flight, or finished and not yet
+// released); the caller takes a result (llcomp_mi_stream_wait), uses it and releases the slot.
+// Results come back in submission order.  One stream object is driven by one thread at a time (calls are serialised by
+// a mutex); use several objects for several producer threads.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/llcomp_mi.h"
+#include "codec_internal.hpp"
+
+using namespace llcomp_mi;
+
+namespace {
+enum SlotState : int { kFree = 0, kEncSizing, kCopying, kFailed, kHeld };
+struct Slot {
+    HostLane* lane = nullptr;
+    uint8_t* h_out = nullptr;  // pinned: a container (encode) or a frame (decode)
+    hipEvent_t e1 = nullptr, e2 = nullptr;
+    SlotState state = kFree;
+    uint32_t kind = 0;
+    uint64_t tag = 0;
+    uint64_t out_len = 0;
+    int status = LLCOMP_MI_OK;
+};
+}  // namespace
+
+struct llcomp_mi_stream {
+    std::mutex mu;
+    int device = 0;
+    uint32_t w = 0, h = 0, c = 0, tile_w = 0, tile_h = 0, planar = 0;
+    uint64_t raw = 0, out_cap = 0;
+    std::vector<Slot> slots;
+    std::deque<uint32_t> fifo;  // slots in submission order that have not been handed out by wait() yet
+    uint64_t jobs_done = 0;
+};
+
+namespace {
+
+// encode job whose size mailbox has arrived: queue the container copy (exact size) or fail the job
+int start_container_copy(llcomp_mi_stream* s, Slot& sl) {
+    HostLane* l = sl.lane;
+    const int rc = status_from_bits(uint32_t(l->h_meta[1]));
+    if (rc) {
+        sl.status = rc;
+        sl.state = kFailed;
+        return LLCOMP_MI_OK;
+    }
+    sl.out_len = uint64_t(l->head_bytes) + l->h_meta[0];
+    if (sl.out_len > s->out_cap) {  // cannot happen (payload capacity <= out_cap), but never write past a buffer
+        sl.status = LLCOMP_MI_OUTPUT_OVERFLOW;
+        sl.state = kFailed;
+        return LLCOMP_MI_OK;
+    }
+    LLMI_HIP_TRY(hipMemcpyAsync(sl.h_out, l->d_container, sl.out_len, hipMemcpyDeviceToHost, l->stream));
+    LLMI_HIP_TRY(hipEventRecord(sl.e2, l->stream));
+    sl.state = kCopying;
+    return LLCOMP_MI_OK;
+}
+
+int pump(llcomp_mi_stream* s) {
+    for (uint32_t i : s->fifo) {
+        Slot& sl = s->slots[i];
+        if (sl.state != kEncSizing) continue;
+        const hipError_t q = hipEventQuery(sl.e1);
+        if (q == hipErrorNotReady) continue;
+        if (q != hipSuccess) return LLCOMP_MI_HIP_ERROR;
+        if (int rc = start_container_copy(s, sl)) return rc;
+    }
+    return LLCOMP_MI_OK;
+}
+
+int free_slot(llcomp_mi_stream* s) {
+    for (size_t i = 0; i < s->slots.size(); ++i)
+        if (s->slots[i].state == kFree) return int(i);
+    return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int llcomp_mi_stream_create(llcomp_mi_stream** out, int32_t device, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w,
+                            uint32_t tile_h, uint32_t planar, uint32_t depth) {
+    if (!out) return LLCOMP_MI_BAD_ARGS;
+    *out = nullptr;
+    if (depth < 1 || depth > 16) return LLCOMP_MI_BAD_ARGS;
+    if (int rc = check_shape(w, h, c, false)) return rc;
+    int dev = 0;
+    if (int rc = resolve_device(device, &dev)) return rc;
+    llcomp_mi_stream* s = new (std::nothrow) llcomp_mi_stream;
+    if (!s) return LLCOMP_MI_NOMEM;
+    s->device = dev;
+    s->w = w; s->h = h; s->c = c;
+    s->tile_w = tile_w == 0 || tile_w > w ? w : tile_w;
+    s->tile_h = tile_h == 0 || tile_h > h ? h : tile_h;
+    s->planar = planar ? 1 : 0;
+    s->raw = uint64_t(w) * h * c;
+    s->slots.resize(depth);
+    DeviceGuard guard(dev);
+    int rc = guard.ok ? LLCOMP_MI_OK : LLCOMP_MI_HIP_ERROR;
+    for (uint32_t i = 0; i < depth && !rc; ++i) {
+        Slot& sl = s->slots[i];
+        // room for 2x raw (noise needs ~1.25x); a frame that needs more fails with OUTPUT_OVERFLOW and can go through
+        // llcomp_mi_encode, which retries with the proven worst case of 13 bytes per sample
+        const uint64_t cap = 2 * s->raw + 64ull * llcomp_mi_slice_count(w, h, c, s->tile_w, s->tile_h, s->planar) + 4096;
+        rc = lane_create(&sl.lane, dev, w, h, c, s->tile_w, s->tile_h, s->planar, false, cap);
+        if (rc) break;
+        s->out_cap = std::max<uint64_t>(s->raw, sl.lane->head_bytes + sl.lane->payload_cap);
+        if (hipHostMalloc(reinterpret_cast<void**>(&sl.h_out), s->out_cap, hipHostMallocDefault) != hipSuccess) rc = LLCOMP_MI_NOMEM;
+        else if (hipEventCreateWithFlags(&sl.e1, hipEventDisableTiming) != hipSuccess ||
+                 hipEventCreateWithFlags(&sl.e2, hipEventDisableTiming) != hipSuccess)
+            rc = LLCOMP_MI_HIP_ERROR;
+    }
+    if (rc) {
+        llcomp_mi_stream_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return LLCOMP_MI_OK;
+}
+
+void llcomp_mi_stream_destroy(llcomp_mi_stream* s) {
+    if (!s) return;
+    DeviceGuard guard(s->device);
+    for (Slot& sl : s->slots) {
+        if (sl.lane && sl.lane->stream) (void)hipStreamSynchronize(sl.lane->stream);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.e1) (void)hipEventDestroy(sl.e1);
+        if (sl.e2) (void)hipEventDestroy(sl.e2);
+        lane_destroy(sl.lane);
+    }
+    delete s;
+}
+
+uint64_t llcomp_mi_stream_container_capacity(const llcomp_mi_stream* s) { return s ? s->out_cap : 0; }
+
+int llcomp_mi_stream_submit_encode(llcomp_mi_stream* s, const uint8_t* px, uint64_t tag) {
+    if (!s || !px) return LLCOMP_MI_BAD_ARGS;
+    std::lock_guard<std::mutex> lock(s->mu);
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
+    if (int rc = pump(s)) return rc;
+    const int i = free_slot(s);
+    if (i < 0) return LLCOMP_MI_BUSY;
+    Slot& sl = s->slots[size_t(i)];
+    HostLane* l = sl.lane;
+    LLMI_HIP_TRY(hipMemcpyAsync(l->d_px, px, s->raw, hipMemcpyHostToDevice, l->stream));
+    if (int rc = lane_enqueue_encode(l)) return rc;
+    LLMI_HIP_TRY(hipEventRecord(sl.e1, l->stream));
+    sl.state = kEncSizing;
+    sl.kind = LLCOMP_MI_JOB_ENCODE;
+    sl.tag = tag;
+    sl.status = LLCOMP_MI_OK;
+    sl.out_len = 0;
+    s->fifo.push_back(uint32_t(i));
+    return LLCOMP_MI_OK;
+}
+
+int llcomp_mi_stream_submit_decode(llcomp_mi_stream* s, const uint8_t* data, size_t len, uint64_t tag) {
+    if (!s || !data) return LLCOMP_MI_BAD_ARGS;
+    llcomp_mi_info info;
+    if (int rc = llcomp_mi_probe(data, len, &info)) return rc;
+    if (info.format != LLCOMP_MI_FORMAT_SLICED || info.width != s->w || info.height != s->h || info.channels != s->c ||
+        info.tile_w != s->tile_w || info.tile_h != s->tile_h || info.planar != s->planar)
+        return LLCOMP_MI_BAD_ARGS;  // a stream object codes ONE geometry
+    std::lock_guard<std::mutex> lock(s->mu);
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
+    if (int rc = pump(s)) return rc;
+    const int i = free_slot(s);
+    if (i < 0) return LLCOMP_MI_BUSY;
+    Slot& sl = s->slots[size_t(i)];
+    HostLane* l = sl.lane;
+    // a container longer than the slot's buffer carries bytes no slice can use (the table is bounds-checked on the GPU)
+    const uint64_t n = std::min<uint64_t>(len, uint64_t(l->head_bytes) + l->payload_cap);
+    LLMI_HIP_TRY(hipMemcpyAsync(l->d_container, data, n, hipMemcpyHostToDevice, l->stream));
+    if (int rc = lane_enqueue_decode(l, n)) return rc;
+    LLMI_HIP_TRY(hipMemcpyAsync(sl.h_out, l->d_px, s->raw, hipMemcpyDeviceToHost, l->stream));
+    LLMI_HIP_TRY(hipEventRecord(sl.e2, l->stream));
+    sl.state = kCopying;
+    sl.kind = LLCOMP_MI_JOB_DECODE;
+    sl.tag = tag;
+    sl.status = LLCOMP_MI_OK;
+    sl.out_len = s->raw;
+    s->fifo.push_back(uint32_t(i));
+    return LLCOMP_MI_OK;
+}
+
+int llcomp_mi_stream_pending(llcomp_mi_stream* s) {
+    if (!s) return 0;
+    std::lock_guard<std::mutex> lock(s->mu);
+    return int(s->fifo.size());
+}
+
+int llcomp_mi_stream_poll(llcomp_mi_stream* s) {
+    if (!s) return LLCOMP_MI_BAD_ARGS;
+    std::lock_guard<std::mutex> lock(s->mu);
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
+    if (int rc = pump(s)) return rc;
+    if (s->fifo.empty()) return LLCOMP_MI_OK;
+    Slot& sl = s->slots[s->fifo.front()];
+    if (sl.state == kFailed) return LLCOMP_MI_OK;
+    if (sl.state == kCopying) {
+        const hipError_t q = hipEventQuery(sl.e2);
+        if (q == hipSuccess) return LLCOMP_MI_OK;
+        if (q != hipErrorNotReady) return LLCOMP_MI_HIP_ERROR;
+    }
+    return LLCOMP_MI_BUSY;  // the oldest job is still in flight
+}
+
+int llcomp_mi_stream_wait(llcomp_mi_stream* s, llcomp_mi_stream_result* r) {
+    if (!s || !r) return LLCOMP_MI_BAD_ARGS;
+    std::memset(r, 0, sizeof(*r));
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (s->fifo.empty()) return LLCOMP_MI_BAD_ARGS;  // nothing was submitted
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
+    if (int rc = pump(s)) return rc;
+    const uint32_t i = s->fifo.front();
+    Slot& sl = s->slots[i];
+    if (sl.state == kEncSizing) {
+        LLMI_HIP_TRY(hipEventSynchronize(sl.e1));
+        if (int rc = pump(s)) return rc;  // queues this job's container copy -- and any other whose size has arrived
+    }
+    if (sl.state == kCopying) {
+        LLMI_HIP_TRY(hipEventSynchronize(sl.e2));
+        if (sl.kind == LLCOMP_MI_JOB_DECODE) sl.status = status_from_bits(uint32_t(sl.lane->h_meta[1]));
+    }
+    s->fifo.pop_front();
+    sl.state = kHeld;
+    ++s->jobs_done;
+    r->slot = i;
+    r->kind = sl.kind;
+    r->status = sl.status;
+    r->tag = sl.tag;
+    r->data = sl.status == LLCOMP_MI_OK ? sl.h_out : nullptr;
+    r->len = sl.status == LLCOMP_MI_OK ? sl.out_len : 0;
+    return LLCOMP_MI_OK;
+}
+
+int llcomp_mi_stream_release(llcomp_mi_stream* s, uint32_t slot) {
+    if (!s) return LLCOMP_MI_BAD_ARGS;
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (slot >= s->slots.size() || s->slots[slot].state != kHeld) return LLCOMP_MI_BAD_ARGS;
+    s->slots[slot].state = kFree;
+    return LLCOMP_MI_OK;
+}
+
+}  // extern "C"

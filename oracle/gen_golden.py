@@ -43,6 +43,8 @@ def fnv(b):
 
 
 def special(name, w, h, c):
+    if name.startswith("g3@"):  # std::mt19937 noise with another seed
+        return GENERATORS["g3"](w, h, c, seed=int(name[3:]))
     if name == "const0":
         return np.zeros((h, w, c), np.uint8)
     if name == "const255":
@@ -90,6 +92,10 @@ def slice_payloads(ref):
         ("g3", 256, 128, 3, 64, 64, True), ("g3", 256, 128, 3, 64, 64, False), ("g2", 1920, 1080, 3, 1920, 1, False), ("g3", 1920, 1080, 3, 1920, 1, False),
         ("g3", 1920, 1080, 3, 64, 64, True), ("mid", 1920, 1080, 3, 128, 128, True), ("g2", 3840, 2160, 3, 64, 64, True), ("g3", 3840, 2160, 3, 64, 64, True),
         ("mid", 3840, 2160, 3, 64, 64, True), ("g3", 3840, 2160, 3, 256, 256, False),
+        # the benchmarked slicing (bench.py default: per-channel planes, 480x1) at full 4K size, and two frames of BASELINE
+        # config 5's batch (frame i = std::mt19937(1234 + i)): frame 0 is "g3" itself, frame 63 = seed 1297
+        ("g3", 3840, 2160, 3, 480, 1, True), ("g2", 3840, 2160, 3, 480, 1, True), ("mid", 3840, 2160, 3, 480, 1, True),
+        ("nat", 3840, 2160, 3, 64, 64, True), ("g3@1297", 3840, 2160, 3, 480, 1, True),
     ]
     out = []
     for name, w, h, c, tw, th, planar in cases:

@@ -50,6 +50,8 @@ def make_image(gen, w, h, c):
         return np.zeros((h, w, c), np.uint8)
     if gen == "const255":
         return np.full((h, w, c), 255, np.uint8)
+    if gen.startswith("g3@"):  # std::mt19937 noise with another seed (BASELINE config 5: frame i = seed 1234 + i)
+        return orc_mod.GENERATORS["g3"](w, h, c, seed=int(gen[3:]))
     return orc_mod.GENERATORS[gen](w, h, c)
 
 

@@ -32,7 +32,7 @@ def test_header_symbols_all_exported(mi):
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in llcomp_mi.h but not exported by libllcomp_mi.so"
-    assert lib.llcomp_mi_abi_version() == 1
+    assert lib.llcomp_mi_abi_version() == 2
 
 
 def test_struct_layouts_match_header(mi):
@@ -40,6 +40,7 @@ def test_struct_layouts_match_header(mi):
 
     assert C.sizeof(_lib.Opts) == 24
     assert C.sizeof(_lib.Info) == 48
+    assert C.sizeof(_lib.StreamResult) == 40
 
 
 def test_no_cpu_fallback(mi):

@@ -23,6 +23,18 @@ def mi():
     return llcomp_amd
 
 
+@pytest.fixture
+def set_hook(mi, monkeypatch):
+    """The library reads its LLCOMP_MI_* test hooks once per process; a test that changes one says so (reload_tuning)."""
+    def _set(name, value):
+        monkeypatch.setenv(name, value)
+        mi.reload_tuning()
+
+    yield _set
+    monkeypatch.undo()
+    mi.reload_tuning()
+
+
 # ---- P0: legacy whole-image format, one serial lane on the GPU --------------------------------------------------
 LEGACY_CASES = [v for v in KAT if v["w"] * v["h"] * v["c"] <= 1920 * 1080 * 3 and not (v["gen"] == "g3" and v["w"] >= 1920)]
 
@@ -252,9 +264,9 @@ def test_c4_8k_roundtrip_and_band_merge_property(mi, orc):
 
 
 @pytest.mark.parametrize("lpw", ["64", "7", "1"])
-def test_lanes_per_wave_does_not_change_bytes(mi, orc, lpw, monkeypatch):
+def test_lanes_per_wave_does_not_change_bytes(mi, orc, lpw, set_hook):
     """The launcher spreads slices over wavefronts (1..64 slices per wave); the bytes must not depend on it."""
-    monkeypatch.setenv("LLCOMP_MI_LPW", lpw)
+    set_hook("LLCOMP_MI_LPW", lpw)
     img = make_image("g3", 200, 150, 3)
     img[:, 100:] = make_image("mid", 100, 150, 3)
     for planar in (False, True):
@@ -320,7 +332,7 @@ def test_cli_roundtrip_matches_reference_behaviour(mi, orc, tmp_path):
     assert r.returncode == 1 and "Invalid magic number" in r.stderr
 
 
-def test_one_row_slices_through_both_kernel_families(mi, orc, monkeypatch):
+def test_one_row_slices_through_both_kernel_families(mi, orc, set_hook):
     """tile_h == 1 normally runs the register-resident kernels (+ the fused 16-bit-symbol stage A when planar);
     LLCOMP_MI_NOROWS=1 forces the same slicing through the general table-in-HBM kernels.  Same bytes either way."""
     img = make_image("g3", 300, 9, 3)
@@ -328,13 +340,13 @@ def test_one_row_slices_through_both_kernel_families(mi, orc, monkeypatch):
     for planar in (False, True):
         want = orc.compress_sliced(img, 70, 1, planar)
         for norows in ("0", "1"):
-            monkeypatch.setenv("LLCOMP_MI_NOROWS", norows)
+            set_hook("LLCOMP_MI_NOROWS", norows)
             s = mi.compress_image(img, 300, 9, 3, format=mi.FORMAT_SLICED, tile_w=70, tile_h=1, planar=planar)
             assert s == want
             assert np.array_equal(mi.decompress_image(s).pixels, img)
 
 
-def test_state_table_in_lds_or_hbm_same_bytes(mi, orc, monkeypatch):
+def test_state_table_in_lds_or_hbm_same_bytes(mi, orc, set_hook):
     """With one slice per wavefront (a lone legacy stream, a few big tiles) the 63 KB state table of the slice lives in
     LDS; LLCOMP_MI_NOLDSTAB=1 keeps it in HBM like every multi-lane launch.  Same bytes either way, all channel counts."""
     for c in (1, 2, 3, 4):
@@ -343,7 +355,7 @@ def test_state_table_in_lds_or_hbm_same_bytes(mi, orc, monkeypatch):
         legacy = orc.compress_image(img)
         tiled = orc.compress_sliced(img, 50, 21, False)
         for off in ("0", "1"):
-            monkeypatch.setenv("LLCOMP_MI_NOLDSTAB", off)
+            set_hook("LLCOMP_MI_NOLDSTAB", off)
             s = mi.compress_image(img, 97, 41, c)
             assert s == legacy
             assert np.array_equal(mi.decompress_image(s).pixels, img)
@@ -385,7 +397,7 @@ def test_host_calls_are_reentrant(mi, orc):
     assert not errors, errors
 
 
-def test_decoder_rollback_and_checked_replay(mi, orc, monkeypatch):
+def test_decoder_rollback_and_checked_replay(mi, orc, set_hook):
     """The decoder's fast path never checks its input window; a sample that outruns the window is rolled back and
     replayed with per-step refills.  That almost never happens on real data, so LLCOMP_MI_FORCE_REPLAY=1 sends EVERY
     sample through rollback + replay: the pixels must not change.  Also a hostile-statistics image (long constant runs,
@@ -397,7 +409,7 @@ def test_decoder_rollback_and_checked_replay(mi, orc, monkeypatch):
         for tw, th, planar in ((w, 1, True), (50, 1, False), (64, 8, True)):
             want = orc.compress_sliced(img, tw, th, planar)
             for force in ("0", "1"):
-                monkeypatch.setenv("LLCOMP_MI_FORCE_REPLAY", force)
+                set_hook("LLCOMP_MI_FORCE_REPLAY", force)
                 assert mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar) == want
                 assert np.array_equal(mi.decompress_image(want).pixels, img)
 
@@ -444,9 +456,9 @@ def test_batch_codec_fused_rows_all_channel_counts(mi, orc, c):
 
 
 @pytest.mark.parametrize("shift", ["0", "2", "5"])
-def test_lane_group_width_does_not_change_bytes(mi, orc, shift, monkeypatch):
+def test_lane_group_width_does_not_change_bytes(mi, orc, shift, set_hook):
     """Lane groups narrower than 64 (few slices, or forced here) change every HBM layout but not a single byte."""
-    monkeypatch.setenv("LLCOMP_MI_LANE_SHIFT", shift)
+    set_hook("LLCOMP_MI_LANE_SHIFT", shift)
     img = make_image("g3", 190, 21, 3)
     img[:, 90:] = make_image("mid", 100, 21, 3)
     for tw, th, planar in ((45, 1, True), (45, 1, False), (32, 8, True), (190, 21, False)):

@@ -1,0 +1,187 @@
+"""BASELINE config 5 through the product's streaming pipeline (llcomp_mi_stream_*, C ABI): 64 distinct 4K noise frames
+host -> GPU -> host (container) -> GPU -> host, several jobs in flight, back-pressure, every frame bit-exact; plus
+the caller-provided / pinned-buffer host calls.  Reference analogue: one image in RAM per call, llcompc.cpp:25-41,
+llcompd.cpp:17-31."""
+import time
+
+import numpy as np
+import pytest
+from conftest import fnv_hex, load_golden, make_image
+
+pytestmark = pytest.mark.gpu
+
+SLC = load_golden("slice_payloads.json")["vectors"]
+
+
+@pytest.fixture(scope="module")
+def mi():
+    import llcomp_amd
+
+    assert llcomp_amd.device_count() >= 1, "GPU tests need a HIP device"
+    return llcomp_amd
+
+
+def golden(gen, w, tw, th, planar):
+    return [v for v in SLC if v["gen"] == gen and v["w"] == w and v["tile_w"] == tw and v["tile_h"] == th and v["planar"] == planar][0]
+
+
+def run_stream(mi, frames, tw, th, planar, depth, max_encodes_in_flight, check=None):
+    """Streams every frame through encode and straight back through decode.  An encode result (pinned container) is
+    handed to submit_decode as it is and released only when that decode has come back.  Returns per-frame container
+    lengths and the completion time of every frame."""
+    n, (h, w, c) = len(frames), frames[0].shape
+    st = mi.Stream(w, h, c, tw, th, planar, depth=depth)
+    lens, done_at, busy_seen = [0] * n, [0.0] * n, 0
+    enc_held = {}      # frame index -> encode job whose container a decode job is still reading
+    to_decode = []     # encode jobs that finished but found no free slot yet
+    next_frame, finished, enc_in_flight = 0, 0, 0
+    t0 = time.perf_counter()
+    while finished < n:
+        progressed = False
+        while to_decode:  # containers first: they free slots
+            job = to_decode[0]
+            if not st.submit_decode(job.data, tag=job.tag):
+                busy_seen += 1
+                break
+            enc_held[job.tag] = job
+            to_decode.pop(0)
+            progressed = True
+        while next_frame < n and enc_in_flight < max_encodes_in_flight and not to_decode:
+            if not st.submit_encode(frames[next_frame], tag=next_frame):
+                busy_seen += 1
+                break
+            next_frame += 1
+            enc_in_flight += 1
+            progressed = True
+        if st.pending() and (not progressed or st.ready()):
+            job = st.wait()
+            assert job.status == mi.OK, f"frame {job.tag}: status {job.status}"
+            if job.kind == mi.JOB_ENCODE:
+                enc_in_flight -= 1
+                lens[job.tag] = job.data.size
+                if check:
+                    check(job.tag, job.data)
+                to_decode.append(job)
+            else:
+                assert np.array_equal(job.data, frames[job.tag]), f"frame {job.tag} is not bit-exact after the round trip"
+                done_at[job.tag] = time.perf_counter() - t0
+                st.release(job)
+                st.release(enc_held.pop(job.tag))
+                finished += 1
+    assert st.pending() == 0 and not enc_held
+    st.close()
+    return lens, done_at, busy_seen
+
+
+def test_stream_small_frames_match_oracle(mi, orc):
+    """Every container the pipeline returns == the oracle's container of that frame (several slicings, ragged shapes,
+    more frames than slots so that slots are reused and back-pressure is exercised)."""
+    for (w, h, c, tw, th, planar) in ((200, 37, 3, 50, 1, True), (131, 40, 4, 32, 16, True), (97, 21, 1, 97, 1, False), (64, 64, 3, 64, 64, False)):
+        frames = [np.ascontiguousarray(np.roll(make_image(("g3", "mid", "g1", "checker")[i % 4], w, h, c), 3 * i, axis=1)) for i in range(11)]
+        want = [orc.compress_sliced(f, tw, th, planar) for f in frames]
+
+        def check(i, data):
+            assert data.tobytes() == want[i], f"frame {i}: container differs from the oracle's"
+
+        lens, _, busy = run_stream(mi, frames, tw, th, planar, depth=3, max_encodes_in_flight=2, check=check)
+        assert lens == [len(x) for x in want]
+        assert busy > 0, "11 frames through 3 slots must have hit back-pressure"
+
+
+def test_stream_api_errors_and_backpressure(mi):
+    w, h, c = 64, 16, 3
+    st = mi.Stream(w, h, c, 16, 1, True, depth=2)
+    a = np.zeros((h, w, c), np.uint8)
+    assert st.submit_encode(a, 1) and st.submit_encode(a, 2)
+    assert st.submit_encode(a, 3) is False          # both slots occupied: BUSY, not an exception, nothing queued
+    assert st.pending() == 2
+    j1 = st.wait()
+    assert st.submit_encode(a, 3) is False          # finished but not released: still occupied
+    j2 = st.wait()
+    assert (j1.tag, j2.tag) == (1, 2) and j1.data.tobytes() == j2.data.tobytes()
+    with pytest.raises(mi.LlcompError):              # nothing pending
+        st.wait()
+    other = mi.compress_image(np.zeros((h, w + 1, c), np.uint8), w + 1, h, c, format=mi.FORMAT_SLICED, tile_w=16, tile_h=1, planar=True)
+    with pytest.raises(mi.LlcompError) as e:         # a stream object codes one geometry
+        st.submit_decode(np.frombuffer(other, np.uint8))
+    assert e.value.status == mi.BAD_ARGS
+    st.release(j1)
+    with pytest.raises(mi.LlcompError):              # released twice
+        st.release(j1)
+    bad = j2.data.copy()
+    bad[24 + 4 * int.from_bytes(bad[20:24].tobytes(), "little"):] = 0xFF   # payload of all ones: runs of 1 bins -> "Invalid exponent" or garbage, never a fault
+    assert st.submit_decode(bad, 9)
+    j3 = st.wait()
+    assert j3.tag == 9 and j3.status in (mi.OK, mi.BAD_EXPONENT)
+    st.release(j2)
+    st.release(j3)
+    st.close()
+
+
+def test_host_calls_with_caller_provided_pinned_buffers(mi, orc):
+    """llcomp_mi_encode_into / llcomp_mi_decode_into with pinned buffers from llcomp_mi_host_alloc: same bytes as the
+    allocating calls; too-small buffers are reported with the size it takes and are not written."""
+    img = make_image("mid", 300, 70, 3)
+    src = mi.PinnedBuffer(img.size)
+    src.array[:] = img.reshape(-1)
+    out = mi.PinnedBuffer(2 * img.size + 65536)
+    for kw, want in ((dict(), orc.compress_image(img)),
+                     (dict(format=mi.FORMAT_SLICED, tile_w=64, tile_h=1, planar=True), orc.compress_sliced(img, 64, 1, True)),
+                     (dict(format=mi.FORMAT_SLICED, tile_w=64, tile_h=32, planar=False), orc.compress_sliced(img, 64, 32, False))):
+        n = mi.compress_image_into(src.array, 300, 70, 3, out.array, **kw)
+        assert out.array[:n].tobytes() == want
+        back = mi.PinnedBuffer(img.size)
+        back.array[:] = 0xAA
+        assert mi.decompress_image_into(out.array[:n], back.array) == (300, 70, 3)
+        assert np.array_equal(back.array.reshape(img.shape), img)
+        small = np.full(len(want) - 1, 0x55, np.uint8)
+        with pytest.raises(mi.LlcompError) as e:
+            mi.compress_image_into(src.array, 300, 70, 3, small, **kw)
+        assert e.value.status == mi.OUTPUT_OVERFLOW and e.value.needed == len(want) and bool((small == 0x55).all())
+        small = np.full(img.size - 1, 0x55, np.uint8)
+        with pytest.raises(mi.LlcompError) as e:
+            mi.decompress_image_into(out.array[:n], small)
+        assert e.value.status == mi.OUTPUT_OVERFLOW and e.value.shape == (300, 70, 3) and bool((small == 0x55).all())
+        back.close()
+    src.close()
+    out.close()
+
+
+@pytest.mark.parametrize("gen", ["g3", "g2", "mid"])
+def test_c3_4k_bench_slicing_golden(mi, orc, gen):
+    """The slicing bench.py measures (per-channel planes, 480x1) at full 4K size: container bytes pinned to the real
+    reference's per-slice streams (tests/golden/slice_payloads.json), then decoded back."""
+    v = golden(gen, 3840, 480, 1, True)
+    img = make_image(gen, 3840, 2160, 3)
+    s = mi.compress_image(img, 3840, 2160, 3, format=mi.FORMAT_SLICED, tile_w=480, tile_h=1, planar=True)
+    assert len(s) == v["container_len"] and fnv_hex(orc, s) == v["container_fnv1a64"]
+    assert np.array_equal(mi.decompress_image(s).pixels, img)
+
+
+def test_c5_stream_64_frames_4k(mi, orc):
+    """BASELINE config 5: 64 distinct 4K RGB8 noise frames (std::mt19937 seeds 1234+i) streamed host -> GPU -> host ->
+    GPU -> host through llcomp_mi_stream_*.  Every frame bit-exact; frames 0 and 63 pinned to golden container hashes made
+    with the real reference; steady state (first 4 frames excluded) and compression ratio reported."""
+    from llcomp_amd import synth
+
+    W, H, C, N = 3840, 2160, 3, 64
+    pinned = mi.PinnedBuffer(N * W * H * C)  # source frames in pinned memory: H2D is plain DMA
+    frames = []
+    for i in range(N):
+        f = pinned.array[i * W * H * C:(i + 1) * W * H * C].reshape(H, W, C)
+        f[:] = synth.gen_g3(W, H, C, seed=1234 + i)
+        frames.append(f)
+    pins = {0: golden("g3", 3840, 480, 1, True), 63: golden("g3@1297", 3840, 480, 1, True)}
+
+    def check(i, data):
+        if i in pins:
+            assert data.size == pins[i]["container_len"] and fnv_hex(orc, data.tobytes()) == pins[i]["container_fnv1a64"], f"frame {i}: golden mismatch"
+
+    lens, done_at, _ = run_stream(mi, frames, 480, 1, True, depth=6, max_encodes_in_flight=3, check=check)
+    steady = (N - 4) * W * H / 1e6 / (done_at[-1] - done_at[3])
+    ratio = N * W * H * C / sum(lens)
+    print(f"\nC5 stream: {N} frames, steady state {steady:.0f} MPix/s end to end over PCIe (first 4 frames excluded), ratio {ratio:.4f} "
+          f"(reference whole-image stream of frame 0: 0.8026)")
+    assert 0.76 < ratio < 0.79
+    assert steady > 500  # one pageable 4K frame through the round-1 host calls ran at 640 MPix/s; a pipeline must not be slower
+    pinned.close()

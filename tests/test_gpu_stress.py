@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Randomised HIP-vs-oracle parity over shapes, contents, slicings and kernel-family overrides.  Collected by pytest
+(-m gpu) with a bounded number of cases; a longer run by hand on a GPU box:
+
+    python tests/test_gpu_stress.py [cases] [first seed]
+
+Every case: random shape (up to ~700 x 300, 1..4 channels), random content class, random slicing (rows, tiles, whole
+image; interleaved and planar), random lane-group width / kernel-family overrides -- the container must equal the
+oracle's byte for byte and decode back to the input, through the C ABI.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import pytest  # noqa: E402
+
+HOOKS = ("LLCOMP_MI_LANE_SHIFT", "LLCOMP_MI_NOROWS", "LLCOMP_MI_NOLDSTAB", "LLCOMP_MI_FORCE_REPLAY")
+
+
+def make(rng, w, h, c, kind):
+    if kind == 0:
+        return rng.integers(0, 256, size=(h, w, c), dtype=np.uint8)
+    y, x, k = np.meshgrid(np.arange(h), np.arange(w), np.arange(c), indexing="ij")
+    if kind == 1:
+        return ((x * 3 + y * 5 + k * 11 + rng.integers(-2, 3, size=(h, w, c))) & 0xFF).astype(np.uint8)
+    if kind == 2:
+        return (((x + y + k) & 1) * 255).astype(np.uint8)
+    if kind == 3:  # long flat runs with sparse spikes: zero-flag heavy, then maximal residuals
+        img = np.full((h, w, c), int(rng.integers(0, 256)), np.uint8)
+        m = rng.random((h, w, c)) < 0.02
+        img[m] = rng.integers(0, 256, size=int(m.sum()), dtype=np.uint8)
+        return img
+    return ((x + y + 37 * k) & 0xFF).astype(np.uint8)
+
+
+def run_case(mi, orc, seed, check_legacy):
+    rng = np.random.default_rng(seed)
+    w, h, c = int(rng.integers(1, 700)), int(rng.integers(1, 300)), int(rng.integers(1, 5))
+    img = make(rng, w, h, c, int(rng.integers(0, 5)))
+    mode = int(rng.integers(0, 4))
+    if mode == 0:
+        tw, th = int(rng.integers(1, w + 1)), 1
+    elif mode == 1:
+        tw, th = int(rng.integers(8, 97)), int(rng.integers(2, 65))
+    elif mode == 2:
+        tw, th = w, int(rng.integers(1, h + 1))
+    else:
+        tw, th = 0, 0
+    planar = bool(rng.integers(0, 2))
+    env = {}
+    if rng.random() < 0.3:
+        env["LLCOMP_MI_LANE_SHIFT"] = str(int(rng.integers(0, 7)))
+    if rng.random() < 0.15:
+        env["LLCOMP_MI_NOROWS"] = "1"
+    if rng.random() < 0.15:
+        env["LLCOMP_MI_NOLDSTAB"] = "1"
+    if rng.random() < 0.1:
+        env["LLCOMP_MI_FORCE_REPLAY"] = "1"
+    for k in HOOKS:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    mi.reload_tuning()  # the library reads its hooks once per process unless told otherwise
+    try:
+        want = orc.compress_sliced(img, tw, th, planar)
+        got = mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar)
+        assert got == want, f"case {seed}: container differs ({w}x{h}x{c} tile {tw}x{th} planar={planar} env={env})"
+        assert np.array_equal(mi.decompress_image(got).pixels, img), f"case {seed}: round trip"
+        if check_legacy and w * h * c <= 120000:
+            leg = mi.compress_image(img, w, h, c)
+            assert leg == orc.compress_image(img), f"case {seed}: legacy stream differs"
+            assert np.array_equal(mi.decompress_image(leg).pixels, img)
+    finally:
+        for k in HOOKS:
+            os.environ.pop(k, None)
+        mi.reload_tuning()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", range(6))
+def test_stress_parity(chunk):
+    """72 random cases per run (12 per chunk), every one byte-exact against the oracle and lossless."""
+    import llcomp_amd as mi
+    import orc as orc_mod
+
+    assert mi.device_count() >= 1, "GPU tests need a HIP device"
+    orc = orc_mod.Orc()
+    for i in range(12):
+        run_case(mi, orc, 1000 + chunk * 12 + i, check_legacy=(i % 6 == 0))
+
+
+def main():
+    import llcomp_amd as mi
+    import orc as orc_mod
+
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    orc = orc_mod.Orc()
+    for i in range(cases):
+        run_case(mi, orc, seed0 + i, check_legacy=(i % 7 == 0))
+        if i % 25 == 24:
+            print(f"{i + 1} cases ok", flush=True)
+    print(f"stress parity: {cases} cases ok")
+
+
+if __name__ == "__main__":
+    main()
