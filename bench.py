@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric: encode+decode MPix/s on 4K RGB8, bit-exact, with achieved HBM GB/s vs peak.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--content g3|g2|mid] [--tile-w TW --tile-h TH] [--interleaved]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--content g3|g2|mid|nat] [--tile-w TW --tile-h TH] [--interleaved]
 
-A "step" = one pass of the hot path over one batch: F frames of 3840x2160 RGB8 already resident in HBM are
-encoded into the sliced container payload (stage A -> k_encode_slices -> scan + pack) and decoded back
-(stage streams -> k_decode_slices -> stage A inverse); the round trip is verified bit-exact outside the timed region.
-The frames of a step are split over --streams independent pipelines (codec object + HIP stream each) so that the
-memory-bound kernels of one overlap the issue-bound slice kernels of another.
-value = pixels coded / wall time, i.e. w*h / (t_enc + t_dec) per frame, whole job over all ranks.
-N > 1: launched by torch.distributed.run, one rank per GPU; frames are independent objects, so ranks shard
-frames with no data-path collective (weak scaling: F frames per rank).
+N = 1 (default): BASELINE config 3.  A "step" = one pass of the hot path over one batch: F frames of 3840x2160 RGB8 already
+resident in HBM are encoded into the sliced container payload (stage A -> k_encode_slices -> scan + pack) and decoded back
+(stage streams -> k_decode_slices -> stage A inverse); the round trip is verified bit-exact outside the timed region.  The
+frames of a step are split over --streams independent pipelines (codec object + HIP stream each) so that the memory-bound
+kernels of one overlap the issue-bound slice kernels of another.  value = pixels coded / wall time, i.e.
+w*h / (t_enc + t_dec) per frame.  `also` = the other workloads of DESIGN.md section 7, a few steps each, measured in the
+same run: other contents, 2-D tiles, one-frame latency, batched legacy streams, the PCIe-inclusive C5 stream, and the C4
+workload on one GPU (the N = 1 point of the strong-scaling curve).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL over xGMI): BASELINE config 4, STRONG scaling -- a fixed
+batch of 8192x8192 RGB8 images, every image sharded over all ranks by interleaved chunks of tile rows
+(llcomp_amd/sharding.py): local encode, slice-table all_gather, one payload message per rank to rank 0, device
+concatenator -> one container per image on rank 0; decode mirrors it.  The gather / scatter is inside the timed region,
+container 0 is compared with the one-piece container.  `replica` = the config-3 workload with frames sharded over the ranks
+(no data-path collective, weak scaling), a few steps, as a second key.
 """
 import argparse
 import json
@@ -22,38 +29,44 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 W4K, H4K, C4K = 3840, 2160, 3
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK = 1024 * 2.4e9 / 2  # wave-instructions/s: 256 CUs x 4 SIMDs, one VALU instruction per 2 cycles at 2.4 GHz
+RMW_CEILING = 22.0e9       # random 8-byte read-modify-writes/s into multi-GB tables: tools/ubench/rand_table.hip, profiles/r02_rand_table.txt
 
 
-def make_frames(content, frames, rank):
+def make_frames(content, frames, rank, w=W4K, h=H4K, c=C4K, distinct=None):
+    """frames x [h,w,c] uint8.  `distinct` < frames: only that many frames are generated, the rest are horizontal rotations
+    of them (cheap, and different bytes for the coder)."""
     import numpy as np
     from llcomp_amd import synth
 
-    out = np.empty((frames, H4K, W4K, C4K), dtype=np.uint8)
+    out = np.empty((frames, h, w, c), dtype=np.uint8)
+    distinct = frames if distinct is None else max(1, min(distinct, frames))
     for i in range(frames):
         seed = 1234 + rank * frames + i
-        if content == "g3":
-            out[i] = synth.gen_g3(W4K, H4K, C4K, seed=seed)
+        if i >= distinct:
+            out[i] = np.roll(out[i % distinct], 11 * (i // distinct), axis=1)
+        elif content == "g3":
+            out[i] = synth.gen_g3(w, h, c, seed=seed)
         elif content == "g2":
-            out[i] = np.roll(synth.gen_g2(W4K, H4K, C4K), (seed - 1234) * 5, axis=1)
+            out[i] = np.roll(synth.gen_g2(w, h, c), (seed - 1234) * 5, axis=1)
         elif content == "nat":
-            out[i] = synth.gen_nat(W4K, H4K, C4K, seed=seed)
+            out[i] = synth.gen_nat(w, h, c, seed=seed)
         else:
-            out[i] = synth.gen_mid(W4K, H4K, C4K, seed=seed)
+            out[i] = synth.gen_mid(w, h, c, seed=seed)
     return out
 
 
-def cpu_baseline(content, tile_w, tile_h, planar):
-    """Time the CPU path on ONE frame of the same workload, single thread.  kind 'reference' = the real
-    llcomp.hpp compiled in place (oracle/_ref, whole-image stream: O2 encode + unmodified decompressImage);
-    kind 'port' = the plain-C restatement (same sliced container as the GPU produces)."""
+def cpu_baseline(img, label, tile_w, tile_h, planar):
+    """Time the CPU path on ONE frame, single thread.  kind 'reference' = the real llcomp.hpp compiled in place
+    (oracle/_ref, whole-image stream: O2 encode + unmodified decompressImage); kind 'port' = the plain-C restatement
+    (same sliced container as the GPU produces)."""
     import numpy as np
 
     sys.path.insert(0, os.path.join(ROOT, "oracle"))  # the checker: imported by this leg of the bench only
     import orc as orc_mod
 
-    img = make_frames(content, 1, 0)[0]
-    cores = 1
+    h, w, _ = img.shape
     if orc_mod.Ref.available():
         ref = orc_mod.Ref()
         t0 = time.perf_counter()
@@ -62,7 +75,7 @@ def cpu_baseline(content, tile_w, tile_h, planar):
         rc, px = ref.o1_decompress_image(s)
         t2 = time.perf_counter()
         assert rc == 0 and np.array_equal(px, img)
-        kind, sample = "reference", f"1 frame 3840x2160 RGB8 {content}, whole-image stream, llcomp.hpp -O2 -DNDEBUG (enc {t1 - t0:.2f}s + dec {t2 - t1:.2f}s)"
+        kind, sample = "reference", f"1 frame {label}, whole-image stream (ratio {img.size / len(s):.4f}), llcomp.hpp -O2 -DNDEBUG (enc {t1 - t0:.2f}s + dec {t2 - t1:.2f}s)"
     else:
         orc = orc_mod.Orc()
         t0 = time.perf_counter()
@@ -71,8 +84,199 @@ def cpu_baseline(content, tile_w, tile_h, planar):
         rc, px = orc.decompress(s)
         t2 = time.perf_counter()
         assert rc == 0 and np.array_equal(px, img)
-        kind, sample = "port", f"1 frame 3840x2160 RGB8 {content}, same slicing, plain-C oracle (enc {t1 - t0:.2f}s + dec {t2 - t1:.2f}s)"
-    return {"value": round(W4K * H4K / 1e6 / (t2 - t0), 4), "unit": "MPix/s", "cores": cores, "kind": kind, "sample": sample}
+        kind, sample = "port", f"1 frame {label}, same slicing, plain-C oracle (enc {t1 - t0:.2f}s + dec {t2 - t1:.2f}s)"
+    return {"value": round(w * h / 1e6 / (t2 - t0), 4), "unit": "MPix/s", "cores": 1, "kind": kind, "sample": sample}
+
+
+def measure(frames_np, tile_w, tile_h, planar, streams, steps, warmup, local_rank, barrier=None, isolated=False):
+    """The device-resident round trip of bench.py: frames_np [F,h,w,c] resident in HBM, split over `streams` pipelines.
+    Returns a dict with the wall time of `steps` timed steps and the per-kernel event timings."""
+    import torch
+
+    import llcomp_amd as mi
+
+    F, h, w, c = frames_np.shape
+    S = max(1, min(streams, F))
+    d_px = torch.from_numpy(frames_np).cuda()
+    d_out = torch.empty_like(d_px)
+    parts, lo = [], 0
+    for i in range(S):
+        n = F // S + (1 if i < F % S else 0)
+        codec = mi.Codec(n, w, h, c, tile_w, tile_h, planar, device=local_rank)
+        cap = min(codec.max_payload_bytes, 2 * n * w * h * c + 64 * codec.n_slices + 4096)
+        parts.append(dict(codec=codec, lo=lo, n=n, cap=cap, stream=torch.cuda.Stream() if S > 1 else torch.cuda.current_stream(),
+                          pay=torch.empty(cap, dtype=torch.uint8, device="cuda"), len=torch.empty(codec.n_slices, dtype=torch.int32, device="cuda"),
+                          tot=torch.zeros(1, dtype=torch.int64, device="cuda"), st=torch.zeros(2, dtype=torch.int32, device="cuda"), total=None))
+        lo += n
+    n_slices = sum(p["codec"].n_slices for p in parts)
+
+    def run(p):
+        cd, st = p["codec"], p["stream"].cuda_stream
+        px, out = d_px[p["lo"]:p["lo"] + p["n"]], d_out[p["lo"]:p["lo"] + p["n"]]
+        cd.encode(px.data_ptr(), p["pay"].data_ptr(), p["cap"], p["len"].data_ptr(), p["tot"].data_ptr(), p["st"].data_ptr(), st)
+        # decode needs the payload size on the host only as an upper bound for its bounds checks
+        cd.decode(p["pay"].data_ptr(), p["total"] if p["total"] is not None else p["cap"], p["len"].data_ptr(), out.data_ptr(), p["st"][1:].data_ptr(), st)
+
+    def step():
+        for p in parts:
+            run(p)
+
+    def check():
+        torch.cuda.synchronize()
+        for p in parts:
+            assert int(p["st"][0].item()) == 0 and int(p["st"][1].item()) == 0, f"status {p['st'].tolist()}"
+        assert torch.equal(d_out, d_px), "round trip is not lossless"
+
+    # first pass: learn the payload sizes, check status and the bit-exact round trip (outside the timed region)
+    torch.cuda.synchronize()
+    step()
+    check()
+    for p in parts:
+        p["total"] = int(p["tot"].item())
+    total = sum(p["total"] for p in parts)
+    for _ in range(max(0, warmup - 1)):
+        step()
+    torch.cuda.synchronize()
+    for p in parts:
+        p["codec"].set_profiling(True)
+        p["codec"].get_profile()
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    dt = time.perf_counter() - t0
+    prof, n_enc, n_dec = {}, 0, 0
+    for p in parts:
+        pr, ne, nd = p["codec"].get_profile()
+        p["codec"].set_profiling(False)
+        for k, v in pr.items():
+            prof[k] = prof.get(k, 0.0) + v
+        n_enc, n_dec = n_enc + ne, n_dec + nd
+    check()
+
+    # The same launches once more with every pipeline ALONE on the GPU (outside the timed region): per-launch durations
+    # without the other streams' kernels beside them, reported next to the live ones (roofline.isolated).
+    iso, iso_enc, iso_dec = {}, 0, 0
+    if S > 1 and isolated:
+        for p in parts:
+            cd = p["codec"]
+            cd.set_profiling(True)
+            cd.get_profile()
+            torch.cuda.synchronize()
+            for _ in range(2):
+                run(p)
+                torch.cuda.synchronize()
+            pr, ne, nd = cd.get_profile()
+            cd.set_profiling(False)
+            for k, v in pr.items():
+                iso[k] = iso.get(k, 0.0) + v
+            iso_enc, iso_dec = iso_enc + ne, iso_dec + nd
+    for p in parts:
+        p["codec"].close()
+    del d_px, d_out, parts
+    torch.cuda.empty_cache()
+    container_bytes = total + 24 * F + 4 * n_slices  # per-frame container headers + slice tables
+    return dict(dt=dt, steps=steps, F=F, S=S, w=w, h=h, c=c, n_slices=n_slices, payload=total, container_bytes=container_bytes,
+                raw_bytes=int(frames_np.size), prof=prof, n_enc=n_enc, n_dec=n_dec, iso=iso, iso_enc=iso_enc, iso_dec=iso_dec,
+                mpix=F * w * h * steps / dt / 1e6, ratio=frames_np.size / container_bytes)
+
+
+def brief(m, **extra):
+    d = {"value": round(m["mpix"], 1), "unit": "MPix/s", "ms_per_step": round(m["dt"] / m["steps"] * 1e3, 3), "steps": m["steps"],
+         "frames": m["F"], "streams": m["S"], "compression_ratio": round(m["ratio"], 4)}
+    d.update(extra)
+    return d
+
+
+def profile_numbers(F, tile_w, tile_h, planar, content, S, dom):
+    """HBM-side bytes and VALU instructions per launch of kernel `dom` from the committed rocprofv3 PMC passes of THIS
+    configuration (profiles/*_traffic.json); (None, None, None) when no committed profile matches."""
+    for name in ("r02_default_traffic.json", "r02_single_stream_traffic.json", "r01_default_traffic.json", "r01_single_stream_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            same = all(tj["config"].get(k) == v for k, v in (("frames_per_step_per_gpu", F), ("tile_w", tile_w), ("tile_h", tile_h),
+                                                            ("planar", planar), ("content", content), ("streams", S)))
+            if same:
+                k = tj["per_launch"][dom]
+                return k.get("hbm_bytes_corrected"), k.get("valu_insts"), "profiles/" + name
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, None, None
+
+
+def c5_stream(frames_np, tile_w, tile_h, planar, depth=6):
+    """BASELINE config 5, PCIe inclusive: the frames stream host -> GPU -> host (container) -> GPU -> host through the
+    product's pipeline (llcomp_mi_stream_*), twice over the batch; every frame verified bit-exact."""
+    import llcomp_amd as mi
+
+    F, h, w, c = frames_np.shape
+    pinned = mi.PinnedBuffer(frames_np.size)
+    pinned.array[:] = frames_np.reshape(-1)
+    views = [pinned.array[i * h * w * c:(i + 1) * h * w * c].reshape(h, w, c) for i in range(F)]
+    st = mi.Stream(w, h, c, tile_w, tile_h, planar, depth=depth)
+    jobs = views + views
+    lens, done_at, busy = mi.pipeline_roundtrip(st, jobs, max_encodes_in_flight=depth // 2, verify=True)
+    st.close()
+    n = len(jobs)
+    steady = (n - 4) * w * h / 1e6 / (done_at[-1] - done_at[3])
+    pinned.close()
+    return {"value": round(steady, 1), "unit": "MPix/s", "frames": n, "depth": depth, "compression_ratio": round(n * h * w * c / sum(lens), 4),
+            "pcie_bytes_per_frame": int(2 * (h * w * c + sum(lens) / n)), "backpressure_hits": busy,
+            "note": "end to end over PCIe from/to pinned host memory, steady state (first 4 frames excluded), every frame bit-exact; never part of `value`"}
+
+
+def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank, check_one_piece=True):
+    """BASELINE config 4: `images` noise images of size x size RGB8, each sharded over all ranks; encode (+ gather to rank 0)
+    and decode (+ scatter) per step.  Returns the max-over-ranks wall time."""
+    import torch
+    import torch.distributed as dist
+
+    import llcomp_amd as mi
+    from llcomp_amd import sharding
+
+    dev = torch.device("cuda", local_rank)
+    sc = sharding.ShardedCodec(size, size, 3, tile_w, tile_h, True, images=images, device=dev)
+    # uniform byte noise (torch Philox, seed 1234 + image): every rank draws the full image on its GPU and keeps its rows
+    bands, first = [], None
+    for b in range(images):
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + b)
+        full = torch.randint(0, 256, (1, size, size, 3), dtype=torch.uint8, device=dev, generator=g)
+        bands.append(torch.cat([full[:, y0:y1] for y0, y1 in sc.rows], dim=1) if sc.rows else full[:, :0])
+        if b == 0 and rank == 0 and check_one_piece:
+            first = full[0].cpu().numpy()
+        del full
+    band = torch.cat(bands, dim=0).contiguous()
+    del bands
+    conts = sc.encode(band)
+    out = sc.decode(conts)
+    assert torch.equal(out, band), "sharded round trip is not lossless"
+    payload_bytes = sum(int(c_.numel()) for c_ in conts) if rank == 0 else 0
+    if first is not None:
+        one = mi.compress_image(first, size, size, 3, format=mi.FORMAT_SLICED, tile_w=tile_w, tile_h=tile_h, planar=True, device=local_rank)
+        assert bytes(conts[0].cpu().numpy()) == one, "sharded container differs from the one-piece container"
+    for _ in range(max(0, warmup - 1)):
+        sc.decode(sc.encode(band))
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = sc.decode(sc.encode(band))
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    assert torch.equal(out, band)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    del sc, band, out, conts
+    torch.cuda.empty_cache()
+    return float(t.item()), payload_bytes
 
 
 def main():
@@ -88,6 +292,10 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="split the frames of a step over this many HIP streams (codec objects)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra one-pipeline-at-a-time launches behind the timed region (profiler runs)")
+    ap.add_argument("--no-also", action="store_true", help="only the headline workload (profiler runs, sweeps)")
+    ap.add_argument("--c4-images", type=int, default=8, help="8192x8192 images per step of the sharded (config 4) workload")
+    ap.add_argument("--c4-tile-w", type=int, default=512)
+    ap.add_argument("--c4-tile-h", type=int, default=1)
     args = ap.parse_args()
 
     import numpy as np
@@ -104,172 +312,158 @@ def main():
     if not torch.cuda.is_available() or mi.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: llcomp_amd has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world == 1:  # the sharded workload runs under torch.distributed at every N, so the N = 1 point is the same code
+        import socket
+
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+        sk.close()
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    barrier = dist.barrier if world > 1 else None
 
     planar = not args.interleaved
     F = args.frames
-    S = max(1, min(args.streams, F))
-    frames_np = make_frames(args.content, F, rank)
-    d_px = torch.from_numpy(frames_np).cuda()
-    d_out = torch.empty_like(d_px)
-    raw_bytes = frames_np.size
-    # S independent pipelines (codec object + HIP stream each) over disjoint frame ranges: the memory-bound stage-A /
-    # pack / stage kernels of one overlap the issue-bound slice kernels of another
-    parts = []
-    lo = 0
-    for i in range(S):
-        n = F // S + (1 if i < F % S else 0)
-        codec = mi.Codec(n, W4K, H4K, C4K, args.tile_w, args.tile_h, planar, device=local_rank)
-        cap = min(codec.max_payload_bytes, 2 * n * W4K * H4K * C4K + 64 * codec.n_slices + 4096)
-        parts.append(dict(codec=codec, lo=lo, n=n, cap=cap, stream=torch.cuda.Stream() if S > 1 else torch.cuda.current_stream(),
-                          pay=torch.empty(cap, dtype=torch.uint8, device="cuda"), len=torch.empty(codec.n_slices, dtype=torch.int32, device="cuda"),
-                          tot=torch.zeros(1, dtype=torch.int64, device="cuda"), st=torch.zeros(2, dtype=torch.int32, device="cuda"), total=None))
-        lo += n
-    n_slices = sum(p["codec"].n_slices for p in parts)
-
-    def step():
-        for p in parts:
-            c, st = p["codec"], p["stream"].cuda_stream
-            px, out = d_px[p["lo"]:p["lo"] + p["n"]], d_out[p["lo"]:p["lo"] + p["n"]]
-            c.encode(px.data_ptr(), p["pay"].data_ptr(), p["cap"], p["len"].data_ptr(), p["tot"].data_ptr(), p["st"].data_ptr(), st)
-            # decode needs the payload size on the host only as an upper bound for its bounds checks
-            c.decode(p["pay"].data_ptr(), p["total"] if p["total"] is not None else p["cap"], p["len"].data_ptr(), out.data_ptr(), p["st"][1:].data_ptr(), st)
-
-    def check():
-        torch.cuda.synchronize()
-        for p in parts:
-            assert int(p["st"][0].item()) == 0 and int(p["st"][1].item()) == 0, f"status {p['st'].tolist()}"
-        assert torch.equal(d_out, d_px), "round trip is not lossless"
-
-    # first pass: learn the payload sizes, check status and the bit-exact round trip (outside the timed region)
-    torch.cuda.synchronize()
-    step()
-    check()
-    for p in parts:
-        p["total"] = int(p["tot"].item())
-    total = sum(p["total"] for p in parts)
-    for _ in range(max(0, args.warmup - 1)):
-        step()
-    torch.cuda.synchronize()
-
-    for p in parts:
-        p["codec"].set_profiling(True)
-        p["codec"].get_profile()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    prof, n_enc, n_dec = {}, 0, 0
-    for p in parts:
-        pr, ne, nd = p["codec"].get_profile()
-        p["codec"].set_profiling(False)
-        for k, v in pr.items():
-            prof[k] = prof.get(k, 0.0) + v
-        n_enc, n_dec = n_enc + ne, n_dec + nd
-    check()
-
-    # The same launches once more with every pipeline ALONE on the GPU (outside the timed region): per-launch durations
-    # without the other streams' kernels beside them, reported next to the live ones (roofline.isolated).
-    iso, iso_enc, iso_dec = {}, 0, 0
-    if S > 1 and not args.no_isolated:
-        for p in parts:
-            c, st = p["codec"], p["stream"].cuda_stream
-            px, out = d_px[p["lo"]:p["lo"] + p["n"]], d_out[p["lo"]:p["lo"] + p["n"]]
-            c.set_profiling(True)
-            c.get_profile()
-            torch.cuda.synchronize()
-            for _ in range(2):
-                c.encode(px.data_ptr(), p["pay"].data_ptr(), p["cap"], p["len"].data_ptr(), p["tot"].data_ptr(), p["st"].data_ptr(), st)
-                c.decode(p["pay"].data_ptr(), p["total"], p["len"].data_ptr(), out.data_ptr(), p["st"][1:].data_ptr(), st)
-                torch.cuda.synchronize()
-            pr, ne, nd = c.get_profile()
-            c.set_profiling(False)
-            for k, v in pr.items():
-                iso[k] = iso.get(k, 0.0) + v
-            iso_enc, iso_dec = iso_enc + ne, iso_dec + nd
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        # ---- BASELINE config 4: strong scaling of sharded 8192^2 images, gather + scatter inside the timed region ----
+        size, B = 8192, args.c4_images
+        dt, payload = c4_run(B, size, args.c4_tile_w, args.c4_tile_h, args.steps, args.warmup, local_rank, world, rank)
+        # second key: the config-3 workload, frames sharded over the ranks (independent objects, no collective)
+        m = measure(make_frames(args.content, F, rank, distinct=min(F, 8)), args.tile_w, args.tile_h, planar, args.streams, max(2, args.steps // 3), 1,
+                    local_rank, barrier=barrier)
+        t = torch.tensor([m["dt"]], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        tot = torch.tensor([total], dtype=torch.int64, device="cuda")
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_all = int(tot.item())
-    else:
-        total_all = total
-
-    if rank == 0:
-        pix_per_step = world * F * W4K * H4K
-        value = pix_per_step * args.steps / dt / 1e6
-        # roofline of the dominant kernel (algorithmic bytes of one coding direction = raw + stream)
-        # mean duration of ONE launch (a launch covers F/S frames); algorithmic bytes below are per launch as well
-        k_enc = prof["k_encode_slices"] / max(1, n_enc)
-        k_dec = prof["k_decode_slices"] / max(1, n_dec)
-        dom, dom_ms = ("k_decode_slices", k_dec) if k_dec >= k_enc else ("k_encode_slices", k_enc)
-        stream_bytes = total + 24 * F + 4 * n_slices  # per-frame container headers + slice tables
-        algo = (raw_bytes + stream_bytes) // S
-        achieved = algo / (dom_ms * 1e-3) / 1e9
-        traffic = None  # HBM-side bytes per launch from committed rocprofv3 PMC passes of THIS configuration
-        for name in ("r01_default_traffic.json", "r01_single_stream_traffic.json"):
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-                same = all(tj["config"].get(k) == v for k, v in (("frames_per_step_per_gpu", F), ("tile_w", args.tile_w), ("tile_h", args.tile_h),
-                                                                ("planar", planar), ("content", args.content), ("streams", S)))
-                if same and world == 1 and traffic is None:
-                    traffic = tj["per_launch"][dom]["hbm_bytes_corrected"]
-            except (OSError, KeyError, ValueError):
-                pass
-        isolated = None
-        if iso:
-            iso_ms = iso[dom] / max(1, iso_enc if dom == "k_encode_slices" else iso_dec)
-            isolated = {"avg_launch_ms": round(iso_ms, 4), "achieved": round(algo / (iso_ms * 1e-3) / 1e9, 3),
-                        "frac": round(algo / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                        "note": "the same launches with one pipeline at a time on the GPU, outside the timed region"}
-        res = {
-            "metric": "encode+decode MPix/s on 4K RGB8, bit-exact",
-            "value": round(value, 2),
-            "unit": "MPix/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "int32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"C3 3840x2160 RGB8 {args.content} ({'std::mt19937 noise' if args.content == 'g3' else args.content}), "
-                            f"{F} frames/step/GPU resident in HBM, sliced container: {args.tile_w}x{args.tile_h} tiles, "
-                            f"{'per-channel planes' if planar else 'channels interleaved'}, {n_slices // F} slices/frame, {S} stream(s)",
-                "frames_per_step_per_gpu": F, "tile_w": args.tile_w, "tile_h": args.tile_h, "planar": planar, "content": args.content,
-                "slices_per_frame": n_slices // F, "streams": S,
-                "compression_ratio": round(world * raw_bytes / (total_all + world * (24 * F + 4 * n_slices)), 4),
-                "parallelism": f"frames sharded over {world} GPU(s), no data-path collective",
-            },
-            "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(dom_ms, 4), "isolated": isolated,
-                "note": "path is serial-dependency / instruction-issue bound (one lane per slice), not HBM bound: DESIGN.md 4; launch durations are measured while the pipelines of the other stream(s) run beside them",
-            },
-            "kernel_ms_per_step": {k: round(v / max(1, args.steps), 4) for k, v in prof.items()},
-        }
-        if not args.no_cpu_baseline and world == 1:  # the CPU reference is timed at N=1 only
-            res["cpu_baseline"] = cpu_baseline(args.content, args.tile_w, args.tile_h, planar)
-            res["speedup_vs_cpu_baseline"] = round(value / res["cpu_baseline"]["value"], 1)
-        print(json.dumps(res), flush=True)
-    for p in parts:
-        p["codec"].close()
-    if world > 1:
+        if rank == 0:
+            value = B * size * size * args.steps / dt / 1e6
+            raw = B * size * size * 3
+            res = {
+                "metric": "encode+decode MPix/s on 8192x8192 RGB8 sharded over the GPUs, RCCL gather + scatter included, bit-exact",
+                "value": round(value, 2), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "int32", "data": "synthetic",
+                "config": {
+                    "workload": f"C4 {B} x 8192x8192 RGB8 uniform noise per step (fixed total), every image sharded over {world} GPUs by interleaved "
+                                f"chunks of tile rows; sliced container {args.c4_tile_w}x{args.c4_tile_h} tiles, per-channel planes; per step: local encode, "
+                                f"slice-table all_gather, one payload message per rank to rank 0 over RCCL, device concatenator -> {B} containers on rank 0; "
+                                f"then table broadcast, payload scatter, local decode (decoded rows stay on their ranks)",
+                    "images_per_step": B, "tile_w": args.c4_tile_w, "tile_h": args.c4_tile_h, "planar": True, "content": "uniform noise (torch Philox, seed 1234+i)",
+                    "compression_ratio": round(raw / payload, 4),
+                    "parallelism": f"tile-row chunks of every image round-robin over {world} GPUs; exchange = all_gather(lengths) + send/recv(payload) per direction",
+                    "one_gpu_point": "the N=1 run reports the same workload under also.c4_sharded_one_gpu",
+                },
+                "roofline": {"bound": "hbm", "kernel": "whole step (sharded)", "achieved": round(2 * (raw + payload) * args.steps / dt / 1e9, 3),
+                             "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(2 * (raw + payload) * args.steps / dt / 1e9 / (HBM_PEAK_GBS * world), 6),
+                             "traffic": None, "note": "algorithmic bytes of encode + decode over the whole job / wall time; the per-kernel roofline is in the N=1 line"},
+                "replica": brief(dict(m, dt=float(t.item()), mpix=world * m["F"] * W4K * H4K * m["steps"] / float(t.item()) / 1e6), scaling="weak",
+                                 workload=f"C3 {F} frames/step/GPU, frames sharded over {world} GPUs, no data-path collective"),
+            }
+            print(json.dumps(res), flush=True)
         dist.destroy_process_group()
+        return
+
+    # ---- N = 1: BASELINE config 3 (headline) ------------------------------------------------------------------------
+    frames_np = make_frames(args.content, F, rank)
+    m = measure(frames_np, args.tile_w, args.tile_h, planar, args.streams, args.steps, args.warmup, local_rank, isolated=not args.no_isolated)
+    S, prof = m["S"], m["prof"]
+    # roofline of the dominant kernel (algorithmic bytes of one coding direction = raw + stream), per launch
+    # (a launch covers F/S frames), duration measured live with hipEvents on the launching stream
+    k_enc = prof["k_encode_slices"] / max(1, m["n_enc"])
+    k_dec = prof["k_decode_slices"] / max(1, m["n_dec"])
+    dom, dom_ms = ("k_decode_slices", k_dec) if k_dec >= k_enc else ("k_encode_slices", k_enc)
+    algo = (m["raw_bytes"] + m["container_bytes"]) // S
+    achieved = algo / (dom_ms * 1e-3) / 1e9
+    traffic, valu, source = profile_numbers(F, args.tile_w, args.tile_h, planar, args.content, S, dom)
+    isolated = None
+    if m["iso"]:
+        iso_ms = m["iso"][dom] / max(1, m["iso_enc"] if dom == "k_encode_slices" else m["iso_dec"])
+        isolated = {"avg_launch_ms": round(iso_ms, 4), "achieved": round(algo / (iso_ms * 1e-3) / 1e9, 3),
+                    "frac": round(algo / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                    "note": "the same launches with one pipeline at a time on the GPU, outside the timed region"}
+        if valu:
+            isolated["valu_issue_frac"] = round(valu / (iso_ms * 1e-3) / VALU_PEAK, 4)
+    res = {
+        "metric": "encode+decode MPix/s on 4K RGB8, bit-exact",
+        "value": round(m["mpix"], 2),
+        "unit": "MPix/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(m["dt"] / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"C3 3840x2160 RGB8 {args.content} ({'std::mt19937 noise' if args.content == 'g3' else args.content}), "
+                        f"{F} frames/step/GPU resident in HBM, sliced container: {args.tile_w}x{args.tile_h} tiles, "
+                        f"{'per-channel planes' if planar else 'channels interleaved'}, {m['n_slices'] // F} slices/frame, {S} stream(s)",
+            "frames_per_step_per_gpu": F, "tile_w": args.tile_w, "tile_h": args.tile_h, "planar": planar, "content": args.content,
+            "slices_per_frame": m["n_slices"] // F, "streams": S,
+            "compression_ratio": round(m["ratio"], 4),
+            "parallelism": "one GPU (N > 1 runs the sharded config-4 workload)",
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": source,
+            "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(dom_ms, 4), "isolated": isolated,
+            "limiter": "valu_issue",
+            "valu_issue": None if not valu else {
+                "valu_wave_insts_per_launch": valu, "source": source, "achieved": round(valu / (dom_ms * 1e-3) / 1e9, 2), "peak": VALU_PEAK / 1e9,
+                "unit": "G wave-instructions/s", "frac": round(valu / (dom_ms * 1e-3) / VALU_PEAK, 4),
+                "note": "VALU wave-instructions of one launch (committed rocprofv3 SQ_INSTS_VALU pass of this configuration) / live launch duration, "
+                        "against 1024 SIMDs x 2.4 GHz / 2; live launches share the SIMDs with the other pipelines' kernels, isolated.valu_issue_frac is the kernel alone"},
+            "note": "the contract's HBM roofline is reported as asked, but this kernel is bound by VALU issue / its serial dependency chain (one lane per slice), "
+                    "not by HBM: DESIGN.md 4; launch durations are measured while the pipelines of the other stream(s) run beside them",
+        },
+        "kernel_ms_per_step": {k: round(v / max(1, args.steps), 4) for k, v in prof.items()},
+    }
+    if not args.no_cpu_baseline:  # the CPU reference is timed at N=1 only
+        res["cpu_baseline"] = cpu_baseline(frames_np[0], f"3840x2160 RGB8 {args.content}", args.tile_w, args.tile_h, planar)
+        res["speedup_vs_cpu_baseline"] = round(m["mpix"] / res["cpu_baseline"]["value"], 1)
+        res["cpu_baseline"]["note"] = ("the reference codes one whole-image stream; the GPU figure is on independent slices (ratio in config.compression_ratio vs "
+                                       "the whole-image ratio in `sample`), so the quotient is throughput at unequal compression, not a like-for-like latency claim")
+
+    if not args.no_also:
+        also = {}
+        sub = max(3, args.steps // 3)
+        t_also = time.perf_counter()
+        # other contents at the default slicing (4 distinct frames, the rest rotations)
+        for content in ("g2", "mid"):
+            if content != args.content:
+                also[f"{content}_default_slicing"] = brief(measure(make_frames(content, F, 0, distinct=4), args.tile_w, args.tile_h, planar, args.streams, sub, 1, local_rank),
+                                                           workload=f"{F} frames 4K {content}, {args.tile_w}x{args.tile_h} planar")
+        # 2-D tiles keep vertical prediction (and the reference's ratio); bound by random state-bank accesses in HBM
+        for content in ("nat", "mid", "g3"):
+            fr = frames_np[:16] if content == args.content else make_frames(content, 16, 0, distinct=4)
+            m2 = measure(fr, 64, 64, True, 2, sub, 1, local_rank)
+            samples = 2 * 16 * W4K * H4K * C4K * m2["steps"]  # one state-bank read-modify-write per sample and direction
+            also[f"{content}_tiles64x64_16frames"] = brief(m2, workload=f"16 frames 4K {content}, 64x64 planar tiles, state tables in HBM",
+                                                           state_bank_rmw_per_s=round(samples / m2["dt"] / 1e9, 2), rmw_ceiling=RMW_CEILING / 1e9,
+                                                           frac_of_random_access_ceiling=round(samples / m2["dt"] / RMW_CEILING, 3))
+        # latency of ONE frame
+        m1 = measure(frames_np[:1], args.tile_w, args.tile_h, planar, 1, 20, 2, local_rank)
+        also["one_frame_latency"] = brief(m1, workload=f"1 frame 4K {args.content}, {args.tile_w}x{args.tile_h} planar", ms_enc_plus_dec=round(m1["dt"] / m1["steps"] * 1e3, 3))
+        # the reference's own format in bulk: 512 whole-image streams (one lane each) of 256x256 RGB8
+        leg = make_frames("mid", 512, 0, w=256, h=256, c=3, distinct=16)
+        ml = measure(leg, 256, 256, False, 1, 1, 1, local_rank)
+        also["legacy_streams_batched"] = brief(ml, workload="512 frames 256x256 RGB8 mid, one whole-image stream each (payload == reference stream), one GPU lane per stream")
+        if not args.no_cpu_baseline:
+            also["legacy_streams_batched"]["cpu_reference"] = cpu_baseline(leg[0], "256x256 RGB8 mid", 256, 256, False)
+        # BASELINE config 5 through the streaming pipeline, PCIe inclusive
+        also["c5_stream_pcie"] = c5_stream(frames_np, args.tile_w, args.tile_h, planar)
+        # BASELINE config 4 on one GPU: the N = 1 point of the strong-scaling curve the N > 1 runs report
+        dt4, pay4 = c4_run(args.c4_images, 8192, args.c4_tile_w, args.c4_tile_h, max(2, sub // 2), 1, local_rank, world, rank)
+        also["c4_sharded_one_gpu"] = {"value": round(args.c4_images * 8192 * 8192 * max(2, sub // 2) / dt4 / 1e6, 1), "unit": "MPix/s",
+                                      "ms_per_step": round(dt4 / max(2, sub // 2) * 1e3, 3), "images_per_step": args.c4_images,
+                                      "compression_ratio": round(args.c4_images * 8192 * 8192 * 3 / pay4, 4),
+                                      "workload": f"C4 {args.c4_images} x 8192x8192 RGB8 uniform noise, {args.c4_tile_w}x{args.c4_tile_h} planar, the sharded code path on 1 GPU"}
+        also["seconds"] = round(time.perf_counter() - t_also, 1)
+        res["also"] = also
+    print(json.dumps(res), flush=True)
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@
 
 namespace llcomp_mi {
 
-constexpr uint32_t kMaxChannels = 4;  // channels per pixel the kernels are instantiated for
+constexpr uint32_t kMaxChannels = 255;  // one byte in both headers; 1..4 run the specialised kernels, more the generic ones
 
 struct Geometry {
     uint32_t frames, w, h, c;
@@ -133,7 +133,7 @@ inline bool make_geometry(Geometry& g, uint32_t frames, uint32_t w, uint32_t h, 
         g.lpw = p;
     }
     g.flags = 0;
-    if (g.tile_h == 1 && !tune.norows) g.flags |= kGeoRows;
+    if (g.tile_h == 1 && !tune.norows && g.nch <= 4) g.flags |= kGeoRows;  // (the register-resident row kernels exist for 1..4 channels)
     else if (g.lpw == 1 && !tune.noldstab) g.flags |= kGeoLdsTable;
     if (tune.force_replay) g.flags |= kGeoForceReplay;
     return true;

@@ -166,6 +166,65 @@ __global__ __launch_bounds__(256) void k_model_inv(const Geometry g, const int16
     }
 }
 
+// ---- stage A for any channel count (c > 4) -------------------------------------------------------------------------
+// The reference's header holds the channel count in one byte and its coder passes channels beyond the third through
+// untransformed (llcomp.hpp:407-409, 541-543).  stb_image never delivers more than four, so these two kernels are the
+// plain form -- one thread per pixel, neighbours straight from HBM, the colour transform redone per neighbour -- kept
+// for format completeness, not for speed.
+__device__ __forceinline__ int sample_at(const uint8_t* p, uint32_t c, uint32_t k) {  // colour-transformed sample k of the pixel at p
+    if (c >= 3 && k < 3) {
+        const int g = p[1], cb = int(p[2]) - g, cr = int(p[0]) - g;
+        return k == 0 ? cr : (k == 1 ? g + (cb + cr) / 4 : cb);  // llcomp.hpp:396-406
+    }
+    return p[k];
+}
+__global__ __launch_bounds__(256) void k_model_fwd_any(const Geometry g, const uint8_t* __restrict__ px, uint32_t* __restrict__ sym,
+                                                       size_t npix) {
+    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const size_t plane = size_t(g.h) * g.w;
+    const uint32_t frame = uint32_t(i / plane);
+    const uint32_t rem = uint32_t(i - size_t(frame) * plane), y = rem / g.w, x = rem - y * g.w;
+    const uint32_t tx = x / g.tile_w, ty = y / g.tile_h, lx = x - tx * g.tile_w, ly = y - ty * g.tile_h;
+    const uint32_t sw = g.w - tx * g.tile_w < g.tile_w ? g.w - tx * g.tile_w : g.tile_w;
+    const size_t rowb = size_t(g.w) * g.c;
+    const uint8_t* p = px + i * g.c;
+    for (uint32_t k = 0; k < g.c; ++k) {
+        const int cur = sample_at(p, g.c, k);
+        const int l = lx > 0 ? sample_at(p - g.c, g.c, k) : 0, L = lx > 1 ? sample_at(p - 2 * g.c, g.c, k) : 0;
+        const int t = ly > 0 ? sample_at(p - rowb, g.c, k) : 0, tl = (ly > 0 && lx > 0) ? sample_at(p - rowb - g.c, g.c, k) : 0;
+        const int tr = (ly > 0 && lx + 1 < sw) ? sample_at(p - rowb + g.c, g.c, k) : 0, T = ly > 1 ? sample_at(p - 2 * rowb, g.c, k) : 0;
+        const Hood n = apply_borders(l, L, t, tl, tr, T, lx, ly, sw);
+        int ctx = context_hash(n), res = cur - predict(n);
+        if (ctx < 0) {  // llcomp.hpp:433-436
+            ctx = -ctx;
+            res = -res;
+        }
+        sym[sample_index(g, frame, y, x, k)] = uint32_t(ctx) | (uint32_t(res) << 16);
+    }
+}
+__global__ __launch_bounds__(256) void k_model_inv_any(const Geometry g, const int16_t* __restrict__ rec, uint8_t* __restrict__ px,
+                                                       size_t npix) {
+    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const size_t plane = size_t(g.h) * g.w;
+    const uint32_t frame = uint32_t(i / plane);
+    const uint32_t rem = uint32_t(i - size_t(frame) * plane), y = rem / g.w, x = rem - y * g.w;
+    uint8_t* o = px + i * g.c;
+    uint32_t k = 0;
+    if (g.c >= 3) {  // llcomp.hpp:532-540
+        int r = rec[sample_index(g, frame, y, x, 0)], gg = rec[sample_index(g, frame, y, x, 1)], b = rec[sample_index(g, frame, y, x, 2)];
+        gg -= (r + b) / 4;
+        r += gg;
+        b += gg;
+        o[0] = uint8_t(min(max(r, 0), 255));
+        o[1] = uint8_t(min(max(gg, 0), 255));
+        o[2] = uint8_t(min(max(b, 0), 255));
+        k = 3;
+    }
+    for (; k < g.c; ++k) o[k] = uint8_t(rec[sample_index(g, frame, y, x, k)]);  // llcomp.hpp:541-543
+}
+
 // ---- slice length scan ------------------------------------------------------------------------------------------------
 // The packed payload holds the slices back to back in slice order, so slice i starts at the sum of the lengths before
 // it.  pack / stage work on whole lane groups (64 consecutive slices) and find a slice's offset as
@@ -515,8 +574,11 @@ __global__ __launch_bounds__(256) void k_model_rows_fwd(const Geometry g, const 
         const uint32_t tt = i / RUNW, d = i - tt * RUNW;
         const long long start = (long long)tiles[tt].base + (long long)(int(k0) - 2) * C;  // may be < 0 for the first run
         const long long al = (start & ~3ll) + 4ll * d;
-        raw[tt][d] = (al >= 0 && size_t(al) + 4 <= ((total_bytes + 3) & ~size_t(3)))
-                         ? *reinterpret_cast<const uint32_t*>(px + al) : 0u;
+        // never a byte beyond the caller's buffer: the last partial dword is assembled from byte loads
+        uint32_t v = 0;
+        if (al >= 0 && size_t(al) + 4 <= total_bytes) __builtin_memcpy(&v, px + al, 4);  // (px itself may be unaligned)
+        else if (al >= 0 && size_t(al) < total_bytes) v = load_bytes_le(px + al, uint32_t(total_bytes - size_t(al)));
+        raw[tt][d] = v;
     }
     __syncthreads();
     // this thread: pixels k0 + 8*q + i, i = 0..7, of tile tt, walking left to right so l and L come from registers
@@ -670,6 +732,11 @@ __global__ __launch_bounds__(256) void k_model_rows_inv(const Geometry g, const 
     }
 
 hipError_t launch_model_fwd(const Geometry& g, const uint8_t* d_px, uint32_t* d_sym, hipStream_t stream) {
+    if (g.c > 4) {
+        const size_t npix = size_t(g.frames) * g.h * g.w;
+        k_model_fwd_any<<<dim3(uint32_t((npix + 255) / 256)), dim3(256), 0, stream>>>(g, d_px, d_sym, npix);
+        return hipGetLastError();
+    }
     const uint32_t nbx = (g.w + kMW - 1) / kMW;
     const uint32_t spt = (g.tile_h + kMH - 1) / kMH;
     const uint64_t blocks = uint64_t(nbx) * spt * g.nty * g.frames;
@@ -697,7 +764,7 @@ hipError_t launch_from_lane_order_i16(const Geometry& g, const int16_t* d_lanes,
     return hipGetLastError();
 }
 
-bool model_is_fused(const Geometry& g) { return g.planar && rows_mode(g); }
+bool model_is_fused(const Geometry& g) { return g.planar && rows_mode(g) && g.c <= 4; }
 
 hipError_t launch_model_rows_fwd(const Geometry& g, const uint8_t* d_px, uint16_t* d_lanes, hipStream_t stream) {
     const uint64_t blocks = uint64_t(lane_groups(g)) * ((g.tile_w + 63) / 64);
@@ -715,6 +782,10 @@ hipError_t launch_model_rows_inv(const Geometry& g, const int16_t* d_lanes, uint
 
 hipError_t launch_model_inv(const Geometry& g, const int16_t* d_rec, uint8_t* d_px, hipStream_t stream) {
     const size_t npix = size_t(g.frames) * g.h * g.w;
+    if (g.c > 4) {
+        k_model_inv_any<<<dim3(uint32_t((npix + 255) / 256)), dim3(256), 0, stream>>>(g, d_rec, d_px, npix);
+        return hipGetLastError();
+    }
     const uint32_t blocks = uint32_t(std::min<size_t>((npix + 255) / 256, 256 * 16));
     LLMI_DISPATCH_C(g.c, (k_model_inv<C><<<dim3(blocks), dim3(256), 0, stream>>>(g, d_rec, d_px, npix)));
     return hipGetLastError();

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     e.out = scratch + ((((size_t(id >> g.lane_shift) * (g.slice_cap >> 4)) << g.lane_shift) + (id & ((1u << g.lane_shift) - 1))) << 4);
     e.cap = int32_t(g.slice_cap);
     e.shift = g.lane_shift;
-    const uint32_t n_row = r.sw * NCH;  // samples per slice row
+    const uint32_t n_row = r.sw * (NCH ? uint32_t(NCH) : g.nch);  // samples per slice row (NCH == 0: any channel count)
     // symbols in lane order: sample k of this slice is p0[k * GW]; the lanes of a group read one contiguous piece
     const SYM* p0 = sym + lane_order_index(g, id, 0);
     const size_t GW = size_t(1) << g.lane_shift;  // distance between consecutive samples of this slice
@@ -772,6 +772,37 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
             banks = states + ((size_t(id >> g.lane_shift) * kContexts) << g.lane_shift) + (id & ((1u << g.lane_shift) - 1));
             bsh = g.lane_shift;
         }
+        if constexpr (NCH == 0) {
+            // Any channel count (c > 4, channels interleaved): the plain form -- all six neighbours are read back from the
+            // lane-order array this lane has written itself.  Format completeness, not speed.
+            const uint32_t nch = g.nch;
+            const ptrdiff_t px_step = ptrdiff_t(nch) * GW, up = ptrdiff_t(r.sw) * px_step;
+            for (uint32_t y = 0; y < r.sh; ++y) {
+                for (uint32_t x = 0; x < r.sw; ++x) {
+                    for (uint32_t k = 0; k < nch; ++k) {
+                        int16_t* q = p0 + ptrdiff_t(y) * up + ptrdiff_t(x) * px_step + ptrdiff_t(k) * GW;
+                        if (window_low(d)) dec_append(d);
+                        const Hood n = apply_borders(x > 0 ? q[-px_step] : 0, x > 1 ? q[-2 * px_step] : 0, y > 0 ? q[-up] : 0,
+                                                     (y > 0 && x > 0) ? q[-up - px_step] : 0, (y > 0 && x + 1 < r.sw) ? q[-up + px_step] : 0,
+                                                     y > 1 ? q[-2 * up] : 0, x, y, r.sw);
+                        int ctx = context_hash(n);
+                        const bool neg = ctx < 0;
+                        if (neg) ctx = -ctx;
+                        const uint64_t b64 = banks[size_t(ctx) << bsh];
+                        Bank bank{{uint32_t(b64), uint32_t(b64 >> 32)}, nullptr};
+                        uint32_t v;
+                        if (!dec_sample<false>(d, bank, tab, hot, replay_always, v)) {
+                            atomicOr(status, kStBadExponent);
+                            return;
+                        }
+                        hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true)));
+                        banks[size_t(ctx) << bsh] = uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32);
+                        if (neg) v = 0u - v;
+                        *q = int16_t(uint32_t(predict(n)) + v);
+                    }
+                }
+            }
+        } else {
         const ptrdiff_t up = ptrdiff_t(r.sw) * NCH * GW;  // one slice row back, in lane-order elements
         for (uint32_t y = 0; y < r.sh; ++y) {
             int16_t* row = p0 + ptrdiff_t(y) * up;
@@ -820,6 +851,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 }
             }
         }
+        }
     }
 }
 
@@ -827,7 +859,9 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
 
 // (channels per slice, 1-row slices, state table in LDS) -> template instance
 #define LLMI_DISPATCH_SLICE(nch, rows, lds, ...)                                                             \
-    switch ((nch) * 4 + ((rows) ? 2 : 0) + ((lds) ? 1 : 0)) {                                                 \
+    switch (((nch) > 4 ? 0 : (nch)) * 4 + ((rows) ? 2 : 0) + ((lds) ? 1 : 0)) {                               \
+        case 0: { constexpr int C = 0; constexpr bool R = false; constexpr bool T = false; __VA_ARGS__; } break;    \
+        case 1: { constexpr int C = 0; constexpr bool R = false; constexpr bool T = true; __VA_ARGS__; } break;     \
         case 4: { constexpr int C = 1; constexpr bool R = false; constexpr bool T = false; __VA_ARGS__; } break;    \
         case 5: { constexpr int C = 1; constexpr bool R = false; constexpr bool T = true; __VA_ARGS__; } break;     \
         case 6: { constexpr int C = 1; constexpr bool R = true; constexpr bool T = false; __VA_ARGS__; } break;     \

@@ -41,8 +41,6 @@ LEGACY_CASES = [v for v in KAT if v["w"] * v["h"] * v["c"] <= 1920 * 1080 * 3 an
 
 @pytest.mark.parametrize("v", LEGACY_CASES, ids=_id)
 def test_p0_legacy_stream_equals_reference(mi, orc, v):
-    if v["c"] > 4:
-        pytest.skip("HIP path supports 1..4 channels (what stb_image can deliver)")
     img = make_image(v["gen"], v["w"], v["h"], v["c"])
     s = mi.compress_image(img, v["w"], v["h"], v["c"])
     assert len(s) == v["len"]
@@ -93,6 +91,27 @@ def test_random_shapes_match_oracle(mi, orc, seed):
     assert np.array_equal(mi.decompress_image(orc.compress_image(img)).pixels, img)
 
 
+@pytest.mark.parametrize("c", [5, 6, 9, 17])
+def test_more_than_four_channels_match_oracle(mi, orc, c):
+    """The reference passes channels beyond the third through untransformed for any count its one-byte header holds
+    (llcomp.hpp:407-409, 541-543).  Here they run through the generic (any channel count) kernels: legacy stream, sliced
+    interleaved and planar, 1-row slices included."""
+    rng = np.random.default_rng(700 + c)
+    w, h = int(rng.integers(20, 60)), int(rng.integers(6, 30))
+    y, x, k = np.meshgrid(np.arange(h), np.arange(w), np.arange(c), indexing="ij")
+    img = ((x * 3 + y * 5 + k * 29 + rng.integers(-3, 4, size=(h, w, c))) & 0xFF).astype(np.uint8)
+    img[:, w // 2:] = rng.integers(0, 256, size=(h, w - w // 2, c), dtype=np.uint8)
+    s = mi.compress_image(img, w, h, c)
+    assert s == orc.compress_image(img)
+    out = mi.decompress_image(s)
+    assert out.channels == c and np.array_equal(out.pixels, img)
+    for tw, th in ((16, 8), (w, 1), (11, 1)):
+        for planar in (False, True):
+            t = mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar)
+            assert t == orc.compress_sliced(img, tw, th, planar), (tw, th, planar)
+            assert np.array_equal(mi.decompress_image(t).pixels, img)
+
+
 # ---- decoder behaviour on damaged streams == the real reference's ------------------------------------------------
 @pytest.mark.parametrize("v", DEC, ids=lambda v: v["name"])
 def test_decoder_behaviour_equals_reference(mi, orc, v):
@@ -122,8 +141,11 @@ def test_error_codes(mi):
         mi.compress_image(np.zeros(70000 * 3, np.uint8), 70000, 1, 3)  # u16 header field (D4)
     assert e.value.status == mi.OUT_OF_RANGE
     with pytest.raises(mi.LlcompError) as e:
-        mi.compress_image(np.zeros(5 * 4, np.uint8), 2, 2, 5)
+        mi.compress_image(np.zeros(256 * 4, np.uint8), 2, 2, 256)  # the channel count is one byte in both headers
     assert e.value.status == mi.BAD_ARGS
+    with pytest.raises(mi.LlcompError) as e:
+        mi.Codec(1, 32768, 32768, 3)  # w*h*c >= 2^31 (llcomp.hpp:359 `int size`)
+    assert e.value.status == mi.OUT_OF_RANGE
     # sliced format has u32 dimensions: a 70000-pixel-wide strip is fine there
     img = (np.arange(70000 * 3) & 0xFF).astype(np.uint8).reshape(1, 70000, 3)
     s = mi.compress_image(img, 70000, 1, 3, format=mi.FORMAT_SLICED, tile_w=1000)

@@ -1,0 +1,94 @@
+"""The multi-GPU path (llcomp_amd/sharding.py) with the PRODUCT's local coder -- the device-resident HIP codec object --
+under torch.distributed:
+  * world size 1 on the nccl (= RCCL) backend: every collective of the path runs on device tensors;
+  * world size 2 on the gloo backend, both ranks on the one GPU of the test box: the full exchange logic (slice-table
+    all_gather / broadcast, one payload message per rank, device concatenator) around real HIP encodes / decodes.
+Containers must equal the one-piece container of the host call byte for byte (BASELINE config 4 sizes included)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, backend, port, cases, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    import llcomp_amd as mi
+    from llcomp_amd import sharding, synth
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        for (gen, w, h, c), (tw, th), planar, images, cpr in cases:
+            full = np.stack([np.roll(synth.GENERATORS[gen](w, h, c), 5 * b, axis=1) for b in range(images)])
+            sc = sharding.ShardedCodec(w, h, c, tw, th, planar, images=images, chunks_per_rank=cpr, device=dev)
+            assert sc.band is None or type(sc.band).__name__ == "_HipBand"
+            band = sc.take_local(full)
+            conts = sc.encode(band)
+            if rank == 0:
+                for b in range(images):
+                    want = mi.compress_image(full[b], w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar, device=0)
+                    assert conts[b].is_cuda and bytes(conts[b].cpu().numpy()) == want, f"{gen} {w}x{h}: image {b} differs from the one-piece container"
+            out = sc.decode(conts)
+            assert out.is_cuda and torch.equal(out, band), "decoded rows differ from the source rows"
+            px = sc.gather_pixels(out)
+            if rank == 0:
+                assert np.array_equal(px.cpu().numpy(), full)
+            del sc
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, backend, cases):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, backend, port, cases, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert res == [(r, "ok") for r in range(world)], res
+    assert all(p.exitcode == 0 for p in procs)
+
+
+def test_sharded_path_world1_rccl_device_tensors():
+    _run(1, "nccl", [(("mid", 2048, 1024, 3), (128, 128), True, 2, 4),
+                     (("g3", 1000, 333, 4), (480, 1), True, 1, 4),
+                     (("mid", 8192, 8192, 3), (128, 128), True, 1, 4)])   # BASELINE config 4 size
+
+
+def test_sharded_path_world2_hip_coder_gloo_exchange():
+    _run(2, "gloo", [(("mid", 2048, 1024, 3), (128, 128), True, 2, 4),
+                     (("g3", 1000, 333, 4), (480, 1), True, 2, 3),
+                     (("nat", 777, 130, 3), (64, 16), False, 1, 1),
+                     (("g3", 8192, 2048, 3), (480, 1), True, 1, 4)])      # a quarter of config 4, noise

@@ -26,49 +26,12 @@ def golden(gen, w, tw, th, planar):
 
 
 def run_stream(mi, frames, tw, th, planar, depth, max_encodes_in_flight, check=None):
-    """Streams every frame through encode and straight back through decode.  An encode result (pinned container) is
-    handed to submit_decode as it is and released only when that decode has come back.  Returns per-frame container
-    lengths and the completion time of every frame."""
-    n, (h, w, c) = len(frames), frames[0].shape
+    """Streams every frame through encode and straight back through decode (llcomp_amd.pipeline_roundtrip: the loop
+    bench.py's C5 leg uses too); every decoded frame is compared with its source inside."""
+    h, w, c = frames[0].shape
     st = mi.Stream(w, h, c, tw, th, planar, depth=depth)
-    lens, done_at, busy_seen = [0] * n, [0.0] * n, 0
-    enc_held = {}      # frame index -> encode job whose container a decode job is still reading
-    to_decode = []     # encode jobs that finished but found no free slot yet
-    next_frame, finished, enc_in_flight = 0, 0, 0
-    t0 = time.perf_counter()
-    while finished < n:
-        progressed = False
-        while to_decode:  # containers first: they free slots
-            job = to_decode[0]
-            if not st.submit_decode(job.data, tag=job.tag):
-                busy_seen += 1
-                break
-            enc_held[job.tag] = job
-            to_decode.pop(0)
-            progressed = True
-        while next_frame < n and enc_in_flight < max_encodes_in_flight and not to_decode:
-            if not st.submit_encode(frames[next_frame], tag=next_frame):
-                busy_seen += 1
-                break
-            next_frame += 1
-            enc_in_flight += 1
-            progressed = True
-        if st.pending() and (not progressed or st.ready()):
-            job = st.wait()
-            assert job.status == mi.OK, f"frame {job.tag}: status {job.status}"
-            if job.kind == mi.JOB_ENCODE:
-                enc_in_flight -= 1
-                lens[job.tag] = job.data.size
-                if check:
-                    check(job.tag, job.data)
-                to_decode.append(job)
-            else:
-                assert np.array_equal(job.data, frames[job.tag]), f"frame {job.tag} is not bit-exact after the round trip"
-                done_at[job.tag] = time.perf_counter() - t0
-                st.release(job)
-                st.release(enc_held.pop(job.tag))
-                finished += 1
-    assert st.pending() == 0 and not enc_held
+    lens, done_at, busy_seen = mi.pipeline_roundtrip(st, frames, max_encodes_in_flight, on_container=check, verify=True)
+    assert st.pending() == 0
     st.close()
     return lens, done_at, busy_seen
 

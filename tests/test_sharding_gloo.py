@@ -1,7 +1,9 @@
-"""N > 1 path on CPU: two gloo ranks shard one image by tile rows, gather the per-rank containers to rank 0 and
-stitch them with the product's host concatenator; the result must equal the one-piece container.  The encoder /
-decoder plugged in here is the oracle (there is no GPU in this test) -- what is under test is the distributed
-plumbing (band split, variable-length gather/scatter) and llcomp_mi_merge_bands / llcomp_mi_split_band."""
+"""N > 1 path on CPU: gloo ranks shard images by interleaved chunks of tile rows (llcomp_amd/sharding.py), exchange the
+slice tables (all_gather / broadcast) and one payload message per rank, and the gathering rank's concatenator interleaves
+the pieces into image order.  Every container must equal the one-piece container byte for byte, and decode must give
+every rank its rows back.  The local coder plugged in here is the oracle (no GPU in this test; the HIP coder under the
+same code runs in tests/test_gpu_sharding.py) -- what is under test is the distributed logic: chunk plan, slice
+permutation, segment tables, message sizes."""
 import os
 import socket
 import sys
@@ -21,10 +23,55 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, shape, tile, planar, q):
+def oracle_band_factory(orc):
+    import torch
+
+    class OracleBand:
+        """CPU stand-in for the device codec object: same contract (packed payload + slice lengths, frame-major)."""
+
+        def __init__(self, images, w, h, c, tile_w, tile_h, planar, device):
+            self.geo = (images, w, h, c, tile_w, min(tile_h, h), planar)
+            self.n_slices = images * orc.slice_count(w, h, c, tile_w, min(tile_h, h), planar)
+
+        def encode(self, px):
+            images, w, h, c, tw, th, planar = self.geo
+            pays, lens = [], []
+            for b in range(images):
+                s = orc.compress_sliced(px[b].numpy(), tw, th, planar)
+                n = int.from_bytes(s[20:24], "little")
+                lens.append(np.frombuffer(s[24:24 + 4 * n], dtype="<u4"))
+                pays.append(s[24 + 4 * n:])
+            payload = torch.frombuffer(bytearray(b"".join(pays) + bytes(16)), dtype=torch.uint8)
+            lens = torch.from_numpy(np.concatenate(lens).astype(np.int32))
+            return payload, lens, torch.tensor([int(lens.sum())]), torch.zeros(1, dtype=torch.int32)
+
+        def decode(self, payload, payload_bytes, lens, out):
+            images, w, h, c, tw, th, planar = self.geo
+            per = self.n_slices // images
+            lens = lens.numpy().astype(np.int64)
+            data = payload.numpy().tobytes()
+            pos = 0
+            for b in range(images):
+                ln = lens[b * per:(b + 1) * per]
+                head = bytes([0x9C, 1, c, 1 if planar else 0]) + b"".join(int(v).to_bytes(4, "little") for v in (w, h, tw, th, per))
+                body = data[pos:pos + int(ln.sum())]
+                pos += int(ln.sum())
+                rc, px = orc.decompress(head + ln.astype("<u4").tobytes() + body)
+                assert rc == 0
+                out[b] = torch.from_numpy(px.copy())
+            return torch.zeros(1, dtype=torch.int32)
+
+        def check(self, status):
+            assert int(status.item()) == 0
+
+    return OracleBand
+
+
+def _worker(rank, world, port, case, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
     import torch.distributed as dist
 
     import orc as orc_mod
@@ -33,55 +80,68 @@ def _worker(rank, world, port, shape, tile, planar, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         orc = orc_mod.Orc()
-        w, h, c = shape
-        tw, th = tile
-        img = orc_mod.gen_mid(w, h, c)
-        y0, y1 = sharding.band_rows(h, th, world)[rank]
-
-        def enc(b, bw, bh, bc, tile_w, tile_h, pl):
-            return orc.compress_sliced(np.ascontiguousarray(b).reshape(bh, bw, bc), tile_w, tile_h, pl)
-
-        def dec(data):
-            rc, px = orc.decompress(data)
-            assert rc == 0
-            return px
-
-        whole = sharding.encode_image_sharded(img[y0:y1], w, y1 - y0, c, tile_w=tw, tile_h=th, planar=planar, encode_fn=enc)
+        (w, h, c), (tw, th), planar, images, cpr = case
+        full = np.stack([np.roll(orc_mod.gen_mid(w, h, c) if b % 2 == 0 else orc_mod.gen_g3(w, h, c, seed=5 + b), 3 * b, axis=1) for b in range(images)])
+        sc = sharding.ShardedCodec(w, h, c, tw, th, planar, images=images, chunks_per_rank=cpr, device=torch.device("cpu"),
+                                   band_factory=oracle_band_factory(orc))
+        band = sc.take_local(full)
+        rows = [y for y0, y1 in sc.rows for y in range(y0, y1)]
+        assert band.shape == (images, len(rows), w, c)
+        conts = sc.encode(band)
         if rank == 0:
-            assert whole == orc.compress_sliced(img, tw, th, planar), "stitched container differs from one-piece container"
-        px = sharding.decode_image_sharded(whole, decode_fn=dec)
+            for b in range(images):
+                assert bytes(conts[b].numpy()) == orc.compress_sliced(full[b], tw, th, planar), f"image {b}: sharded container differs from the one-piece container"
+        else:
+            assert conts is None
+        out = sc.decode(conts)
+        assert np.array_equal(out.numpy(), full[:, rows]), "decoded rows differ"
+        px = sc.gather_pixels(out)
         if rank == 0:
-            assert np.array_equal(px, img)
+            assert np.array_equal(px.numpy(), full)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
-        q.put((rank, repr(e)))
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
         raise
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,shape,tile,planar", [(2, (70, 50, 3), (32, 8), True), (2, (33, 9, 1), (16, 4), False), (3, (40, 20, 4), (40, 1), True), (2, (20, 5, 3), (8, 8), True)])
-def test_two_rank_shard_gather_stitch(world, shape, tile, planar):
+CASES = [
+    (2, ((70, 50, 3), (32, 8), True, 1, 4)),      # ragged last tile row, planar
+    (2, ((33, 9, 1), (16, 4), False, 2, 1)),      # contiguous bands (one chunk per rank), two images, interleaved channels
+    (3, ((40, 20, 4), (40, 1), True, 2, 2)),      # one-row slices, three ranks
+    (2, ((20, 5, 3), (8, 8), True, 1, 4)),        # a single tile row: rank 1 has nothing to code
+    (3, ((64, 37, 3), (16, 5), False, 3, 4)),     # 8 tile rows over 3 ranks x 4 chunks: uneven chunks, ragged tail
+]
+
+
+@pytest.mark.parametrize("world,case", CASES)
+def test_sharded_containers_equal_one_piece(world, case):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, tile, planar, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
     res = sorted(q.get(timeout=5) for _ in range(world))
     assert res == [(r, "ok") for r in range(world)], res
     assert all(p.exitcode == 0 for p in procs)
 
 
-def test_band_rows_cover_image():
+def test_chunk_plan_covers_image():
     from llcomp_amd import sharding
 
-    for h, th, world in [(2160, 64, 8), (8192, 128, 8), (5, 8, 2), (10, 1, 4), (7, 3, 3), (1, 1, 8)]:
-        bands = sharding.band_rows(h, th, world)
-        assert bands[0][0] == 0 and bands[-1][1] == h or any(b[1] == h for b in bands)
-        flat = [y for y0, y1 in bands for y in range(y0, y1)]
+    for h, th, world, cpr in [(2160, 64, 8, 4), (8192, 128, 8, 4), (8192, 1, 8, 4), (5, 8, 2, 4), (10, 1, 4, 1), (7, 3, 3, 2), (1, 1, 8, 4)]:
+        chunks = sharding.plan_chunks(h, th, world, cpr)
+        nty = (h + min(th, h) - 1) // min(th, h)
+        assert chunks[0][0] == 0 and chunks[-1][1] == nty
+        assert all(a[1] == b[0] for a, b in zip(chunks, chunks[1:])) and all(t1 > t0 for t0, t1, _ in chunks)
+        assert [o for _, _, o in chunks] == [i % world for i in range(len(chunks))]
+        sizes = [t1 - t0 for t0, t1, _ in chunks]
+        assert max(sizes) - min(sizes) <= 1
+        flat = sorted(y for r in range(world) for y0, y1 in sharding.local_rows(h, th, world, r, cpr) for y in range(y0, y1))
         assert flat == list(range(h))
-        for (y0, y1) in bands[:-1]:
-            assert y0 % min(th, h) == 0

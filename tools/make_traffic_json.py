@@ -26,7 +26,7 @@ def per_kernel(pattern):
     return {k: acc[k] / cnt[k] for k in acc}
 
 
-fetch, write = per_kernel("pmc_fetch"), per_kernel("pmc_write")
+fetch, write, sq1 = per_kernel("pmc_fetch"), per_kernel("pmc_write"), per_kernel("pmc_sq1")
 out = {}
 for (k, c), v in fetch.items():
     if "llcomp_mi" not in k:
@@ -36,6 +36,8 @@ for (k, c), v in fetch.items():
     short = m.group(1) if m else k
     w = write.get((k, "WRITE_SIZE"), 0.0)
     out[short] = {"fetch_size_kib": v, "write_size_kib": w, "hbm_bytes_corrected": int(2 * v * 1024 + w * 1024)}
+    if (k, "SQ_INSTS_VALU") in sq1:  # VALU wave-instructions per launch (bench.py: roofline.valu_issue)
+        out[short]["valu_insts"] = int(sq1[(k, "SQ_INSTS_VALU")])
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
 doc = {"config": bench["config"], "bench_value": bench["value"], "kernel_ms_per_step": bench["kernel_ms_per_step"], "per_launch": out,
        "correction": "bytes = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes); FETCH_SIZE = 1/2 of known read volume on this access pattern"}
