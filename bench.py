@@ -209,7 +209,7 @@ def profile_numbers(F, tile_w, tile_h, planar, content, S, dom):
     return None, None, None
 
 
-def c5_stream(frames_np, tile_w, tile_h, planar, depth=6):
+def c5_stream(frames_np, tile_w, tile_h, planar, depth=8):
     """BASELINE config 5, PCIe inclusive: the frames stream host -> GPU -> host (container) -> GPU -> host through the
     product's pipeline (llcomp_mi_stream_*), twice over the batch; every frame verified bit-exact."""
     import llcomp_amd as mi
@@ -220,7 +220,7 @@ def c5_stream(frames_np, tile_w, tile_h, planar, depth=6):
     views = [pinned.array[i * h * w * c:(i + 1) * h * w * c].reshape(h, w, c) for i in range(F)]
     st = mi.Stream(w, h, c, tile_w, tile_h, planar, depth=depth)
     jobs = views + views
-    lens, done_at, busy = mi.pipeline_roundtrip(st, jobs, max_encodes_in_flight=depth // 2, verify=True)
+    lens, done_at, busy = mi.pipeline_roundtrip(st, jobs, max_encodes_in_flight=3, verify=True)
     st.close()
     n = len(jobs)
     steady = (n - 4) * w * h / 1e6 / (done_at[-1] - done_at[3])

@@ -184,54 +184,77 @@ class Stream:
         _check(self._L.llcomp_mi_stream_release(self._h, job.slot))
 
 
-def pipeline_roundtrip(stream, frames, max_encodes_in_flight=3, on_container=None, verify=True):
+def pipeline_roundtrip(stream, frames, max_encodes_in_flight=3, on_container=None, verify=True, verify_threads=3):
     """Drives BASELINE config 5 through a Stream: every frame host -> GPU -> host (container) -> GPU -> host.  An encode
     result (pinned container) is handed to submit_decode as it is and released only when that decode has come back;
     submit_* returning False (back-pressure) makes the loop take a finished job first.  frames: list of C-contiguous
     uint8 arrays (pinned for DMA).  Returns (container lengths, completion time of every frame in seconds, number of
     times back-pressure was hit).  on_container(i, bytes_view) sees every container; verify compares every decoded frame
-    with its source bit for bit."""
+    with its source bit for bit -- on a few worker threads (numpy releases the GIL), the slot is released afterwards."""
     import time
+    from concurrent.futures import ThreadPoolExecutor
 
     n = len(frames)
     lens, done_at, busy_seen = [0] * n, [0.0] * n, 0
-    enc_held, to_decode = {}, []
+    enc_held, to_decode, checking = {}, [], []
     next_frame = finished = enc_in_flight = 0
+    pool = ThreadPoolExecutor(max_workers=verify_threads) if verify and verify_threads > 0 else None
+
+    def reap(block):
+        nonlocal finished
+        while checking and (block or checking[0][0].done()):
+            fut, job = checking.pop(0)
+            if not fut.result():
+                raise AssertionError(f"frame {job.tag} is not bit-exact after the round trip")
+            stream.release(job)
+            finished += 1
+            block = False
+
     t0 = time.perf_counter()
-    while finished < n:
-        progressed = False
-        while to_decode:  # containers first: their decode frees two slots
-            job = to_decode[0]
-            if not stream.submit_decode(job.data, tag=job.tag):
-                busy_seen += 1
-                break
-            enc_held[job.tag] = job
-            to_decode.pop(0)
-            progressed = True
-        while next_frame < n and enc_in_flight < max_encodes_in_flight and not to_decode:
-            if not stream.submit_encode(frames[next_frame], tag=next_frame):
-                busy_seen += 1
-                break
-            next_frame += 1
-            enc_in_flight += 1
-            progressed = True
-        if stream.pending() and (not progressed or stream.ready()):
-            job = stream.wait()
-            if job.status != OK:
-                raise LlcompError(job.status)
-            if job.kind == JOB_ENCODE:
-                enc_in_flight -= 1
-                lens[job.tag] = job.data.size
-                if on_container:
-                    on_container(job.tag, job.data)
-                to_decode.append(job)
-            else:
-                if verify and not np.array_equal(job.data, frames[job.tag]):
-                    raise AssertionError(f"frame {job.tag} is not bit-exact after the round trip")
-                done_at[job.tag] = time.perf_counter() - t0
-                stream.release(job)
-                stream.release(enc_held.pop(job.tag))
-                finished += 1
+    try:
+        while finished < n:
+            progressed = False
+            reap(False)
+            while to_decode:  # containers first: their decode frees two slots
+                job = to_decode[0]
+                if not stream.submit_decode(job.data, tag=job.tag):
+                    busy_seen += 1
+                    break
+                enc_held[job.tag] = job
+                to_decode.pop(0)
+                progressed = True
+            while next_frame < n and enc_in_flight < max_encodes_in_flight and not to_decode:
+                if not stream.submit_encode(frames[next_frame], tag=next_frame):
+                    busy_seen += 1
+                    break
+                next_frame += 1
+                enc_in_flight += 1
+                progressed = True
+            if stream.pending() and (not progressed or stream.ready()):
+                job = stream.wait()
+                if job.status != OK:
+                    raise LlcompError(job.status)
+                if job.kind == JOB_ENCODE:
+                    enc_in_flight -= 1
+                    lens[job.tag] = job.data.size
+                    if on_container:
+                        on_container(job.tag, job.data)
+                    to_decode.append(job)
+                else:
+                    done_at[job.tag] = time.perf_counter() - t0
+                    stream.release(enc_held.pop(job.tag))
+                    if pool:
+                        checking.append((pool.submit(np.array_equal, job.data, frames[job.tag]), job))
+                    else:
+                        if verify and not np.array_equal(job.data, frames[job.tag]):
+                            raise AssertionError(f"frame {job.tag} is not bit-exact after the round trip")
+                        stream.release(job)
+                        finished += 1
+            elif not progressed:
+                reap(True)  # every slot is held by a frame that is being compared
+    finally:
+        if pool:
+            pool.shutdown(wait=True)
     return lens, done_at, busy_seen
 
 

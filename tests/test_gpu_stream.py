@@ -140,7 +140,7 @@ def test_c5_stream_64_frames_4k(mi, orc):
         if i in pins:
             assert data.size == pins[i]["container_len"] and fnv_hex(orc, data.tobytes()) == pins[i]["container_fnv1a64"], f"frame {i}: golden mismatch"
 
-    lens, done_at, _ = run_stream(mi, frames, 480, 1, True, depth=6, max_encodes_in_flight=3, check=check)
+    lens, done_at, _ = run_stream(mi, frames, 480, 1, True, depth=8, max_encodes_in_flight=3, check=check)
     steady = (N - 4) * W * H / 1e6 / (done_at[-1] - done_at[3])
     ratio = N * W * H * C / sum(lens)
     print(f"\nC5 stream: {N} frames, steady state {steady:.0f} MPix/s end to end over PCIe (first 4 frames excluded), ratio {ratio:.4f} "

@@ -4,7 +4,10 @@
 // (/root/reference/llcompc.cpp:14-43): exactly one required positional argument, output written next to the input as
 // "<image>.llcomp", exit status 1 for usage, unreadable image or unwritable output, 0 otherwise.  stb_image is neither
 // vendored nor installed, so the image reader is tools/image_io.hpp (PNG, binary PGM / PPM / PAM).  Without options the
-// stream is the reference's own format; --sliced selects the parallel container.
+// stream is the reference's own format (magic 0x79), as a drop-in must: that is ONE serial range-coder chain, which a
+// GPU runs on a single lane -- many times slower than the CPU reference on a large image.  The
+// tool says so on stderr for images above one megapixel; --sliced TWxTH selects the parallel container (e.g. 480x1),
+// --legacy states the default explicitly and silences the note.
 #include <cstdio>
 #include <exception>
 #include <string>
@@ -16,11 +19,13 @@
 
 namespace {
 
-bool parse_flags(int argc, char** argv, llcomp::Options& opt) {
+bool parse_flags(int argc, char** argv, llcomp::Options& opt, bool& explicit_legacy) {
     for (int i = 2; i < argc; ++i) {
         const std::string flag = argv[i];
         if (flag == "--interleaved") {
             opt.planar = false;
+        } else if (flag == "--legacy") {
+            explicit_legacy = true;
         } else if (flag == "--sliced" && i + 1 < argc) {
             unsigned tw = 0, th = 0;
             if (std::sscanf(argv[++i], "%ux%u", &tw, &th) != 2) return false;
@@ -32,13 +37,17 @@ bool parse_flags(int argc, char** argv, llcomp::Options& opt) {
     return true;
 }
 
-int compress_file(const std::string& image_path, const llcomp::Options& opt) {
+int compress_file(const std::string& image_path, const llcomp::Options& opt, bool explicit_legacy) {
     std::vector<uint8_t> pixels;
     int w = 0, h = 0, c = 0;
     if (const std::string reason = image_io::load_image(image_path, pixels, w, h, c); !reason.empty()) {
         std::fprintf(stderr, "Error loading image: %s\n", reason.c_str());
         return cli::kFailed;
     }
+    if (!opt.sliced && !explicit_legacy && size_t(w) * size_t(h) > (1u << 20))
+        std::fprintf(stderr,
+                     "note: writing the reference's single-stream format (%dx%d): one serial chain = one GPU lane, slower than the CPU "
+                     "reference; use --sliced 480x1 (or e.g. 64x64) for the parallel container, --legacy to silence this note\n", w, h);
     std::vector<uint8_t> stream;
     try {
         stream = llcomp::compressImage(pixels, w, h, c, opt);
@@ -58,9 +67,10 @@ int compress_file(const std::string& image_path, const llcomp::Options& opt) {
 
 int main(int argc, char** argv) {
     llcomp::Options opt;
-    if (argc < 2 || !parse_flags(argc, argv, opt)) {
-        std::fprintf(stderr, "Usage: %s <image_path> [--sliced TWxTH] [--interleaved]\n", argc ? argv[0] : "llcompc");
+    bool explicit_legacy = false;
+    if (argc < 2 || !parse_flags(argc, argv, opt, explicit_legacy)) {
+        std::fprintf(stderr, "Usage: %s <image_path> [--sliced TWxTH] [--interleaved] [--legacy]\n", argc ? argv[0] : "llcompc");
         return cli::kFailed;
     }
-    return compress_file(argv[1], opt);
+    return compress_file(argv[1], opt, explicit_legacy);
 }
