@@ -14,8 +14,9 @@ workload on one GPU (the N = 1 point of the strong-scaling curve).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL over xGMI): BASELINE config 4, STRONG scaling -- a fixed
 batch of 8192x8192 RGB8 images, every image sharded over all ranks by interleaved chunks of tile rows
-(llcomp_amd/sharding.py): local encode, slice-table all_gather, one payload message per rank to rank 0, device
-concatenator -> one container per image on rank 0; decode mirrors it.  The gather / scatter is inside the timed region,
+(llcomp_amd/sharding.py): local encode, slice-table all_gather, one variable-size all-to-all of the payloads (image b is
+gathered on rank b % N), device concatenator -> complete containers spread over the ranks; decode mirrors it.  The exchange is
+inside the timed region,
 container 0 is compared with the one-piece container.  `replica` = the config-3 workload with frames sharded over the ranks
 (no data-path collective, weak scaling), a few steps, as a second key.
 """
@@ -242,21 +243,23 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     dev = torch.device("cuda", local_rank)
     sc = sharding.ShardedCodec(size, size, 3, tile_w, tile_h, True, images=images, device=dev)
     # uniform byte noise (torch Philox, seed 1234 + image): every rank draws the full image on its GPU and keeps its rows
-    bands, first = [], None
+    bands, first = {}, None
     for b in range(images):
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + b)
         full = torch.randint(0, 256, (1, size, size, 3), dtype=torch.uint8, device=dev, generator=g)
-        bands.append(torch.cat([full[:, y0:y1] for y0, y1 in sc.rows], dim=1) if sc.rows else full[:, :0])
-        if b == 0 and rank == 0 and check_one_piece:
+        bands[b] = torch.cat([full[:, y0:y1] for y0, y1 in sc.rows], dim=1) if sc.rows else full[:, :0]
+        if b == 0 and rank == sc.root_of[0] and check_one_piece:
             first = full[0].cpu().numpy()
         del full
-    band = torch.cat(bands, dim=0).contiguous()
+    band = torch.cat([bands[b] for b in sc.frame_images], dim=0).contiguous()  # frames in the codec's order
     del bands
     conts = sc.encode(band)
     out = sc.decode(conts)
     assert torch.equal(out, band), "sharded round trip is not lossless"
-    payload_bytes = sum(int(c_.numel()) for c_ in conts) if rank == 0 else 0
+    pb = torch.tensor([sum(int(c_.numel()) for c_ in conts.values())], dtype=torch.int64, device=dev)
+    dist.all_reduce(pb, op=dist.ReduceOp.SUM)
+    payload_bytes = int(pb.item())
     if first is not None:
         one = mi.compress_image(first, size, size, 3, format=mi.FORMAT_SLICED, tile_w=tile_w, tile_h=tile_h, planar=True, device=local_rank)
         assert bytes(conts[0].cpu().numpy()) == one, "sharded container differs from the one-piece container"
@@ -296,6 +299,8 @@ def main():
     ap.add_argument("--c4-images", type=int, default=8, help="8192x8192 images per step of the sharded (config 4) workload")
     ap.add_argument("--c4-tile-w", type=int, default=512)
     ap.add_argument("--c4-tile-h", type=int, default=1)
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="rehearsal of the N > 1 code path on a one-GPU box: all ranks use cuda:0 and exchange over gloo (RCCL refuses two ranks on one device); the numbers mean nothing")
     args = ap.parse_args()
 
     import numpy as np
@@ -306,7 +311,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.rehearse_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available() or mi.device_count() < 1:
@@ -320,7 +325,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
         sk.close()
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if args.rehearse_one_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     barrier = dist.barrier if world > 1 else None
 
     planar = not args.interleaved
@@ -346,11 +354,12 @@ def main():
                 "config": {
                     "workload": f"C4 {B} x 8192x8192 RGB8 uniform noise per step (fixed total), every image sharded over {world} GPUs by interleaved "
                                 f"chunks of tile rows; sliced container {args.c4_tile_w}x{args.c4_tile_h} tiles, per-channel planes; per step: local encode, "
-                                f"slice-table all_gather, one payload message per rank to rank 0 over RCCL, device concatenator -> {B} containers on rank 0; "
-                                f"then table broadcast, payload scatter, local decode (decoded rows stay on their ranks)",
+                                f"slice-table all_gather, variable-size all-to-all of the packed payloads over RCCL (image b is gathered on rank b % {world}), "
+                                f"device concatenator -> {B} complete containers spread over the ranks; then table all_gather, all-to-all back, local decode "
+                                f"(decoded rows stay on their ranks)",
                     "images_per_step": B, "tile_w": args.c4_tile_w, "tile_h": args.c4_tile_h, "planar": True, "content": "uniform noise (torch Philox, seed 1234+i)",
                     "compression_ratio": round(raw / payload, 4),
-                    "parallelism": f"tile-row chunks of every image round-robin over {world} GPUs; exchange = all_gather(lengths) + send/recv(payload) per direction",
+                    "parallelism": f"tile-row chunks of every image round-robin over {world} GPUs; exchange = all_gather(lengths) + alltoallv(payload) per direction",
                     "one_gpu_point": "the N=1 run reports the same workload under also.c4_sharded_one_gpu",
                 },
                 "roofline": {"bound": "hbm", "kernel": "whole step (sharded)", "achieved": round(2 * (raw + payload) * args.steps / dt / 1e9, 3),

@@ -29,8 +29,11 @@ extern "C" {
 /* Wire formats.  LEGACY is the reference's own: [0x79][channels u8][width u16 LE][height u16 LE] + ONE
  * range-coded stream (llcomp.hpp:375-378); it is a single serial chain (one GPU lane).  SLICED is this
  * project's container: independent slices, each a bare reference-compatible stream with fresh state:
- *   [0x9C][ver=1][channels][flags bit0=planar] [w u32][h u32][tile_w u32][tile_h u32][n_slices u32]
- *   [len u32] x n_slices  [payload bytes ...]                                  (all little-endian) */
+ *   [0x9C][ver=1][channels][flags bit0=planar, bit1=small model] [w u32][h u32][tile_w u32][tile_h u32][n_slices u32]
+ *   [len u32] x n_slices  [payload bytes ...]                                  (all little-endian)
+ * "Small model" = the bitstream of a reference built with `LargeModel = false` (llcomp.hpp:21, 26-32, 427-429: the two
+ * quant5 terms are left out of the context).  The reference's header does not record that build option (the magic
+ * stays 0x79), so for the LEGACY format the caller has to say so on both sides; the SLICED header carries a flag. */
 #define LLCOMP_MI_MAGIC_LEGACY 0x79
 #define LLCOMP_MI_MAGIC_SLICED 0x9C
 #define LLCOMP_MI_SLICED_HEADER_BYTES 24
@@ -58,7 +61,10 @@ typedef struct llcomp_mi_opts {
     uint32_t tile_h;      /* slice height in pixels, 0 = full height  (SLICED only) */
     uint32_t planar;      /* 1 = one slice per colour-transformed channel plane, 0 = channels interleaved */
     int32_t device;       /* HIP device ordinal, -1 = current device */
+    uint32_t small_model; /* 1 = code like a reference built with LargeModel = false.  This field was added in ABI 2:
+                             struct_size 24 (without it) is still accepted and means 0. */
 } llcomp_mi_opts;
+#define LLCOMP_MI_FLAG_SMALL_MODEL 1u /* llcomp_mi_decode_flags / llcomp_mi_codec_create_ex */
 
 /* ---- host-buffer API: drop-in for compressImage / decompressImage ------------------------------------ */
 /* px: h*w*c bytes, row-major, channels interleaved (exactly the reference's `rgb` vector).  opts==NULL means
@@ -68,6 +74,10 @@ int llcomp_mi_encode(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, cons
 /* Accepts either wire format (dispatch on the magic byte).  *px allocated by the library. */
 int llcomp_mi_decode(const uint8_t* data, size_t len, int32_t device, uint8_t** px, uint32_t* w, uint32_t* h,
                      uint32_t* c);
+/* The same with flags: LLCOMP_MI_FLAG_SMALL_MODEL = a LEGACY stream that was written with the small model (a SLICED
+ * container says so itself; the flag is ignored for it). */
+int llcomp_mi_decode_flags(const uint8_t* data, size_t len, int32_t device, uint32_t flags, uint8_t** px, uint32_t* w,
+                           uint32_t* h, uint32_t* c);
 void llcomp_mi_free(void* p);
 /* The same two calls with CALLER-PROVIDED output buffers (nothing is allocated for the caller).  If the capacity is too
  * small they return LLCOMP_MI_OUTPUT_OVERFLOW and report what it takes (*out_len; *w,*h,*c), and nothing is written.
@@ -92,6 +102,8 @@ typedef struct llcomp_mi_info {
     uint32_t format, channels, width, height, tile_w, tile_h, planar, n_slices;
     uint64_t table_offset;   /* byte offset of the slice length table (0 for LEGACY) */
     uint64_t payload_offset; /* byte offset of the first payload byte */
+    uint32_t small_model;    /* SLICED: the header's small-model flag; LEGACY: always 0 (not recorded in that header) */
+    uint32_t reserved;
 } llcomp_mi_info;
 int llcomp_mi_probe(const uint8_t* data, size_t len, llcomp_mi_info* info);
 uint32_t llcomp_mi_slice_count(uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar);
@@ -111,6 +123,9 @@ int llcomp_mi_split_band(const uint8_t* data, size_t len, uint32_t tile_row0, ui
 typedef struct llcomp_mi_codec llcomp_mi_codec;
 int llcomp_mi_codec_create(llcomp_mi_codec** codec, int32_t device, uint32_t frames, uint32_t w, uint32_t h,
                            uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar);
+/* flags: LLCOMP_MI_FLAG_SMALL_MODEL */
+int llcomp_mi_codec_create_ex(llcomp_mi_codec** codec, int32_t device, uint32_t frames, uint32_t w, uint32_t h,
+                              uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar, uint32_t flags);
 void llcomp_mi_codec_destroy(llcomp_mi_codec* codec);
 uint32_t llcomp_mi_codec_slices(const llcomp_mi_codec* codec);        /* total = frames * slices per frame */
 uint64_t llcomp_mi_codec_workspace_bytes(const llcomp_mi_codec* codec);

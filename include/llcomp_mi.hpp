@@ -35,6 +35,7 @@ struct Options {
     uint32_t tile_h = 0;    // slice height (0 = full height)
     bool planar = true;     // one slice per colour-transformed channel plane
     int device = -1;        // HIP device ordinal, -1 = current
+    bool small_model = false;  // bitstream of a reference built with LargeModel = false (llcomp.hpp:21)
 };
 
 struct RawImage {
@@ -64,6 +65,7 @@ inline std::vector<uint8_t> compressImage(const std::vector<uint8_t>& rgb, int w
     o.tile_h = opt.tile_h;
     o.planar = opt.planar ? 1u : 0u;
     o.device = opt.device;
+    o.small_model = opt.small_model ? 1u : 0u;
     uint8_t* out = nullptr;
     size_t n = 0;
     if (int rc = llcomp_mi_encode(rgb.data(), uint32_t(width), uint32_t(height), uint32_t(channels), &o, &out, &n))
@@ -73,10 +75,11 @@ inline std::vector<uint8_t> compressImage(const std::vector<uint8_t>& rgb, int w
     return v;
 }
 
-inline RawImage decompressImage(const std::vector<uint8_t>& data, int device = -1) {
+inline RawImage decompressImage(const std::vector<uint8_t>& data, int device = -1, bool legacy_small_model = false) {
     uint8_t* px = nullptr;
     uint32_t w = 0, h = 0, c = 0;
-    if (int rc = llcomp_mi_decode(data.data(), data.size(), device, &px, &w, &h, &c)) detail::raise(rc);
+    if (int rc = llcomp_mi_decode_flags(data.data(), data.size(), device, legacy_small_model ? LLCOMP_MI_FLAG_SMALL_MODEL : 0u, &px, &w, &h, &c))
+        detail::raise(rc);
     RawImage img{std::vector<uint8_t>(px, px + size_t(w) * h * c), w, h, uint8_t(c)};
     llcomp_mi_free(px);
     return img;

@@ -43,14 +43,16 @@ def device_count():
     return _lib.load().llcomp_mi_device_count()
 
 
-def compress_image(rgb, width, height, channels, *, format=FORMAT_LEGACY, tile_w=0, tile_h=0, planar=False, device=-1):
+def compress_image(rgb, width, height, channels, *, format=FORMAT_LEGACY, tile_w=0, tile_h=0, planar=False, device=-1, small_model=False):
     """bytes of an llcomp stream.  Default = the reference's own whole-image format (magic 0x79), byte-identical to
-    llcomp::compressImage; format=FORMAT_SLICED produces the parallel container (magic 0x9C)."""
+    llcomp::compressImage; format=FORMAT_SLICED produces the parallel container (magic 0x9C).  small_model=True codes like
+    a reference built with LargeModel = false (llcomp.hpp:21); a legacy stream does not record that, so it must be passed
+    to decompress_image as well."""
     L = _lib.load()
     buf = np.ascontiguousarray(np.frombuffer(rgb, dtype=np.uint8) if isinstance(rgb, (bytes, bytearray, memoryview)) else rgb, dtype=np.uint8).reshape(-1)
     if buf.size != width * height * channels:  # the reference only asserts this (llcomp.hpp:361)
         raise LlcompError(BAD_ARGS)
-    o = Opts(C.sizeof(Opts), format, tile_w, tile_h, int(bool(planar)), device)
+    o = Opts(C.sizeof(Opts), format, tile_w, tile_h, int(bool(planar)), device, int(bool(small_model)))
     out, n = _lib.u8p(), C.c_size_t()
     _check(L.llcomp_mi_encode(buf.ctypes.data_as(_lib.u8p), width, height, channels, C.byref(o), C.byref(out), C.byref(n)))
     try:
@@ -59,13 +61,13 @@ def compress_image(rgb, width, height, channels, *, format=FORMAT_LEGACY, tile_w
         L.llcomp_mi_free(out)
 
 
-def decompress_image(data, *, device=-1):
+def decompress_image(data, *, device=-1, small_model=False):
     """RawImage(pixels: np.uint8[h,w,c], width, height, channels) from either wire format."""
     L = _lib.load()
     data = bytes(data)  # no copy when it already is bytes
     src = C.cast(C.c_char_p(data or b"\0"), _lib.u8p)  # borrows the bytes object's buffer for the call
     px, w, h, c = _lib.u8p(), C.c_uint32(), C.c_uint32(), C.c_uint32()
-    _check(L.llcomp_mi_decode(src, len(data), device, C.byref(px), C.byref(w), C.byref(h), C.byref(c)))
+    _check(L.llcomp_mi_decode_flags(src, len(data), device, 1 if small_model else 0, C.byref(px), C.byref(w), C.byref(h), C.byref(c)))
     try:
         n = w.value * h.value * c.value
         pixels = np.ctypeslib.as_array(px, shape=(max(n, 1),))[:n].copy().reshape(h.value, w.value, c.value)
@@ -104,7 +106,7 @@ def compress_image_into(rgb, width, height, channels, out, *, format=FORMAT_LEGA
     """llcomp_mi_encode_into: `rgb` and `out` are numpy uint8 arrays owned by the caller (pinned: PinnedBuffer.array);
     returns the container length.  Raises LlcompError(OUTPUT_OVERFLOW) with .needed set when `out` is too small."""
     L = _lib.load()
-    o = Opts(C.sizeof(Opts), format, tile_w, tile_h, int(bool(planar)), device)
+    o = Opts(C.sizeof(Opts), format, tile_w, tile_h, int(bool(planar)), device, 0)
     n = C.c_size_t()
     rc = L.llcomp_mi_encode_into(rgb.ctypes.data, width, height, channels, C.byref(o), out.ctypes.data, out.size, C.byref(n))
     if rc != OK:
@@ -303,10 +305,10 @@ class Codec:
     Pointers are raw device addresses (e.g. torch tensor .data_ptr()); `stream` is a hipStream_t handle
     (torch.cuda.current_stream().cuda_stream) or 0."""
 
-    def __init__(self, frames, w, h, c, tile_w=0, tile_h=0, planar=False, device=-1):
+    def __init__(self, frames, w, h, c, tile_w=0, tile_h=0, planar=False, device=-1, small_model=False):
         self._L = _lib.load()
         self._h = C.c_void_p()
-        _check(self._L.llcomp_mi_codec_create(C.byref(self._h), device, frames, w, h, c, tile_w, tile_h, int(bool(planar))))
+        _check(self._L.llcomp_mi_codec_create_ex(C.byref(self._h), device, frames, w, h, c, tile_w, tile_h, int(bool(planar)), 1 if small_model else 0))
         self.frames, self.w, self.h, self.c = frames, w, h, c
         self.n_slices = self._L.llcomp_mi_codec_slices(self._h)
         self.max_payload_bytes = self._L.llcomp_mi_codec_max_payload_bytes(self._h)

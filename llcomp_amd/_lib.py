@@ -17,7 +17,7 @@ SYMBOLS = [
     "llcomp_mi_codec_decode", "llcomp_mi_codec_model", "llcomp_mi_status_from_bits",
     "llcomp_mi_codec_set_profiling", "llcomp_mi_codec_get_profile",
     "llcomp_mi_encode_into", "llcomp_mi_decode_into", "llcomp_mi_host_alloc", "llcomp_mi_host_free",
-    "llcomp_mi_reload_tuning", "llcomp_mi_device_copy_segments",
+    "llcomp_mi_reload_tuning", "llcomp_mi_device_copy_segments", "llcomp_mi_decode_flags", "llcomp_mi_codec_create_ex",
     "llcomp_mi_stream_create", "llcomp_mi_stream_destroy", "llcomp_mi_stream_container_capacity",
     "llcomp_mi_stream_submit_encode", "llcomp_mi_stream_submit_decode", "llcomp_mi_stream_pending",
     "llcomp_mi_stream_poll", "llcomp_mi_stream_wait", "llcomp_mi_stream_release",
@@ -28,13 +28,13 @@ u8p = C.POINTER(C.c_uint8)
 
 class Opts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("format", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32),
-                ("planar", C.c_uint32), ("device", C.c_int32)]
+                ("planar", C.c_uint32), ("device", C.c_int32), ("small_model", C.c_uint32)]
 
 
 class Info(C.Structure):
     _fields_ = [("format", C.c_uint32), ("channels", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
                 ("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("planar", C.c_uint32), ("n_slices", C.c_uint32),
-                ("table_offset", C.c_uint64), ("payload_offset", C.c_uint64)]
+                ("table_offset", C.c_uint64), ("payload_offset", C.c_uint64), ("small_model", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class StreamResult(C.Structure):
@@ -127,6 +127,10 @@ def load():
     L.llcomp_mi_host_free.argtypes = [C.c_void_p]
     L.llcomp_mi_device_copy_segments.restype = C.c_int
     L.llcomp_mi_device_copy_segments.argtypes = [C.c_void_p] * 5 + [C.c_uint32, C.c_uint64, C.c_void_p]
+    L.llcomp_mi_decode_flags.restype = C.c_int
+    L.llcomp_mi_decode_flags.argtypes = [u8p, C.c_size_t, C.c_int32, C.c_uint32, C.POINTER(u8p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.llcomp_mi_codec_create_ex.restype = C.c_int
+    L.llcomp_mi_codec_create_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int32] + [C.c_uint32] * 8
     L.llcomp_mi_reload_tuning.restype = None
     L.llcomp_mi_reload_tuning.argtypes = []
     L.llcomp_mi_stream_create.restype = C.c_int

@@ -126,13 +126,19 @@ void llcomp_mi_free(void* p) { std::free(p); }
 // ---- device-resident codec ------------------------------------------------------------------------------------
 int llcomp_mi_codec_create(llcomp_mi_codec** out, int32_t device, uint32_t frames, uint32_t w, uint32_t h, uint32_t c,
                            uint32_t tile_w, uint32_t tile_h, uint32_t planar) {
-    if (!out) return LLCOMP_MI_BAD_ARGS;
+    return llcomp_mi_codec_create_ex(out, device, frames, w, h, c, tile_w, tile_h, planar, 0);
+}
+
+int llcomp_mi_codec_create_ex(llcomp_mi_codec** out, int32_t device, uint32_t frames, uint32_t w, uint32_t h, uint32_t c,
+                              uint32_t tile_w, uint32_t tile_h, uint32_t planar, uint32_t flags) {
+    if (!out || (flags & ~LLCOMP_MI_FLAG_SMALL_MODEL)) return LLCOMP_MI_BAD_ARGS;
     *out = nullptr;
     if (!frames) return LLCOMP_MI_BAD_ARGS;
     if (int rc = check_shape(w, h, c, false)) return rc;
     Geometry g;
     // kernel family and lane-group width are fixed here, for the life of the codec object
-    if (!make_geometry(g, frames, w, h, c, tile_w, tile_h, planar, current_tuning())) return LLCOMP_MI_OUT_OF_RANGE;
+    if (!make_geometry(g, frames, w, h, c, tile_w, tile_h, planar, current_tuning(), (flags & LLCOMP_MI_FLAG_SMALL_MODEL) != 0))
+        return LLCOMP_MI_OUT_OF_RANGE;
     int dev = 0;
     if (int rc = resolve_device(device, &dev)) return rc;
     DeviceGuard guard(dev);

@@ -81,7 +81,7 @@ struct HostLane {
 };
 // builds a lane for this shape on `dev` (geometry + tuning hooks are fixed here); payload capacity `cap` bytes
 int lane_create(HostLane** out, int dev, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar,
-                bool legacy, uint64_t payload_cap);
+                bool legacy, uint64_t payload_cap, bool small_model = false);
 int lane_grow(HostLane* l, uint64_t payload_cap);  // reallocates the container buffer (contents lost)
 void lane_destroy(HostLane* l);
 // enqueue on the lane's stream (asynchronous): frame in d_px -> container in d_container, {bytes, status} -> h_meta

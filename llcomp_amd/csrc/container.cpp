@@ -18,7 +18,8 @@ void write_legacy_header(uint8_t* o, uint32_t w, uint32_t h, uint32_t c) {
 }
 
 void write_sliced_header(uint8_t* o, const Geometry& g) {
-    o[0] = LLCOMP_MI_MAGIC_SLICED; o[1] = 1; o[2] = uint8_t(g.c); o[3] = uint8_t(g.planar ? 1 : 0);
+    o[0] = LLCOMP_MI_MAGIC_SLICED; o[1] = 1; o[2] = uint8_t(g.c);
+    o[3] = uint8_t((g.planar ? 1 : 0) | ((g.flags & kGeoSmallModel) ? 2 : 0));
     put_u32le(o + 4, g.w); put_u32le(o + 8, g.h);
     put_u32le(o + 12, g.tile_w); put_u32le(o + 16, g.tile_h);
     put_u32le(o + 20, g.slices_per_frame);
@@ -59,7 +60,9 @@ int llcomp_mi_probe(const uint8_t* data, size_t len, llcomp_mi_info* info) {
         if (data[1] != 1) return LLCOMP_MI_BAD_ARGS;
         info->format = LLCOMP_MI_FORMAT_SLICED;
         info->channels = data[2];
+        if (data[3] & ~3u) return LLCOMP_MI_BAD_ARGS;  // unknown flag bits
         info->planar = data[3] & 1;
+        info->small_model = (data[3] >> 1) & 1;
         info->width = get_u32le(data + 4);
         info->height = get_u32le(data + 8);
         info->tile_w = get_u32le(data + 12);
@@ -90,7 +93,7 @@ int llcomp_mi_merge_bands(const uint8_t* const* bands, const size_t* band_lens, 
         const llcomp_mi_info& a = infos[i];
         const llcomp_mi_info& f = infos[0];
         if (a.format != LLCOMP_MI_FORMAT_SLICED) return LLCOMP_MI_BAD_ARGS;
-        if (a.width != f.width || a.channels != f.channels || a.planar != f.planar || a.tile_w != f.tile_w)
+        if (a.width != f.width || a.channels != f.channels || a.planar != f.planar || a.tile_w != f.tile_w || a.small_model != f.small_model)
             return LLCOMP_MI_BAD_ARGS;
         // every band but the last must be whole tile rows of the common tile height; the last may be shorter
         // (then its own tile_h was clamped to its height)
@@ -109,7 +112,7 @@ int llcomp_mi_merge_bands(const uint8_t* const* bands, const size_t* band_lens, 
     if (height >= (1ull << 31) || n_slices >= (1ull << 31)) return LLCOMP_MI_OUT_OF_RANGE;
     Geometry g;
     if (!make_geometry(g, 1, infos[0].width, uint32_t(height), infos[0].channels, infos[0].tile_w, infos[0].tile_h,
-                       infos[0].planar) ||
+                       infos[0].planar, Tuning{}, infos[0].small_model != 0) ||
         g.slices_per_frame != n_slices)
         return LLCOMP_MI_BAD_ARGS;
     const size_t head = LLCOMP_MI_SLICED_HEADER_BYTES + 4 * size_t(n_slices);
@@ -154,7 +157,7 @@ int llcomp_mi_split_band(const uint8_t* data, size_t len, uint32_t tile_row0, ui
     const uint32_t y1 = tile_row1 * a.tile_h < a.height ? tile_row1 * a.tile_h : a.height;
     Geometry g;
     const uint32_t band_h = y1 - y0;
-    if (!make_geometry(g, 1, a.width, band_h, a.channels, a.tile_w, a.tile_h < band_h ? a.tile_h : band_h, a.planar) ||
+    if (!make_geometry(g, 1, a.width, band_h, a.channels, a.tile_w, a.tile_h < band_h ? a.tile_h : band_h, a.planar, Tuning{}, a.small_model != 0) ||
         g.slices_per_frame != s1 - s0)
         return LLCOMP_MI_BAD_ARGS;
     const size_t head = LLCOMP_MI_SLICED_HEADER_BYTES + 4 * size_t(s1 - s0);

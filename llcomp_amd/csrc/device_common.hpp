@@ -37,9 +37,10 @@ __device__ __forceinline__ Hood apply_borders(int l_raw, int L_raw, int t_raw, i
     n.T = ly > 1 ? T_raw : n.t;
     return n;
 }
-__device__ __forceinline__ int context_hash(const Hood& n) {
-    return quant11(n.l - n.tl) + 11 * quant11(n.tl - n.t) + 121 * quant11(n.t - n.tr) + 605 * quant5(n.L - n.l) +
-           3025 * quant5(n.T - n.t);
+// `small` = the reference built with LargeModel = false (llcomp.hpp:21, 427-429): the two quant5 terms are left out.
+__device__ __forceinline__ int context_hash(const Hood& n, bool small = false) {
+    const int h3 = quant11(n.l - n.tl) + 11 * quant11(n.tl - n.t) + 121 * quant11(n.t - n.tr);
+    return small ? h3 : h3 + 605 * quant5(n.L - n.l) + 3025 * quant5(n.T - n.t);
 }
 __device__ __forceinline__ int predict(const Hood& n) { return median3(n.l, n.l + n.t - n.tl, n.t); }
 

@@ -35,6 +35,7 @@ enum : uint32_t {
     kGeoRows = 1u,         // 1-row slices: the three reachable contexts' states live in LDS
     kGeoLdsTable = 2u,     // one slice per wavefront: its 63 KB state table lives in LDS
     kGeoForceReplay = 4u,  // test hook: every decoded sample also goes through rollback + checked replay
+    kGeoSmallModel = 8u,   // bitstream variant: the reference built with LargeModel = false (llcomp.hpp:21, 26-32, 427-429)
 };
 
 // Test / tuning hooks.  They are read from the environment ONCE per process (codec.hip: current_tuning; a test that
@@ -103,7 +104,7 @@ inline uint32_t default_lane_shift(uint32_t n_slices) {
 }
 
 inline bool make_geometry(Geometry& g, uint32_t frames, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w,
-                          uint32_t tile_h, uint32_t planar, const Tuning& tune = Tuning{}) {
+                          uint32_t tile_h, uint32_t planar, const Tuning& tune = Tuning{}, bool small_model = false) {
     if (!frames || !w || !h || c < 1 || c > kMaxChannels) return false;
     if (tile_w == 0 || tile_w > w) tile_w = w;
     if (tile_h == 0 || tile_h > h) tile_h = h;
@@ -136,6 +137,7 @@ inline bool make_geometry(Geometry& g, uint32_t frames, uint32_t w, uint32_t h, 
     if (g.tile_h == 1 && !tune.norows && g.nch <= 4) g.flags |= kGeoRows;  // (the register-resident row kernels exist for 1..4 channels)
     else if (g.lpw == 1 && !tune.noldstab) g.flags |= kGeoLdsTable;
     if (tune.force_replay) g.flags |= kGeoForceReplay;
+    if (small_model) g.flags |= kGeoSmallModel;
     return true;
 }
 

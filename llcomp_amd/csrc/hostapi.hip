@@ -66,12 +66,12 @@ int lane_grow(HostLane* l, uint64_t payload_cap) {
 }
 
 int lane_create(HostLane** out, int dev, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar,
-                bool legacy, uint64_t payload_cap) {
+                bool legacy, uint64_t payload_cap, bool small_model) {
     *out = nullptr;
     HostLane* l = new (std::nothrow) HostLane;
     if (!l) return LLCOMP_MI_NOMEM;
     l->legacy = legacy;
-    if (int rc = llcomp_mi_codec_create(&l->k, dev, 1, w, h, c, tile_w, tile_h, planar)) {
+    if (int rc = llcomp_mi_codec_create_ex(&l->k, dev, 1, w, h, c, tile_w, tile_h, planar, small_model ? LLCOMP_MI_FLAG_SMALL_MODEL : 0)) {
         delete l;
         return rc;
     }
@@ -162,14 +162,14 @@ LaneCache& lane_cache() {
 }
 
 int acquire_lane(HostLane** out, int32_t device, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar,
-                 bool legacy, uint64_t min_cap) {
+                 bool legacy, uint64_t min_cap, bool small_model) {
     Geometry g;
     std::memset(&g, 0, sizeof(g));
-    if (!make_geometry(g, 1, w, h, c, tile_w, tile_h, planar, current_tuning())) return LLCOMP_MI_OUT_OF_RANGE;
+    if (!make_geometry(g, 1, w, h, c, tile_w, tile_h, planar, current_tuning(), small_model)) return LLCOMP_MI_OUT_OF_RANGE;
     int dev = 0;
     if (int rc = resolve_device(device, &dev)) return rc;
     if ((*out = lane_cache().take(dev, g, legacy))) return lane_grow(*out, min_cap);
-    return lane_create(out, dev, w, h, c, tile_w, tile_h, planar, legacy, min_cap);
+    return lane_create(out, dev, w, h, c, tile_w, tile_h, planar, legacy, min_cap, small_model);
 }
 
 struct LaneLease {  // returns the lane to the cache on every exit path
@@ -185,9 +185,10 @@ int encode_common(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, const l
     o.struct_size = sizeof(o);
     o.format = LLCOMP_MI_FORMAT_LEGACY;
     o.device = -1;
-    if (opts) {
-        if (opts->struct_size != sizeof(llcomp_mi_opts)) return LLCOMP_MI_BAD_ARGS;
-        o = *opts;
+    if (opts) {  // struct_size 24 = the ABI-1 layout without small_model
+        if (opts->struct_size != sizeof(llcomp_mi_opts) && opts->struct_size != 24) return LLCOMP_MI_BAD_ARGS;
+        std::memcpy(&o, opts, opts->struct_size);
+        if (o.small_model > 1) return LLCOMP_MI_BAD_ARGS;
     }
     if (o.format != LLCOMP_MI_FORMAT_LEGACY && o.format != LLCOMP_MI_FORMAT_SLICED) return LLCOMP_MI_BAD_ARGS;
     const bool legacy = o.format == LLCOMP_MI_FORMAT_LEGACY;
@@ -200,7 +201,7 @@ int encode_common(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, const l
     LaneLease lease;
     // first try with room for 2x raw (incompressible noise needs ~1.25x), then the proven worst case
     const uint64_t first_cap = 2 * raw + 64ull * llcomp_mi_slice_count(w, h, c, tile_w, tile_h, planar) + 4096;
-    if (int rc = acquire_lane(&lease.l, o.device, w, h, c, tile_w, tile_h, planar, legacy, 0)) return rc;
+    if (int rc = acquire_lane(&lease.l, o.device, w, h, c, tile_w, tile_h, planar, legacy, 0, o.small_model != 0)) return rc;
     HostLane* l = lease.l;
     const uint64_t max_payload = llcomp_mi_codec_max_payload_bytes(l->k);
     if (int rc = lane_grow(l, std::min(first_cap, max_payload))) return rc;
@@ -238,8 +239,9 @@ int encode_common(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, const l
     return LLCOMP_MI_OK;
 }
 
-int decode_common(const uint8_t* data, size_t len, int32_t device, uint8_t* px, size_t px_cap, uint8_t** px_alloc, uint32_t* w,
-                  uint32_t* h, uint32_t* c) {
+int decode_common(const uint8_t* data, size_t len, int32_t device, uint32_t flags, uint8_t* px, size_t px_cap, uint8_t** px_alloc,
+                  uint32_t* w, uint32_t* h, uint32_t* c) {
+    if (flags & ~LLCOMP_MI_FLAG_SMALL_MODEL) return LLCOMP_MI_BAD_ARGS;
     llcomp_mi_info info;
     if (int rc = llcomp_mi_probe(data, len, &info)) return rc;
     const bool legacy = info.format == LLCOMP_MI_FORMAT_LEGACY;
@@ -251,7 +253,7 @@ int decode_common(const uint8_t* data, size_t len, int32_t device, uint8_t* px, 
     if (px && raw > px_cap) return LLCOMP_MI_OUTPUT_OVERFLOW;  // dimensions are reported: the caller can size its buffer
     LaneLease lease;
     if (int rc = acquire_lane(&lease.l, device, info.width, info.height, info.channels, info.tile_w, info.tile_h, info.planar, legacy,
-                              len - info.payload_offset + 16))
+                              len - info.payload_offset + 16, legacy ? (flags & LLCOMP_MI_FLAG_SMALL_MODEL) != 0 : info.small_model != 0))
         return rc;
     HostLane* l = lease.l;
     DeviceGuard guard(l->k->device);
@@ -295,13 +297,20 @@ int llcomp_mi_encode_into(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c,
 int llcomp_mi_decode(const uint8_t* data, size_t len, int32_t device, uint8_t** px, uint32_t* w, uint32_t* h, uint32_t* c) {
     if (!data || !px || !w || !h || !c) return LLCOMP_MI_BAD_ARGS;
     *px = nullptr;
-    return decode_common(data, len, device, nullptr, 0, px, w, h, c);
+    return decode_common(data, len, device, 0, nullptr, 0, px, w, h, c);
+}
+
+int llcomp_mi_decode_flags(const uint8_t* data, size_t len, int32_t device, uint32_t flags, uint8_t** px, uint32_t* w, uint32_t* h,
+                           uint32_t* c) {
+    if (!data || !px || !w || !h || !c) return LLCOMP_MI_BAD_ARGS;
+    *px = nullptr;
+    return decode_common(data, len, device, flags, nullptr, 0, px, w, h, c);
 }
 
 int llcomp_mi_decode_into(const uint8_t* data, size_t len, int32_t device, uint8_t* px, size_t px_cap, uint32_t* w, uint32_t* h,
                           uint32_t* c) {
     if (!data || !px || !w || !h || !c) return LLCOMP_MI_BAD_ARGS;
-    return decode_common(data, len, device, px, px_cap, nullptr, w, h, c);
+    return decode_common(data, len, device, 0, px, px_cap, nullptr, w, h, c);
 }
 
 void* llcomp_mi_host_alloc(size_t bytes) {

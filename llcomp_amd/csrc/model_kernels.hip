@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kMW) void k_model_fwd(const Geometry g, const uint8
                 const int cur = win[s0][k][t + 2];
                 const Hood n = apply_borders(win[s0][k][t + 1], win[s0][k][t], win[s1][k][t + 2], win[s1][k][t + 1],
                                              win[s1][k][t + 3], win[s2][k][t + 2], lx, ly, sw);
-                int ctx = context_hash(n);
+                int ctx = context_hash(n, (g.flags & kGeoSmallModel) != 0);
                 int res = cur - predict(n);
                 if (ctx < 0) {  // llcomp.hpp:433-436
                     ctx = -ctx;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_model_fwd_any(const Geometry g, const u
         const int t = ly > 0 ? sample_at(p - rowb, g.c, k) : 0, tl = (ly > 0 && lx > 0) ? sample_at(p - rowb - g.c, g.c, k) : 0;
         const int tr = (ly > 0 && lx + 1 < sw) ? sample_at(p - rowb + g.c, g.c, k) : 0, T = ly > 1 ? sample_at(p - 2 * rowb, g.c, k) : 0;
         const Hood n = apply_borders(l, L, t, tl, tr, T, lx, ly, sw);
-        int ctx = context_hash(n), res = cur - predict(n);
+        int ctx = context_hash(n, (g.flags & kGeoSmallModel) != 0), res = cur - predict(n);
         if (ctx < 0) {  // llcomp.hpp:433-436
             ctx = -ctx;
             res = -res;
@@ -603,12 +603,13 @@ __global__ __launch_bounds__(256) void k_model_rows_fwd(const Geometry g, const 
             // group-relative lane of this tile's channel 0 (negative / beyond gw: that plane is another group's)
             const int col0 = int((first_tile + tt) * C) - int(first_id);
             const uint32_t n = sw - kb < 8 ? sw - kb : 8;
+            const bool small = (g.flags & kGeoSmallModel) != 0;
             for (uint32_t i = 0; i < n; ++i, p += C) {
                 rct_pixel<C>(p, cur);
                 const bool has_L = (kb + i) > 1;
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) {
-                    const int dq = has_L ? L[ch] - l[ch] : 0;
+                    const int dq = (has_L && !small) ? L[ch] - l[ch] : 0;  // LargeModel = false: no quant5 term, context 0
                     const uint32_t aq = uint32_t(dq < 0 ? -dq : dq);
                     const uint32_t cidx = min(aq, 1u) + (aq > 3 ? 1u : 0u);  // |quant5(L - l)|: context 0 / 605 / 1210
                     int res = cur[ch] - l[ch];

@@ -699,6 +699,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
     load_table(tab);
     const uint32_t lpw = lpw_and_flags & 0xFF;
     const bool replay_always = (lpw_and_flags >> 8) & 1;  // test hook: send every sample through the checked replay too
+    const bool small_model = (g.flags & kGeoSmallModel) != 0;
     const uint32_t id = blockIdx.x * lpw + threadIdx.x;
     if (threadIdx.x >= lpw || id >= g.n_slices) return;
     const SliceRect r = slice_rect(g, id);
@@ -737,7 +738,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 gbase[held_off] = int16_t(held_val);
                 const int lv = l[k];                 // x == 0: 128
                 const int Lv = x > 1 ? L[k] : lv;    // llcomp.hpp:496
-                const int dq = Lv - lv;
+                const int dq = small_model ? 0 : Lv - lv;  // LargeModel = false: no quant5 term, one context
                 const uint32_t aq = uint32_t(dq < 0 ? -dq : dq);
                 const bool neg = dq < 0;               // hash = 605*quant5(L-l) < 0
                 const uint32_t cidx = min(aq, 1u) + (aq > 3 ? 1u : 0u);  // |quant5(L - l)|
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                         const Hood n = apply_borders(x > 0 ? q[-px_step] : 0, x > 1 ? q[-2 * px_step] : 0, y > 0 ? q[-up] : 0,
                                                      (y > 0 && x > 0) ? q[-up - px_step] : 0, (y > 0 && x + 1 < r.sw) ? q[-up + px_step] : 0,
                                                      y > 1 ? q[-2 * up] : 0, x, y, r.sw);
-                        int ctx = context_hash(n);
+                        int ctx = context_hash(n, small_model);
                         const bool neg = ctx < 0;
                         if (neg) ctx = -ctx;
                         const uint64_t b64 = banks[size_t(ctx) << bsh];
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 for (int k = 0; k < NCH; ++k) {
                     if (window_low(d)) dec_append(d);
                     const Hood n = apply_borders(l[k], L[k], t[k], tl[k], tr[k], T[k], x, y, r.sw);
-                    int ctx = context_hash(n);
+                    int ctx = context_hash(n, small_model);
                     const bool neg = ctx < 0;  // llcomp.hpp:511-515
                     if (neg) ctx = -ctx;
                     const uint64_t b64 = banks[size_t(ctx) << bsh];

@@ -179,7 +179,7 @@ int llcomp_mi_stream_submit_decode(llcomp_mi_stream* s, const uint8_t* data, siz
     llcomp_mi_info info;
     if (int rc = llcomp_mi_probe(data, len, &info)) return rc;
     if (info.format != LLCOMP_MI_FORMAT_SLICED || info.width != s->w || info.height != s->h || info.channels != s->c ||
-        info.tile_w != s->tile_w || info.tile_h != s->tile_h || info.planar != s->planar)
+        info.tile_w != s->tile_w || info.tile_h != s->tile_h || info.planar != s->planar || info.small_model)
         return LLCOMP_MI_BAD_ARGS;  // a stream object codes ONE geometry
     std::lock_guard<std::mutex> lock(s->mu);
     DeviceGuard guard(s->device);

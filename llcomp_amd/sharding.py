@@ -11,12 +11,14 @@ device-resident codec object.
 Everything stays in HBM.  Encode, per call (`images` images of one shape):
     1. every rank: llcomp_mi_codec_encode of its local image(s)         -> packed payload + slice lengths on its GPU
     2. all_gather of the slice-length tables (a few MB at most)
-    3. ONE message per rank: its packed payload, GPU -> GPU, to the gathering rank (ncclSend / ncclRecv group)
-    4. gathering rank: llcomp_mi_device_copy_segments interleaves the ranks' pieces chunk by chunk into image order
-       behind the header and the permuted slice table                  -> one container per image, in HBM
-Decode is the mirror image: broadcast of the table, segment copy into rank order, one message per rank, local decode;
-the decoded bands stay on their ranks (gather_pixels() collects them when a single image is wanted).
-The only host round trip is the handful of byte counts the send / recv sizes need.
+    3. ONE variable-size all-to-all of the packed payloads, GPU -> GPU (RCCL alltoallv over xGMI): image b is gathered on
+       rank b % world, so all 7 links of every GPU carry bytes in both directions instead of one GPU's inbound links
+       carrying the whole bitstream (root=r funnels everything to rank r when one rank must hold all containers)
+    4. gathering ranks: llcomp_mi_device_copy_segments interleaves the ranks' pieces chunk by chunk into image order
+       behind the header and the permuted slice table                  -> complete containers, in HBM
+Decode is the mirror image: all_gather of the tables, segment copy into exchange order, all-to-all, local decode; the
+decoded bands stay on their ranks (gather_pixels() collects them when a single image is wanted).
+The only host round trip per direction is the world x world matrix of message sizes.
 """
 import ctypes as C
 
@@ -96,21 +98,26 @@ def _copy_segments(src, dst, src_off, dst_off, lens, max_len):
 
 
 class ShardedCodec:
-    """`images` images of shape (h, w, c), each sharded over all ranks of `group`; containers are gathered on rank `root`.
+    """`images` images of shape (h, w, c), each sharded over all ranks of `group`.
 
-        sc = ShardedCodec(w, h, c, tile_w, tile_h, planar=True, images=B)
-        band = sc.take_local(full)                 # this rank's rows of [B,h,w,c] (tests / bench; a real producer
-                                                   #   delivers each rank only its rows)
-        cont = sc.encode(band)                     # root: [(uint8 device tensor)] * B, others: None
-        out = sc.decode(cont)                      # every rank: its decoded rows, device tensor [B, local_h, w, c]
+        sc = ShardedCodec(w, h, c, tile_w, tile_h, planar=True, images=B)          # containers spread over the ranks
+        band = sc.take_local(full)       # this rank's rows of [B,h,w,c], stacked (tests / bench; a real producer delivers
+                                         #   each rank only its rows); frame f of the stack is image sc.frame_images[f]
+        conts = sc.encode(band)          # {image index: uint8 device tensor = complete SLICED container} for the images
+                                         #   this rank gathers (sc.my_images)
+        out = sc.decode(conts)           # every rank: its decoded rows, device tensor [B, local_h, w, c]
+
+    Where a container is assembled: root=None (default) spreads the images round-robin over the ranks (image b is gathered
+    on rank b % world), so the exchange is an all-to-all that uses every xGMI link in both directions; root=r gathers every
+    image on rank r (a funnel: that rank's seven inbound links carry the whole bitstream).
 
     band_factory(images, w, local_h, c, tile_w, tile_h, planar, device) builds the local coder; the default is the HIP codec
     object, tests inject a CPU stand-in to exercise the distributed logic where no GPU exists."""
 
-    def __init__(self, w, h, c, tile_w=0, tile_h=0, planar=True, images=1, group=None, root=0, chunks_per_rank=4, device=None,
+    def __init__(self, w, h, c, tile_w=0, tile_h=0, planar=True, images=1, group=None, root=None, chunks_per_rank=4, device=None,
                  band_factory=None):
         self.group = group
-        self.rank, self.world, self.root = dist.get_rank(group), dist.get_world_size(group), root
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.w, self.h, self.c, self.images, self.planar = w, h, c, images, bool(planar)
         self.tile_w = w if tile_w <= 0 or tile_w > w else tile_w
@@ -118,41 +125,57 @@ class ShardedCodec:
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         self.device = device
-        # tensors handed to the collectives: device memory with RCCL; gloo (tests) cannot send GPU tensors
+        # tensors handed to the collectives: device memory with RCCL; gloo (tests) cannot move GPU tensors
         self.comm_device = device if self.backend == "nccl" else torch.device("cpu")
-        self.chunks = plan_chunks(h, self.tile_h, self.world, chunks_per_rank)
+        world = self.world
+        self.root_of = [(b % world) if root is None else int(root) for b in range(images)]
+        self.my_images = [b for b in range(images) if self.root_of[b] == self.rank]
+        # a rank's codec packs its frames back to back: frames ordered by (gathering rank, image) make the bytes for one
+        # destination contiguous
+        self.frame_images = sorted(range(images), key=lambda b: (self.root_of[b], b))
+        frame_of = {b: f for f, b in enumerate(self.frame_images)}
+        self.chunks = plan_chunks(h, self.tile_h, world, chunks_per_rank)
         self.ntx = (w + self.tile_w - 1) // self.tile_w
         self.per_row = self.ntx * (c if self.planar else 1)  # slices per tile row
         self.nty = (h + self.tile_h - 1) // self.tile_h
         self.spf = self.per_row * self.nty                  # slices of one full image
         self.rows = [(t0 * self.tile_h, min(h, t1 * self.tile_h)) for t0, t1, o in self.chunks if o == self.rank]
         self.local_h = sum(y1 - y0 for y0, y1 in self.rows)
-        self.local_slices = [sum((t1 - t0) for t0, t1, o in self.chunks if o == r) * self.per_row for r in range(self.world)]
+        self.local_slices = [sum((t1 - t0) for t0, t1, o in self.chunks if o == r) * self.per_row for r in range(world)]
         self.max_local = max(self.local_slices)
         factory = band_factory or _HipBand
         self.band = factory(images, w, self.local_h, c, self.tile_w, self.tile_h, self.planar, device) if self.local_h else None
-        # slice permutation: container order (image, tile row, ...) <- rank-major order (rank, image, local tile row, ...)
-        # position of (rank r, image b, local slice s) in the all_gather'ed [world, images * max_local] table
+        # slice permutation: container order (image, tile row, ...) <- position of (rank r, frame f, local slice s) in the
+        # all_gather'ed [world, images * max_local] table of slice lengths
         src = np.empty((images, self.spf), dtype=np.int64)
-        seen = [0] * self.world
+        seen = [0] * world
         for t0, t1, o in self.chunks:
             n = (t1 - t0) * self.per_row
             for b in range(images):
-                src[b, t0 * self.per_row:t1 * self.per_row] = o * images * self.max_local + b * self.local_slices[o] + seen[o] + np.arange(n)
+                src[b, t0 * self.per_row:t1 * self.per_row] = o * images * self.max_local + frame_of[b] * self.local_slices[o] + seen[o] + np.arange(n)
             seen[o] += n
         self.perm = torch.from_numpy(src.reshape(-1)).to(device)
-        # segments = (image, chunk): the unit the concatenator moves
+        # segments = (image, chunk): the unit the concatenator moves.  All of this is geometry, fixed at construction.
         seg = [(b, ci) for b in range(images) for ci in range(len(self.chunks))]
-        self.seg_first = torch.tensor([b * self.spf + self.chunks[ci][0] * self.per_row for b, ci in seg], dtype=torch.int64, device=device)
-        self.seg_count = torch.tensor([(self.chunks[ci][1] - self.chunks[ci][0]) * self.per_row for b, ci in seg], dtype=torch.int64, device=device)
-        self.seg_image = torch.tensor([b for b, ci in seg], dtype=torch.int64, device=device)
+        t = lambda v: torch.tensor(v, dtype=torch.int64, device=device)  # noqa: E731
+        self.seg_first = t([b * self.spf + self.chunks[ci][0] * self.per_row for b, ci in seg])
+        self.seg_count = t([(self.chunks[ci][1] - self.chunks[ci][0]) * self.per_row for b, ci in seg])
+        self.seg_image = t([b for b, ci in seg])
+        self.seg_owner = t([self.chunks[ci][2] for b, ci in seg])
+        self.seg_root = t([self.root_of[b] for b, ci in seg])
+        # exchange order: (gathering rank, coding rank, frame, chunk) -- the order of the bytes in a gathering rank's receive
+        # buffer (encode) / send buffer (decode)
+        key = [(self.root_of[b], self.chunks[ci][2], frame_of[b], ci) for b, ci in seg]
+        self.xorder = t(sorted(range(len(seg)), key=lambda i: key[i]))
+        self.seg_mine = t([i for i, (b, ci) in enumerate(seg) if self.root_of[b] == self.rank])  # segments of the images I gather
         self.header = torch.tensor(list(bytes([MAGIC_SLICED, 1, c, 1 if self.planar else 0]) + b"".join(
             int(v).to_bytes(4, "little") for v in (w, h, self.tile_w, self.tile_h, self.spf))), dtype=torch.uint8, device=device)
 
     # ---- helpers ------------------------------------------------------------------------------------------------
     def take_local(self, full):
-        """this rank's rows of a full batch [images, h, w, c] (numpy or tensor) as one stacked device tensor"""
-        t = torch.as_tensor(full)
+        """this rank's rows of a full batch [images, h, w, c] (numpy or tensor), frames in codec order (frame_images), as one
+        stacked tensor on this rank's device"""
+        t = torch.as_tensor(full)[self.frame_images]
         parts = [t[:, y0:y1] for y0, y1 in self.rows]
         if not parts:
             return torch.empty((self.images, 0, self.w, self.c), dtype=torch.uint8, device=self.device)
@@ -171,141 +194,153 @@ class ShardedCodec:
         return out.to(self.device).to(torch.int64)
 
     def _segment_tables(self, lens_c):
-        """from the container-order slice lengths [images * spf]: per (image, chunk) segment its byte count, its offset in
-        the rank-major exchange buffers and its offset inside its image's payload"""
+        """From the container-order slice lengths [images * spf]: per (image, chunk) segment its byte count, its offset in
+        the gathering rank's exchange buffer and its offset inside its image's payload; per image its payload bytes; and the
+        message matrix M[coding rank][gathering rank] in bytes."""
         csum = torch.zeros(lens_c.numel() + 1, dtype=torch.int64, device=self.device)
         torch.cumsum(lens_c, 0, out=csum[1:])
         seg_len = csum[self.seg_first + self.seg_count] - csum[self.seg_first]
-        img_base = csum[self.seg_image * self.spf]
-        in_image = csum[self.seg_first] - img_base  # offset of the segment inside its image's payload
-        img_bytes = csum[torch.arange(1, self.images + 1, device=self.device) * self.spf] - csum[torch.arange(0, self.images, device=self.device) * self.spf]
-        # rank-major order: (owner, image, chunk) = the order in which a rank's codec packs its local slices
-        owner = torch.tensor([self.chunks[ci][2] for b in range(self.images) for ci in range(len(self.chunks))], dtype=torch.int64, device=self.device)
-        order = torch.argsort(owner, stable=True)
+        in_image = csum[self.seg_first] - csum[self.seg_image * self.spf]
+        ar = torch.arange(self.images + 1, device=self.device) * self.spf
+        img_bytes = csum[ar[1:]] - csum[ar[:-1]]
+        M = torch.zeros(self.world * self.world, dtype=torch.int64, device=self.device).index_add_(0, self.seg_owner * self.world + self.seg_root, seg_len)
+        M = M.view(self.world, self.world)
+        ordered = seg_len[self.xorder]
+        run = torch.cumsum(ordered, 0) - ordered                      # offset in the concatenation of ALL exchange buffers
+        recv_total = M.sum(0)                                         # bytes every gathering rank holds
+        base = torch.cumsum(recv_total, 0) - recv_total
         in_exchange = torch.empty_like(seg_len)
-        in_exchange[order] = torch.cumsum(seg_len[order], 0) - seg_len[order]
-        rank_bytes = torch.zeros(self.world, dtype=torch.int64, device=self.device).index_add_(0, owner, seg_len)
-        return seg_len, in_exchange, in_image, img_bytes, rank_bytes
+        in_exchange[self.xorder] = run - base[self.seg_root[self.xorder]]  # offset inside ITS gathering rank's buffer
+        return seg_len, in_exchange, in_image, img_bytes, M
+
+    def _exchange(self, send, send_split, recv_split):
+        """variable-size all-to-all of bytes (RCCL alltoallv on device tensors); returns the receive buffer on self.device"""
+        recv = torch.empty(int(sum(recv_split)) + 16, dtype=torch.uint8, device=self.comm_device)
+        n_send = int(sum(send_split))
+        src = self._to_comm(send[:n_send]) if n_send else torch.empty(0, dtype=torch.uint8, device=self.comm_device)
+        if self.world > 1:
+            dist.all_to_all_single(recv[: int(sum(recv_split))], src.contiguous(), output_split_sizes=[int(x) for x in recv_split],
+                                   input_split_sizes=[int(x) for x in send_split], group=self.group)
+        elif n_send:
+            recv[:n_send] = src
+        return recv.to(self.device)
 
     # ---- encode -------------------------------------------------------------------------------------------------
     def encode(self, local_px):
-        """local_px: uint8 device tensor [images, local_h, w, c] (this rank's stacked rows).  Returns on `root` a list of
-        `images` uint8 device tensors, each a complete SLICED container; None on the other ranks."""
+        """local_px: uint8 device tensor [images, local_h, w, c] (this rank's stacked rows, frames in frame_images order).
+        Returns {image index: uint8 device tensor holding the complete SLICED container} for the images this rank gathers."""
         payload = lens = status = None
         if self.band is not None:
             payload, lens, total, status = self.band.encode(local_px)
         all_lens = self._all_lens(lens)                      # collective 1: slice-length tables
         lens_c = all_lens[self.perm]                         # container order
-        seg_len, in_exchange, in_image, img_bytes, rank_bytes = self._segment_tables(lens_c)
-        host = torch.cat([rank_bytes, img_bytes]).cpu()      # the one host round trip: send / recv sizes
+        seg_len, in_exchange, in_image, img_bytes, M = self._segment_tables(lens_c)
+        host = torch.cat([M.reshape(-1), img_bytes]).cpu()   # the one host round trip: message and container sizes
         if self.band is not None:
             self.band.check(status)
-        rank_b, img_b = host[: self.world].tolist(), host[self.world:].tolist()
-        starts = np.concatenate([[0], np.cumsum(rank_b)]).astype(np.int64)
-        # collective 2: every rank's packed payload to the root, one message each, GPU to GPU
-        if self.rank == self.root:
-            exchange = torch.empty(int(starts[-1]) + 16, dtype=torch.uint8, device=self.comm_device)
-            ops = [dist.P2POp(dist.irecv, exchange[starts[r]:starts[r + 1]], r, group=self.group)
-                   for r in range(self.world) if r != self.root and rank_b[r]]
-            for q in (dist.batch_isend_irecv(ops) if ops else []):
-                q.wait()
-            if rank_b[self.root]:
-                exchange[starts[self.root]:starts[self.root + 1]] = self._to_comm(payload[: rank_b[self.root]])
-            exchange = exchange.to(self.device)
-        else:
-            if rank_b[self.rank]:
-                for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, self._to_comm(payload[: rank_b[self.rank]]), self.root, group=self.group)]):
-                    q.wait()
-            return None
-        # root: containers = [header][table][payload], payload interleaved chunk by chunk by the device concatenator
+        M_h = host[: self.world * self.world].view(self.world, self.world).tolist()
+        img_b = host[self.world * self.world:].tolist()
+        if payload is None:
+            payload = torch.empty(0, dtype=torch.uint8, device=self.device)
+        # collective 2: every coding rank's packed payload to the gathering ranks, GPU to GPU
+        exchange = self._exchange(payload, M_h[self.rank], [M_h[s][self.rank] for s in range(self.world)])
+        if not self.my_images:
+            return {}
+        # containers of my images = [header][table][payload], payload interleaved chunk by chunk by the device concatenator
         head = HEADER + 4 * self.spf
-        sizes = [head + b for b in img_b]
+        sizes = [head + img_b[b] for b in self.my_images]
         bases = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         buf = torch.empty(int(bases[-1]) + 16, dtype=torch.uint8, device=self.device)
         table = lens_c.to(torch.int32).view(self.images, self.spf)
-        for b in range(self.images):
-            buf[bases[b]:bases[b] + HEADER] = self.header
-            buf[bases[b] + HEADER:bases[b] + head] = table[b].view(torch.uint8)  # little-endian u32, as on the wire
-        dst_off = torch.as_tensor(bases[:-1], device=self.device)[self.seg_image] + head + in_image
-        _copy_segments(exchange, buf, in_exchange, dst_off, seg_len, max(img_b) if img_b else 0)
-        return [buf[bases[b]:bases[b + 1]] for b in range(self.images)]
+        base_of = torch.zeros(self.images, dtype=torch.int64, device=self.device)
+        for j, b in enumerate(self.my_images):
+            buf[bases[j]:bases[j] + HEADER] = self.header
+            buf[bases[j] + HEADER:bases[j] + head] = table[b].view(torch.uint8)  # little-endian u32, as on the wire
+            base_of[b] = int(bases[j])
+        mine = self.seg_mine
+        dst_off = base_of[self.seg_image[mine]] + head + in_image[mine]
+        _copy_segments(exchange, buf, in_exchange[mine].contiguous(), dst_off, seg_len[mine].contiguous(), max(sizes))
+        return {b: buf[bases[j]:bases[j + 1]] for j, b in enumerate(self.my_images)}
 
     # ---- decode -------------------------------------------------------------------------------------------------
     def decode(self, containers):
-        """containers: on `root` the list returned by encode (uint8 device tensors), None elsewhere.  Every rank returns
-        its decoded rows [images, local_h, w, c] (uint8, on its device)."""
+        """containers: {image index: uint8 device tensor} for the images this rank holds (what encode returned).  Every rank
+        returns its decoded rows [images, local_h, w, c] (uint8, on its device; frames in frame_images order)."""
         head = HEADER + 4 * self.spf
-        lens_c = torch.empty(self.images * self.spf, dtype=torch.int32, device=self.comm_device)
-        if self.rank == self.root:
-            for b, cont in enumerate(containers):
-                if cont.numel() < head or bytes(cont[:HEADER].cpu().numpy()) != bytes(self.header.cpu().numpy()):
-                    raise ValueError("container does not match this ShardedCodec's geometry")
-                lens_c[b * self.spf:(b + 1) * self.spf] = self._to_comm(cont[HEADER:head].clone().view(torch.int32))  # (clone: dword alignment)
-        dist.broadcast(lens_c, src=self.root, group=self.group)  # collective 1: the slice tables
-        lens_c = lens_c.to(self.device).to(torch.int64)
-        seg_len, in_exchange, in_image, img_bytes, rank_bytes = self._segment_tables(lens_c)
-        rank_b = rank_bytes.cpu().tolist()                   # host round trip: message sizes
-        starts = np.concatenate([[0], np.cumsum(rank_b)]).astype(np.int64)
-        mine = None
-        if self.rank == self.root:
-            sizes = [int(c_.numel()) for c_ in containers]
+        per_root = max(1, max(sum(1 for b in range(self.images) if self.root_of[b] == r) for r in range(self.world)))
+        mine_tab = torch.zeros(per_root * self.spf, dtype=torch.int32, device=self.comm_device)
+        for j, b in enumerate(self.my_images):
+            cont = containers[b]
+            if cont.numel() < head or bytes(cont[:HEADER].cpu().numpy()) != bytes(self.header.cpu().numpy()):
+                raise ValueError("container does not match this ShardedCodec's geometry")
+            mine_tab[j * self.spf:(j + 1) * self.spf] = self._to_comm(cont[HEADER:head].clone().view(torch.int32))  # (clone: dword alignment)
+        tabs = torch.empty(self.world * mine_tab.numel(), dtype=torch.int32, device=self.comm_device)
+        dist.all_gather_into_tensor(tabs, mine_tab, group=self.group)    # collective 1: the slice tables of every image
+        tabs = tabs.view(self.world, per_root, self.spf)
+        slot = [0] * self.world
+        pick = []
+        for b in range(self.images):
+            pick.append((self.root_of[b], slot[self.root_of[b]]))
+            slot[self.root_of[b]] += 1
+        lens_c = torch.stack([tabs[r, j] for r, j in pick]).reshape(-1).to(self.device).to(torch.int64)
+        seg_len, in_exchange, in_image, img_bytes, M = self._segment_tables(lens_c)
+        M_h = M.cpu().tolist()                               # host round trip: message sizes
+        # my containers -> send buffer ordered (coding rank, frame, chunk); the table may promise more than a damaged
+        # container holds: clip, the decoder reports it
+        n_out = int(sum(M_h[s][self.rank] for s in range(self.world)))
+        send = torch.zeros(n_out + 16, dtype=torch.uint8, device=self.device)
+        if self.my_images:
+            sizes = [int(containers[b].numel()) for b in self.my_images]
             bases = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-            src = torch.cat(list(containers)) if len(containers) > 1 else containers[0]
-            exchange = torch.empty(int(starts[-1]) + 16, dtype=torch.uint8, device=self.device)
-            src_off = torch.as_tensor(bases[:-1], device=self.device)[self.seg_image] + head + in_image
-            # the table may promise more than the payload holds (damaged container): clip, the decoder reports it
-            seg_clip = torch.minimum(seg_len, torch.clamp(torch.as_tensor(bases[1:], device=self.device)[self.seg_image] - src_off, min=0))
-            _copy_segments(src, exchange, src_off, in_exchange, seg_clip, int(max(sizes)))
-            exchange = self._to_comm(exchange)
-            ops = [dist.P2POp(dist.isend, exchange[starts[r]:starts[r + 1]], r, group=self.group)
-                   for r in range(self.world) if r != self.root and rank_b[r]]
-            for q in (dist.batch_isend_irecv(ops) if ops else []):  # collective 2: one message per rank
-                q.wait()
-            if rank_b[self.root]:
-                mine = exchange[starts[self.root]:starts[self.root + 1]].to(self.device)
-        elif rank_b[self.rank]:
-            mine = torch.empty(rank_b[self.rank] + 16, dtype=torch.uint8, device=self.comm_device)
-            for q in dist.batch_isend_irecv([dist.P2POp(dist.irecv, mine[: rank_b[self.rank]], self.root, group=self.group)]):
-                q.wait()
-            mine = mine.to(self.device)
+            src = torch.cat([containers[b] for b in self.my_images]) if len(self.my_images) > 1 else containers[self.my_images[0]]
+            base_of = torch.zeros(self.images, dtype=torch.int64, device=self.device)
+            end_of = torch.zeros(self.images, dtype=torch.int64, device=self.device)
+            for j, b in enumerate(self.my_images):
+                base_of[b], end_of[b] = int(bases[j]), int(bases[j + 1])
+            mine = self.seg_mine
+            src_off = base_of[self.seg_image[mine]] + head + in_image[mine]
+            seg_clip = torch.minimum(seg_len[mine], torch.clamp(end_of[self.seg_image[mine]] - src_off, min=0))
+            _copy_segments(src, send, src_off, in_exchange[mine].contiguous(), seg_clip.contiguous(), max(sizes))
+        # collective 2: every rank gets the bytes of its slices, already in its codec's order
+        recv = self._exchange(send, [M_h[s][self.rank] for s in range(self.world)], M_h[self.rank])
         out = torch.empty((self.images, self.local_h, self.w, self.c), dtype=torch.uint8, device=self.device)
         if self.band is None:
             return out
-        # this rank's slice lengths in ITS codec's order (image, local tile rows): the inverse of the permutation
+        # this rank's slice lengths in ITS codec's order (frame, local tile rows): the inverse of the permutation
         all_order = torch.empty(self.world * self.images * self.max_local, dtype=torch.int64, device=self.device)
         all_order[self.perm] = lens_c
         per = self.local_slices[self.rank]
         base = self.rank * self.images * self.max_local
         my_lens = all_order[base: base + self.images * per].to(torch.int32).contiguous()
-        if mine is None:
-            mine = torch.zeros(16, dtype=torch.uint8, device=self.device)
-        status = self.band.decode(mine, rank_b[self.rank], my_lens, out)
+        status = self.band.decode(recv, int(sum(M_h[self.rank])), my_lens, out)
         self.band.check(status)
         return out
 
-    def gather_pixels(self, local_out):
-        """root: the full batch [images, h, w, c] assembled from every rank's decoded rows (one message per rank); others None"""
+    def gather_pixels(self, local_out, dst=0):
+        """rank `dst`: the full batch [images, h, w, c] assembled from every rank's decoded rows (one message per rank);
+        None elsewhere"""
         flat = self._to_comm(local_out.contiguous().view(-1))
         row_bytes = self.w * self.c
         heights = [sum(min(self.h, t1 * self.tile_h) - t0 * self.tile_h for t0, t1, o in self.chunks if o == r) for r in range(self.world)]
-        if self.rank != self.root:
+        if self.rank != dst:
             if flat.numel():
-                for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, flat, self.root, group=self.group)]):
+                for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, flat, dst, group=self.group)]):
                     q.wait()
             return None
         parts, ops = [], []
         for r in range(self.world):
-            buf = flat if r == self.root else torch.empty(self.images * heights[r] * row_bytes, dtype=torch.uint8, device=self.comm_device)
-            if r != self.root and buf.numel():
+            buf = flat if r == dst else torch.empty(self.images * heights[r] * row_bytes, dtype=torch.uint8, device=self.comm_device)
+            if r != dst and buf.numel():
                 ops.append(dist.P2POp(dist.irecv, buf, r, group=self.group))
             parts.append(buf)
         for q in (dist.batch_isend_irecv(ops) if ops else []):
             q.wait()
         full = torch.empty((self.images, self.h, self.w, self.c), dtype=torch.uint8, device=self.device)
         seen = [0] * self.world
+        inv = torch.as_tensor(self.frame_images, device=self.device)
         for t0, t1, o in self.chunks:
             y0, y1 = t0 * self.tile_h, min(self.h, t1 * self.tile_h)
             band = parts[o].view(self.images, heights[o], self.w, self.c)[:, seen[o]:seen[o] + (y1 - y0)]
-            full[:, y0:y1] = band.to(self.device)
+            full[inv, y0:y1] = band.to(self.device)  # frame f of the stack is image frame_images[f]
             seen[o] += y1 - y0
         return full

@@ -127,6 +127,49 @@ def slice_payloads(ref):
     return out
 
 
+def small_model(ref_small):
+    """The bitstream of a reference built with LargeModel = false (oracle/_ref/libllcomp_ref_small.so): legacy streams
+    (O1 where defined, else O2) and sliced containers assembled from that reference's per-slice payloads."""
+    assert ref_small.lib.ref_large_model() == 0 and ref_small.lib.ref_states_nb() == (11 * 11 * 11 + 1) // 2 * 8
+    out = []
+    for name, w, h, c in [("g1", 1, 1, 3), ("g1", 8, 8, 3), ("g1", 16, 16, 3), ("g1", 17, 3, 4), ("g1", 8, 2, 1), ("g3", 64, 64, 3), ("mid", 97, 41, 3),
+                          ("checker", 16, 16, 3), ("g1", 33, 31, 5), ("mid", 640, 360, 3), ("g3", 1920, 1080, 3), ("g2", 1920, 1080, 3)]:
+        img = special(name, w, h, c)
+        s2 = ref_small.o2_compress_image(img)
+        s1 = ref_small.o1_compress_image(img, len(s2))
+        assert s1 is None or s1 == s2
+        rec = {"kind": "legacy", "gen": name, "w": w, "h": h, "c": c, "len": len(s2), "fnv1a64": fnv(s2), "source": "O1" if s1 is not None else "O2"}
+        if len(s2) <= HEX_LIMIT:
+            rec["hex"] = s2.hex()
+        if c >= 3:
+            rc, px = ref_small.o1_decompress_image(s2)
+            assert rc == 0 and np.array_equal(px, img)
+        out.append(rec)
+        print("small legacy", name, w, h, c, len(s2), flush=True)
+    for name, w, h, c, tw, th, planar in [("mid", 70, 50, 3, 32, 32, True), ("g3", 70, 50, 4, 32, 16, False), ("g1", 40, 6, 3, 40, 1, True), ("g1", 40, 6, 3, 13, 1, False),
+                                          ("mid", 1920, 1080, 3, 64, 64, True), ("g3", 1920, 1080, 3, 480, 1, True)]:
+        img = special(name, w, h, c)
+        planes = ref_small.o2_forward_rct(img)
+        pays = []
+        for y0 in range(0, h, th):
+            for x0 in range(0, w, tw):
+                if planar:
+                    for k in range(c):
+                        pays.append(ref_small.o2_encode_samples(np.ascontiguousarray(planes[y0:y0 + th, x0:x0 + tw, k:k + 1])))
+                else:
+                    pays.append(ref_small.o2_compress_image(np.ascontiguousarray(img[y0:y0 + th, x0:x0 + tw]))[6:])
+        cont = bytearray(container(w, h, c, tw, th, planar, pays))
+        cont[3] |= 2  # the container's small-model flag
+        cont = bytes(cont)
+        rec = {"kind": "sliced", "gen": name, "w": w, "h": h, "c": c, "tile_w": tw, "tile_h": th, "planar": planar, "n_slices": len(pays),
+               "container_len": len(cont), "container_fnv1a64": fnv(cont)}
+        if len(cont) <= HEX_LIMIT:
+            rec["container_hex"] = cont.hex()
+        out.append(rec)
+        print("small sliced", name, w, h, c, tw, th, planar, len(cont), flush=True)
+    return out
+
+
 def craft_bins(ref, bins):
     """Range-code an arbitrary (slot, bit) list for ONE context with fresh state.  Only used to build
     damaged-stream test inputs that no legal image produces; probabilities and state steps come from
@@ -207,6 +250,15 @@ def main():
         with open(os.path.join(OUT, fn), "w") as f:
             json.dump({"meta": meta, "vectors": make(ref)}, f, indent=1)
         print("wrote", fn)
+    if not only or "small" in only:
+        from orc import REF_SMALL_PATH
+
+        m2 = dict(meta, reference=meta["reference"] + ", compiled with LargeModel = false (oracle/Makefile: _ref/libllcomp_ref_small.so)")
+        with open(os.path.join(OUT, "small_model.json"), "w") as f:
+            json.dump({"meta": m2, "vectors": small_model(Ref(REF_SMALL_PATH))}, f, indent=1)
+        print("wrote small_model.json")
+    if only:
+        return
     # primitive tables straight from the reference's own functions
     prim = {"meta": meta,
             "quant11": [ref.lib.ref_quant11(x) for x in range(-600, 601)],

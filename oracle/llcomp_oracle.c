@@ -250,9 +250,15 @@ static inline hood_t hood(const int16_t* base, long rs, int ps, int tw, int x, i
     n.T = y > 1 ? p[-2 * rs] : n.t;
     return n;
 }
+/* hpp:21 `LargeModel`: a build-time constant of the reference (true as shipped).  With false the two quant5 terms are
+ * left out of the context (hpp:427-429).  Process-wide switch for the tests; the sliced container records it in bit 1
+ * of its flags byte, the legacy header cannot. */
+static int g_small_model;
+void orc_set_small_model(int on) { g_small_model = on != 0; }
 static inline int context_of(const hood_t* n) {  /* hpp:424-429, multipliers 1,11,121,605,3025 (D3) */
-    return orc_quant11(n->l - n->tl) + 11 * orc_quant11(n->tl - n->t) + 121 * orc_quant11(n->t - n->tr) +
-           605 * orc_quant5(n->L - n->l) + 3025 * orc_quant5(n->T - n->t);
+    const int h3 = orc_quant11(n->l - n->tl) + 11 * orc_quant11(n->tl - n->t) + 121 * orc_quant11(n->t - n->tr);
+    if (g_small_model) return h3;
+    return h3 + 605 * orc_quant5(n->L - n->l) + 3025 * orc_quant5(n->T - n->t);
 }
 
 void orc_model_rect(const int16_t* base, long rs, int ps, int nch, int tw, int th, uint16_t* ctx_out,
@@ -385,7 +391,7 @@ long orc_compress_sliced(const uint8_t* px, int w, int h, int c, int tile_w, int
     uint8_t* o = fail ? 0 : (uint8_t*)malloc((size_t)(24 + 4 * ns + total));
     long ret = -1;
     if (o) {
-        o[0] = ORC_MAGIC_SLICED; o[1] = 1; o[2] = (uint8_t)c; o[3] = (uint8_t)planar;
+        o[0] = ORC_MAGIC_SLICED; o[1] = 1; o[2] = (uint8_t)c; o[3] = (uint8_t)(planar | (g_small_model ? 2 : 0));
         put32(o + 4, (uint32_t)w); put32(o + 8, (uint32_t)h);
         put32(o + 12, (uint32_t)tile_w); put32(o + 16, (uint32_t)tile_h);
         put32(o + 20, (uint32_t)ns);
@@ -403,7 +409,16 @@ long orc_compress_sliced(const uint8_t* px, int w, int h, int c, int tile_w, int
     return ret;
 }
 
+static int decompress_impl(const uint8_t* data, size_t len, uint8_t** px, int* pw, int* ph, int* pc);
 int orc_decompress(const uint8_t* data, size_t len, uint8_t** px, int* pw, int* ph, int* pc) {
+    /* a sliced container says in bit 1 of its flags byte which model wrote it; a legacy stream follows the switch */
+    const int saved = g_small_model;
+    if (len >= 4 && data[0] == ORC_MAGIC_SLICED) g_small_model = (data[3] >> 1) & 1;
+    const int rc = decompress_impl(data, len, px, pw, ph, pc);
+    g_small_model = saved;
+    return rc;
+}
+static int decompress_impl(const uint8_t* data, size_t len, uint8_t** px, int* pw, int* ph, int* pc) {
     if (len < 1) return ORC_TRUNCATED;
     int w, h, c, tile_w, tile_h, planar;
     long ns;

@@ -64,6 +64,9 @@ long orc_compress_sliced(const uint8_t* px, int w, int h, int c, int tile_w, int
 /* Decodes either format (dispatch on magic).  *px malloc'd. */
 int orc_decompress(const uint8_t* data, size_t len, uint8_t** px, int* w, int* h, int* c);
 
+/* Bitstream variant of a reference built with LargeModel = false (llcomp.hpp:21, 427-429).  Process-wide, tests only. */
+void orc_set_small_model(int on);
+
 /* slice bookkeeping shared by tests */
 long orc_slice_count(int w, int h, int c, int tile_w, int tile_h, int planar);
 uint64_t orc_fnv1a64(const uint8_t* p, size_t n);

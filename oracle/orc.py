@@ -13,6 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORC_PATH = os.path.join(_HERE, "liborc.so")
 REF_PATH = os.path.join(_HERE, "_ref", "libllcomp_ref.so")
+REF_SMALL_PATH = os.path.join(_HERE, "_ref", "libllcomp_ref_small.so")  # the reference built with LargeModel = false
 
 OK, BAD_MAGIC, BAD_EXPONENT, TRUNCATED, BAD_ARGS, NOMEM = range(6)
 
@@ -67,6 +68,8 @@ class Orc:
         L.orc_fnv1a64.restype = C.c_uint64
         L.orc_fnv1a64.argtypes = [_u8p, C.c_size_t]
         L.orc_free.argtypes = [C.c_void_p]
+        L.orc_set_small_model.restype = None
+        L.orc_set_small_model.argtypes = [C.c_int]
         L.orc_carry_stats.restype = None
         L.orc_carry_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_int]
         for f in ("orc_quant11", "orc_quant5", "orc_state_p"):
@@ -76,6 +79,10 @@ class Orc:
         L.orc_state_next.argtypes = [C.c_int, C.c_int]
         L.orc_median.restype = C.c_int
         L.orc_median.argtypes = [C.c_int] * 3
+
+    def set_small_model(self, on):
+        """process-wide: code like a reference built with LargeModel = false (llcomp.hpp:21, 427-429)"""
+        self.lib.orc_set_small_model(int(bool(on)))
 
     def carry_stats(self, reset=False):
         """(carries through a run of undecided 0xFF bytes, longest run) seen by the encoder since the last reset"""
@@ -188,6 +195,7 @@ class Ref:
         L.ref_median.argtypes = [C.c_int] * 3
         L.ref_states_nb.restype = C.c_int
         L.ref_magic.restype = C.c_int
+        L.ref_large_model.restype = C.c_int
 
     @staticmethod
     def _cap(n):

@@ -38,10 +38,10 @@ inline Hood hood_at(const int16_t* s, int w, int c, int col, int row, int ch) {
     return n;
 }
 
-inline int ctx_of(const Hood& n) {
-    return llcomp::quant11(n.l - n.tl) + 11 * llcomp::quant11(n.tl - n.t) +
-           121 * llcomp::quant11(n.t - n.tr) + 605 * llcomp::quant5(n.L - n.l) +
-           3025 * llcomp::quant5(n.T - n.t);
+inline int ctx_of(const Hood& n) {  // llcomp.hpp:424-429, following the header's own LargeModel constant
+    int ctx = llcomp::quant11(n.l - n.tl) + 11 * llcomp::quant11(n.tl - n.t) + 121 * llcomp::quant11(n.t - n.tr);
+    if (llcomp::LargeModel) ctx += 605 * llcomp::quant5(n.L - n.l) + 3025 * llcomp::quant5(n.T - n.t);
+    return ctx;
 }
 
 }  // namespace
@@ -145,5 +145,6 @@ int ref_state_p(int s) { llcomp::cabac::State st; st.state = uint8_t(s); return 
 int ref_state_next(int s, int bit) { llcomp::cabac::State st; st.state = uint8_t(s); st.update(bit != 0); return st.state; }
 int ref_states_nb(void) { return int(llcomp::getStatesNb()); }
 int ref_magic(void) { return llcomp::magic_revision; }
+int ref_large_model(void) { return llcomp::LargeModel ? 1 : 0; }
 
 }  // extern "C"

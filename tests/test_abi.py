@@ -38,8 +38,8 @@ def test_header_symbols_all_exported(mi):
 def test_struct_layouts_match_header(mi):
     from llcomp_amd import _lib
 
-    assert C.sizeof(_lib.Opts) == 24
-    assert C.sizeof(_lib.Info) == 48
+    assert C.sizeof(_lib.Opts) == 28
+    assert C.sizeof(_lib.Info) == 56
     assert C.sizeof(_lib.StreamResult) == 40
 
 

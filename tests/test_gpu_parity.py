@@ -9,6 +9,7 @@ pytestmark = pytest.mark.gpu
 KAT = load_golden("kat_streams.json")["vectors"]
 SLC = load_golden("slice_payloads.json")["vectors"]
 DEC = load_golden("decode_behaviour.json")["vectors"]
+SMALL = load_golden("small_model.json")["vectors"]  # the reference compiled with LargeModel = false
 
 
 def _id(v):
@@ -110,6 +111,32 @@ def test_more_than_four_channels_match_oracle(mi, orc, c):
             t = mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar)
             assert t == orc.compress_sliced(img, tw, th, planar), (tw, th, planar)
             assert np.array_equal(mi.decompress_image(t).pixels, img)
+
+
+@pytest.mark.parametrize("v", SMALL, ids=lambda v: v["kind"] + "-" + _id(v))
+def test_small_model_equals_reference_built_with_largemodel_false(mi, orc, v):
+    """the bitstream of a reference built with `LargeModel = false` (llcomp.hpp:21, 26-32, 427-429).  Golden
+    vectors from the real header compiled with the constant flipped.  The legacy header does not record the variant (the
+    caller passes small_model on both sides); the sliced container carries it in its flags byte."""
+    img = make_image(v["gen"], v["w"], v["h"], v["c"])
+    if v["kind"] == "legacy":
+        if v["w"] * v["h"] > 700 * 400:
+            pytest.skip("a lone serial stream of this size takes seconds on one GPU lane; the smaller vectors cover the path")
+        s = mi.compress_image(img, v["w"], v["h"], v["c"], small_model=True)
+        assert len(s) == v["len"] and fnv_hex(orc, s) == v["fnv1a64"]
+        if "hex" in v:
+            assert s.hex() == v["hex"]
+        assert np.array_equal(mi.decompress_image(s, small_model=True).pixels, img)
+        if v["w"] * v["h"] > 64:  # decoded with the wrong model it is a different image (or an error), never a crash
+            try:
+                assert not np.array_equal(mi.decompress_image(s).pixels, img)
+            except mi.LlcompError as e:
+                assert e.status == mi.BAD_EXPONENT
+    else:
+        s = mi.compress_image(img, v["w"], v["h"], v["c"], format=mi.FORMAT_SLICED, tile_w=v["tile_w"], tile_h=v["tile_h"], planar=v["planar"], small_model=True)
+        assert len(s) == v["container_len"] and fnv_hex(orc, s) == v["container_fnv1a64"]
+        assert mi.probe(s).small_model == 1
+        assert np.array_equal(mi.decompress_image(s).pixels, img)  # the container says which model wrote it
 
 
 # ---- decoder behaviour on damaged streams == the real reference's ------------------------------------------------

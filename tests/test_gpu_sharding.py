@@ -47,10 +47,10 @@ def _worker(rank, world, backend, port, cases, q):
             assert sc.band is None or type(sc.band).__name__ == "_HipBand"
             band = sc.take_local(full)
             conts = sc.encode(band)
-            if rank == 0:
-                for b in range(images):
-                    want = mi.compress_image(full[b], w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar, device=0)
-                    assert conts[b].is_cuda and bytes(conts[b].cpu().numpy()) == want, f"{gen} {w}x{h}: image {b} differs from the one-piece container"
+            assert sorted(conts) == [b for b in range(images) if b % world == rank]   # containers spread round-robin
+            for b in conts:
+                want = mi.compress_image(full[b], w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar, device=0)
+                assert conts[b].is_cuda and bytes(conts[b].cpu().numpy()) == want, f"{gen} {w}x{h}: image {b} differs from the one-piece container"
             out = sc.decode(conts)
             assert out.is_cuda and torch.equal(out, band), "decoded rows differ from the source rows"
             px = sc.gather_pixels(out)

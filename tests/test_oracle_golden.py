@@ -8,6 +8,7 @@ KAT = load_golden("kat_streams.json")["vectors"]
 SLC = load_golden("slice_payloads.json")["vectors"]
 DEC = load_golden("decode_behaviour.json")["vectors"]
 PRIM = load_golden("primitives.json")
+SMALL = load_golden("small_model.json")["vectors"]  # the reference compiled with LargeModel = false
 
 
 def _id(v):
@@ -91,3 +92,28 @@ def test_truncated_and_empty(orc):
     assert orc.decompress(bytes([0x79, 3, 4]))[0] == 3
     assert orc.decompress(bytes([0x9C, 1, 3, 0]) + bytes(8))[0] == 3
     assert orc.decompress(bytes([0x42]) + bytes(30))[0] == 1
+
+
+@pytest.mark.parametrize("v", SMALL, ids=lambda v: v["kind"] + "-" + _id(v))
+def test_small_model_equals_reference_built_with_largemodel_false(orc, v):
+    """llcomp.hpp:21 `LargeModel` is a build-time constant; the golden vectors come from the real header compiled with it
+    set to false (oracle/Makefile: _ref/libllcomp_ref_small.so)."""
+    img = make_image(v["gen"], v["w"], v["h"], v["c"])
+    orc.set_small_model(True)
+    try:
+        if v["kind"] == "legacy":
+            s = orc.compress_image(img)
+            assert len(s) == v["len"] and fnv_hex(orc, s) == v["fnv1a64"]
+            if "hex" in v:
+                assert s.hex() == v["hex"]
+        else:
+            s = orc.compress_sliced(img, v["tile_w"], v["tile_h"], v["planar"])
+            assert len(s) == v["container_len"] and fnv_hex(orc, s) == v["container_fnv1a64"]
+            assert s[3] & 2, "the container must carry the small-model flag"
+        rc, px = orc.decompress(s)
+        assert rc == 0 and np.array_equal(px, img)
+    finally:
+        orc.set_small_model(False)
+    if v["kind"] == "sliced":  # a container says which model wrote it: it decodes whatever the process-wide switch says
+        rc, px = orc.decompress(s)
+        assert rc == 0 and np.array_equal(px, img)

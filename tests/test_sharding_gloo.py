@@ -80,21 +80,20 @@ def _worker(rank, world, port, case, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         orc = orc_mod.Orc()
-        (w, h, c), (tw, th), planar, images, cpr = case
+        (w, h, c), (tw, th), planar, images, cpr, root = case
         full = np.stack([np.roll(orc_mod.gen_mid(w, h, c) if b % 2 == 0 else orc_mod.gen_g3(w, h, c, seed=5 + b), 3 * b, axis=1) for b in range(images)])
-        sc = sharding.ShardedCodec(w, h, c, tw, th, planar, images=images, chunks_per_rank=cpr, device=torch.device("cpu"),
+        sc = sharding.ShardedCodec(w, h, c, tw, th, planar, images=images, chunks_per_rank=cpr, root=root, device=torch.device("cpu"),
                                    band_factory=oracle_band_factory(orc))
         band = sc.take_local(full)
         rows = [y for y0, y1 in sc.rows for y in range(y0, y1)]
         assert band.shape == (images, len(rows), w, c)
         conts = sc.encode(band)
-        if rank == 0:
-            for b in range(images):
-                assert bytes(conts[b].numpy()) == orc.compress_sliced(full[b], tw, th, planar), f"image {b}: sharded container differs from the one-piece container"
-        else:
-            assert conts is None
+        want_mine = [b for b in range(images) if (b % world if root is None else root) == rank]
+        assert sorted(conts) == want_mine
+        for b in want_mine:
+            assert bytes(conts[b].numpy()) == orc.compress_sliced(full[b], tw, th, planar), f"image {b}: sharded container differs from the one-piece container"
         out = sc.decode(conts)
-        assert np.array_equal(out.numpy(), full[:, rows]), "decoded rows differ"
+        assert np.array_equal(out.numpy(), full[sc.frame_images][:, rows]), "decoded rows differ"
         px = sc.gather_pixels(out)
         if rank == 0:
             assert np.array_equal(px.numpy(), full)
@@ -108,12 +107,13 @@ def _worker(rank, world, port, case, q):
         dist.destroy_process_group()
 
 
-CASES = [
-    (2, ((70, 50, 3), (32, 8), True, 1, 4)),      # ragged last tile row, planar
-    (2, ((33, 9, 1), (16, 4), False, 2, 1)),      # contiguous bands (one chunk per rank), two images, interleaved channels
-    (3, ((40, 20, 4), (40, 1), True, 2, 2)),      # one-row slices, three ranks
-    (2, ((20, 5, 3), (8, 8), True, 1, 4)),        # a single tile row: rank 1 has nothing to code
-    (3, ((64, 37, 3), (16, 5), False, 3, 4)),     # 8 tile rows over 3 ranks x 4 chunks: uneven chunks, ragged tail
+CASES = [  # shape, tile, planar, images, chunks per rank, root (None = containers spread round-robin over the ranks)
+    (2, ((70, 50, 3), (32, 8), True, 1, 4, 0)),       # ragged last tile row, planar, everything gathered on rank 0
+    (2, ((33, 9, 1), (16, 4), False, 2, 1, None)),    # contiguous bands (one chunk per rank), two images, one per rank
+    (3, ((40, 20, 4), (40, 1), True, 2, 2, None)),    # one-row slices, three ranks, rank 2 gathers nothing
+    (2, ((20, 5, 3), (8, 8), True, 1, 4, 1)),         # a single tile row: rank 1 has nothing to code but gathers the image
+    (3, ((64, 37, 3), (16, 5), False, 5, 4, None)),   # 8 tile rows over 3 ranks x 4 chunks: uneven chunks, ragged tail, 5 images over 3 roots
+    (3, ((64, 37, 3), (16, 5), True, 3, 4, 2)),       # funnel to a rank that is not 0
 ]
 
 

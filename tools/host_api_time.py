@@ -1,4 +1,5 @@
-"""Times the host-buffer calls (llcomp_mi_encode / llcomp_mi_decode) on one 4K frame: what a CLI user gets."""
+"""Times the host-buffer calls on one 4K frame: llcomp_mi_encode / llcomp_mi_decode with pageable buffers (what a CLI user
+gets) and llcomp_mi_encode_into / llcomp_mi_decode_into with pinned buffers from llcomp_mi_host_alloc."""
 import sys
 import time
 
@@ -23,3 +24,19 @@ for name, gen in (("g3", gen_g3), ("mid", gen_mid)):
         t2 = time.perf_counter()
         print(f"{name} {tw}x{th} planar={planar}: encode {(t1 - t0) / 5 * 1e3:.1f} ms, decode {(t2 - t1) / 5 * 1e3:.1f} ms per 4K frame "
               f"-> {W * H / 1e6 / ((t2 - t0) / 5):.0f} MPix/s enc+dec, ratio {img.size / len(s):.3f}", flush=True)
+        src, out, back = mi.PinnedBuffer(img.size), mi.PinnedBuffer(2 * img.size + (1 << 20)), mi.PinnedBuffer(img.size)
+        src.array[:] = img.reshape(-1)
+        kw = dict(format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar)
+        n = mi.compress_image_into(src.array, W, H, C, out.array, **kw)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            n = mi.compress_image_into(src.array, W, H, C, out.array, **kw)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            mi.decompress_image_into(out.array[:n], back.array)
+        t2 = time.perf_counter()
+        assert np.array_equal(back.array.reshape(img.shape), img)
+        print(f"{name} {tw}x{th} planar={planar} PINNED: encode {(t1 - t0) / 5 * 1e3:.1f} ms, decode {(t2 - t1) / 5 * 1e3:.1f} ms per 4K frame "
+              f"-> {W * H / 1e6 / ((t2 - t0) / 5):.0f} MPix/s enc+dec", flush=True)
+        for b in (src, out, back):
+            b.close()
