@@ -347,7 +347,7 @@ def main():
             value = B * size * size * args.steps / dt / 1e6
             raw = B * size * size * 3
             res = {
-                "metric": "encode+decode MPix/s on 8192x8192 RGB8 sharded over the GPUs, RCCL gather + scatter included, bit-exact",
+                "metric": "encode+decode MPix/s on 8192x8192 RGB8 sharded over the GPUs, RCCL exchange of the bitstream included, bit-exact",
                 "value": round(value, 2), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "int32", "data": "synthetic",
