@@ -8,7 +8,8 @@
 //   decode  H2D container -> kernels -> D2H frame + status (event e2)
 // The size of a container is known on the GPU only.  Nobody waits for it at submit time: the 16-byte mailbox copy is
 // queued behind the kernels and whoever enters the library next (submit, wait or poll) looks at the events of the
-// jobs in flight ("pump") and queues the container copies whose size has arrived.  With two or more slots busy the
+// jobs in flight ("pump") and queues the container copies whose size has arrived; wait() itself polls (20 us naps), so
+// the copies of younger jobs start while the caller waits for the oldest.  With two or more slots busy the
 // copies of one job overlap the kernels of the others in both PCIe directions.
 // Back-pressure: submit returns LLCOMP_MI_BUSY when every slot is occupied (in flight, or finished and not yet
 // released); the caller takes a result (llcomp_mi_stream_wait), uses it and releases the slot.
@@ -17,10 +18,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <deque>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/llcomp_mi.h"
@@ -237,14 +240,19 @@ int llcomp_mi_stream_wait(llcomp_mi_stream* s, llcomp_mi_stream_result* r) {
     if (int rc = pump(s)) return rc;
     const uint32_t i = s->fifo.front();
     Slot& sl = s->slots[i];
-    if (sl.state == kEncSizing) {
-        LLMI_HIP_TRY(hipEventSynchronize(sl.e1));
-        if (int rc = pump(s)) return rc;  // queues this job's container copy -- and any other whose size has arrived
+    // Wait for the oldest job by polling, not by blocking on its event: while this thread waits, the size mailboxes of
+    // YOUNGER encode jobs keep arriving, and their container copies have to be queued right away or the D2H link idles.
+    for (;;) {
+        if (int rc = pump(s)) return rc;
+        if (sl.state == kFailed) break;
+        if (sl.state == kCopying) {
+            const hipError_t q = hipEventQuery(sl.e2);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return LLCOMP_MI_HIP_ERROR;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
-    if (sl.state == kCopying) {
-        LLMI_HIP_TRY(hipEventSynchronize(sl.e2));
-        if (sl.kind == LLCOMP_MI_JOB_DECODE) sl.status = status_from_bits(uint32_t(sl.lane->h_meta[1]));
-    }
+    if (sl.state == kCopying && sl.kind == LLCOMP_MI_JOB_DECODE) sl.status = status_from_bits(uint32_t(sl.lane->h_meta[1]));
     s->fifo.pop_front();
     sl.state = kHeld;
     ++s->jobs_done;
