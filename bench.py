@@ -244,8 +244,9 @@ def c5_stream(frames_np, tile_w, tile_h, planar, depth=16):
 
 
 def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank, check_one_piece=True):
-    """BASELINE config 4: `images` noise images of size x size RGB8, each sharded over all ranks; encode (+ gather to rank 0)
-    and decode (+ scatter) per step.  Returns the max-over-ranks wall time."""
+    """BASELINE config 4: `images` noise images of size x size RGB8, each sharded over all ranks; encode (+ exchange of the
+    bitstream) and decode (+ exchange back) per step.  The batch is coded as two halves on two HIP streams (a ShardedCodec
+    each) so that the exchange of one half overlaps the coding of the other.  Returns the max-over-ranks wall time."""
     import torch
     import torch.distributed as dist
 
@@ -253,43 +254,67 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     from llcomp_amd import sharding
 
     dev = torch.device("cuda", local_rank)
-    sc = sharding.ShardedCodec(size, size, 3, tile_w, tile_h, True, images=images, device=dev)
+    halves = 2 if images % 2 == 0 and (images // 2) % world == 0 else 1  # every half spreads its containers evenly over the ranks
+    per = images // halves
+    scs = [sharding.ShardedCodec(size, size, 3, tile_w, tile_h, True, images=per, device=dev) for _ in range(halves)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(halves)]
     # uniform byte noise (torch Philox, seed 1234 + image): every rank draws the full image on its GPU and keeps its rows
-    bands, first = {}, None
-    for b in range(images):
-        g = torch.Generator(device=dev)
-        g.manual_seed(1234 + b)
-        full = torch.randint(0, 256, (1, size, size, 3), dtype=torch.uint8, device=dev, generator=g)
-        bands[b] = torch.cat([full[:, y0:y1] for y0, y1 in sc.rows], dim=1) if sc.rows else full[:, :0]
-        if b == 0 and rank == sc.root_of[0] and check_one_piece:
-            first = full[0].cpu().numpy()
-        del full
-    band = torch.cat([bands[b] for b in sc.frame_images], dim=0).contiguous()  # frames in the codec's order
-    del bands
-    conts = sc.encode(band)
-    out = sc.decode(conts)
-    assert torch.equal(out, band), "sharded round trip is not lossless"
-    pb = torch.tensor([sum(int(c_.numel()) for c_ in conts.values())], dtype=torch.int64, device=dev)
+    bands, first = [], None
+    for k, sc in enumerate(scs):
+        rows = {}
+        for j in range(per):
+            b = k * per + j
+            g = torch.Generator(device=dev)
+            g.manual_seed(1234 + b)
+            full = torch.randint(0, 256, (1, size, size, 3), dtype=torch.uint8, device=dev, generator=g)
+            rows[j] = torch.cat([full[:, y0:y1] for y0, y1 in sc.rows], dim=1) if sc.rows else full[:, :0]
+            if b == 0 and rank == sc.root_of[0] and check_one_piece:
+                first = full[0].cpu().numpy()
+            del full
+        bands.append(torch.cat([rows[j] for j in sc.frame_images], dim=0).contiguous())  # frames in the codec's order
+        del rows
+    torch.cuda.synchronize()
+
+    def step():
+        conts, outs = [None] * halves, [None] * halves
+        for k in range(halves):  # local coding of both halves is queued first ...
+            with torch.cuda.stream(streams[k]):
+                scs[k].encode_begin(bands[k])
+        for k in range(halves):  # ... so the exchange of half 0 runs beside the coding of half 1
+            with torch.cuda.stream(streams[k]):
+                conts[k] = scs[k].encode_finish()
+        for k in range(halves):
+            with torch.cuda.stream(streams[k]):
+                outs[k] = scs[k].decode(conts[k])
+        return conts, outs
+
+    conts, outs = step()
+    torch.cuda.synchronize()
+    for k in range(halves):
+        assert torch.equal(outs[k], bands[k]), "sharded round trip is not lossless"
+    pb = torch.tensor([sum(int(c_.numel()) for cs in conts for c_ in cs.values())], dtype=torch.int64, device=dev)
     dist.all_reduce(pb, op=dist.ReduceOp.SUM)
     payload_bytes = int(pb.item())
     if first is not None:
         one = mi.compress_image(first, size, size, 3, format=mi.FORMAT_SLICED, tile_w=tile_w, tile_h=tile_h, planar=True, device=local_rank)
-        assert bytes(conts[0].cpu().numpy()) == one, "sharded container differs from the one-piece container"
-    for _ in range(max(2, warmup - 1)):  # at least two more untimed passes: torch's allocator pools still grow in them
-        sc.decode(sc.encode(band))
+        assert bytes(conts[0][0].cpu().numpy()) == one, "sharded container differs from the one-piece container"
+    del conts, outs
+    for _ in range(max(3, warmup - 1)):  # at least three more untimed passes: torch's allocator pools still grow in them
+        step()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        out = sc.decode(sc.encode(band))
+        conts, outs = step()
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
-    assert torch.equal(out, band)
+    for k in range(halves):
+        assert torch.equal(outs[k], bands[k])
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    del sc, band, out, conts
+    del scs, bands, outs, conts
     torch.cuda.empty_cache()
     return float(t.item()), payload_bytes
 
@@ -308,6 +333,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra one-pipeline-at-a-time launches behind the timed region (profiler runs)")
     ap.add_argument("--no-also", action="store_true", help="only the headline workload (profiler runs, sweeps)")
+    ap.add_argument("--also-only", default="", help="comma-separated subset of the `also` legs: contents,tiles,latency,legacy,c5,c4 (profiling)")
     ap.add_argument("--c4-images", type=int, default=16, help="8192x8192 images per step of the sharded (config 4) workload (fixed total: strong scaling)")
     ap.add_argument("--c4-tile-w", type=int, default=512)
     ap.add_argument("--c4-tile-h", type=int, default=1)
@@ -454,13 +480,15 @@ def main():
         also = {}
         sub = max(3, args.steps // 3)
         t_also = time.perf_counter()
+        only = set(x for x in args.also_only.split(",") if x)
+        want = lambda leg: not only or leg in only  # noqa: E731
         # other contents at the default slicing (4 distinct frames, the rest rotations)
-        for content in ("g2", "mid"):
+        for content in ("g2", "mid") if want("contents") else ():
             if content != args.content:
                 also[f"{content}_default_slicing"] = brief(measure(make_frames(content, F, 0, distinct=4), args.tile_w, args.tile_h, planar, args.streams, sub, 1, local_rank),
                                                            workload=f"{F} frames 4K {content}, {args.tile_w}x{args.tile_h} planar")
         # 2-D tiles keep vertical prediction (and the reference's ratio); bound by random state-bank accesses in HBM
-        for content in ("nat", "mid", "g3"):
+        for content in ("nat", "mid", "g3") if want("tiles") else ():
             fr = frames_np[:16] if content == args.content else make_frames(content, 16, 0, distinct=4)
             m2 = measure(fr, 64, 64, True, 2, sub, 1, local_rank)
             samples = 2 * 16 * W4K * H4K * C4K * m2["steps"]  # one state-bank read-modify-write per sample and direction
@@ -468,22 +496,27 @@ def main():
                                                            state_bank_rmw_per_s=round(samples / m2["dt"] / 1e9, 2), rmw_ceiling=RMW_CEILING / 1e9,
                                                            frac_of_random_access_ceiling=round(samples / m2["dt"] / RMW_CEILING, 3))
         # latency of ONE frame
-        m1 = measure(frames_np[:1], args.tile_w, args.tile_h, planar, 1, 20, 2, local_rank)
-        also["one_frame_latency"] = brief(m1, workload=f"1 frame 4K {args.content}, {args.tile_w}x{args.tile_h} planar", ms_enc_plus_dec=round(m1["dt"] / m1["steps"] * 1e3, 3))
+        if want("latency"):
+            m1 = measure(frames_np[:1], args.tile_w, args.tile_h, planar, 1, 20, 2, local_rank)
+            also["one_frame_latency"] = brief(m1, workload=f"1 frame 4K {args.content}, {args.tile_w}x{args.tile_h} planar", ms_enc_plus_dec=round(m1["dt"] / m1["steps"] * 1e3, 3))
         # the reference's own format in bulk: 512 whole-image streams (one lane each) of 256x256 RGB8
-        leg = make_frames("mid", 512, 0, w=256, h=256, c=3, distinct=16)
-        ml = measure(leg, 256, 256, False, 1, 1, 1, local_rank)
-        also["legacy_streams_batched"] = brief(ml, workload="512 frames 256x256 RGB8 mid, one whole-image stream each (payload == reference stream), one GPU lane per stream")
-        if not args.no_cpu_baseline:
-            also["legacy_streams_batched"]["cpu_reference"] = cpu_baseline(leg[0], "256x256 RGB8 mid", 256, 256, False)
+        if want("legacy"):
+            leg = make_frames("mid", 512, 0, w=256, h=256, c=3, distinct=16)
+            ml = measure(leg, 256, 256, False, 1, 1, 1, local_rank)
+            also["legacy_streams_batched"] = brief(ml, workload="512 frames 256x256 RGB8 mid, one whole-image stream each (payload == reference stream), one GPU lane per stream")
+            if not args.no_cpu_baseline:
+                also["legacy_streams_batched"]["cpu_reference"] = cpu_baseline(leg[0], "256x256 RGB8 mid", 256, 256, False)
         # BASELINE config 5 through the streaming pipeline, PCIe inclusive
-        also["c5_stream_pcie"] = c5_stream(frames_np, args.tile_w, args.tile_h, planar)
+        if want("c5"):
+            also["c5_stream_pcie"] = c5_stream(frames_np, args.tile_w, args.tile_h, planar)
         # BASELINE config 4 on one GPU: the N = 1 point of the strong-scaling curve the N > 1 runs report
-        dt4, pay4 = c4_run(args.c4_images, 8192, args.c4_tile_w, args.c4_tile_h, max(2, sub // 2), 3, local_rank, world, rank)  # (the first two steps still grow torch's allocator pools)
-        also["c4_sharded_one_gpu"] = {"value": round(args.c4_images * 8192 * 8192 * max(2, sub // 2) / dt4 / 1e6, 1), "unit": "MPix/s",
-                                      "ms_per_step": round(dt4 / max(2, sub // 2) * 1e3, 3), "images_per_step": args.c4_images,
-                                      "compression_ratio": round(args.c4_images * 8192 * 8192 * 3 / pay4, 4),
-                                      "workload": f"C4 {args.c4_images} x 8192x8192 RGB8 uniform noise, {args.c4_tile_w}x{args.c4_tile_h} planar, the sharded code path on 1 GPU"}
+        if want("c4"):
+            n4 = max(4, sub // 2)
+            dt4, pay4 = c4_run(args.c4_images, 8192, args.c4_tile_w, args.c4_tile_h, n4, 3, local_rank, world, rank)
+            also["c4_sharded_one_gpu"] = {"value": round(args.c4_images * 8192 * 8192 * n4 / dt4 / 1e6, 1), "unit": "MPix/s",
+                                          "ms_per_step": round(dt4 / n4 * 1e3, 3), "steps": n4, "images_per_step": args.c4_images,
+                                          "compression_ratio": round(args.c4_images * 8192 * 8192 * 3 / pay4, 4),
+                                          "workload": f"C4 {args.c4_images} x 8192x8192 RGB8 uniform noise, {args.c4_tile_w}x{args.c4_tile_h} planar, the sharded code path on 1 GPU"}
         also["seconds"] = round(time.perf_counter() - t_also, 1)
         res["also"] = also
     print(json.dumps(res), flush=True)

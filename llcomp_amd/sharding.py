@@ -168,6 +168,7 @@ class ShardedCodec:
         key = [(self.root_of[b], self.chunks[ci][2], frame_of[b], ci) for b, ci in seg]
         self.xorder = t(sorted(range(len(seg)), key=lambda i: key[i]))
         self.seg_mine = t([i for i, (b, ci) in enumerate(seg) if self.root_of[b] == self.rank])  # segments of the images I gather
+        self._pending = None
         self.header = torch.tensor(list(bytes([MAGIC_SLICED, 1, c, 1 if self.planar else 0]) + b"".join(
             int(v).to_bytes(4, "little") for v in (w, h, self.tile_w, self.tile_h, self.spf))), dtype=torch.uint8, device=device)
 
@@ -215,23 +216,34 @@ class ShardedCodec:
 
     def _exchange(self, send, send_split, recv_split):
         """variable-size all-to-all of bytes (RCCL alltoallv on device tensors); returns the receive buffer on self.device"""
-        recv = torch.empty(int(sum(recv_split)) + 16, dtype=torch.uint8, device=self.comm_device)
         n_send = int(sum(send_split))
+        if self.world == 1:
+            return send  # one rank: what it would send to itself is already in place
+        recv = torch.empty(int(sum(recv_split)) + 16, dtype=torch.uint8, device=self.comm_device)
         src = self._to_comm(send[:n_send]) if n_send else torch.empty(0, dtype=torch.uint8, device=self.comm_device)
-        if self.world > 1:
-            dist.all_to_all_single(recv[: int(sum(recv_split))], src.contiguous(), output_split_sizes=[int(x) for x in recv_split],
-                                   input_split_sizes=[int(x) for x in send_split], group=self.group)
-        elif n_send:
-            recv[:n_send] = src
+        dist.all_to_all_single(recv[: int(sum(recv_split))], src.contiguous(), output_split_sizes=[int(x) for x in recv_split],
+                               input_split_sizes=[int(x) for x in send_split], group=self.group)
         return recv.to(self.device)
 
     # ---- encode -------------------------------------------------------------------------------------------------
     def encode(self, local_px):
         """local_px: uint8 device tensor [images, local_h, w, c] (this rank's stacked rows, frames in frame_images order).
-        Returns {image index: uint8 device tensor holding the complete SLICED container} for the images this rank gathers."""
+        Returns {image index: uint8 device tensor holding the complete SLICED container} for the images this rank gathers.
+        = encode_begin + encode_finish; two ShardedCodec objects on two HIP streams can interleave the halves so that the
+        exchange of one batch overlaps the coding of the other (bench.py does)."""
+        self.encode_begin(local_px)
+        return self.encode_finish()
+
+    def encode_begin(self, local_px):
+        """enqueue the local coding on the current stream (asynchronous, no collective, no host wait)"""
+        self._pending = self.band.encode(local_px) if self.band is not None else None
+
+    def encode_finish(self):
+        """the exchange: slice-table all_gather, message sizes to the host, all-to-all of the payloads, concatenator"""
         payload = lens = status = None
-        if self.band is not None:
-            payload, lens, total, status = self.band.encode(local_px)
+        if self._pending is not None:
+            payload, lens, total, status = self._pending
+        self._pending = None
         all_lens = self._all_lens(lens)                      # collective 1: slice-length tables
         lens_c = all_lens[self.perm]                         # container order
         seg_len, in_exchange, in_image, img_bytes, M = self._segment_tables(lens_c)
