@@ -68,3 +68,34 @@ def test_random_garbage_decodes_like_reference(orc, ref, seed):
         assert rc_o == 0 and np.array_equal(px_o, px_r)
     else:
         assert rc_o == rc_r
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_small_model_random_images_bit_exact(orc, seed):
+    """the LargeModel = false variant against the real header compiled with the constant flipped (oracle/Makefile)"""
+    import os
+
+    import orc as orc_mod
+
+    if not os.path.exists(orc_mod.REF_SMALL_PATH):
+        pytest.skip("oracle/_ref/libllcomp_ref_small.so not built (needs /root/reference)")
+    small = orc_mod.Ref(orc_mod.REF_SMALL_PATH)
+    assert small.lib.ref_large_model() == 0
+    rng = np.random.default_rng(500 + seed)
+    w, h, c = int(rng.integers(1, 68)), int(rng.integers(1, 68)), int(rng.integers(1, 5))
+    if seed % 2:
+        img = rng.integers(0, 256, size=(h, w, c), dtype=np.uint8)
+    else:
+        y, x, k = np.meshgrid(np.arange(h), np.arange(w), np.arange(c), indexing="ij")
+        img = ((x * 3 + y * 5 + k * 11 + rng.integers(-2, 3, size=(h, w, c))) & 0xFF).astype(np.uint8)
+    orc.set_small_model(True)
+    try:
+        s = orc.compress_image(img)
+        assert s == small.o2_compress_image(img)
+        rc, px = orc.decompress(s)
+        assert rc == 0 and np.array_equal(px, img)
+        if c >= 3:
+            rc, px = small.o1_decompress_image(s)
+            assert rc == 0 and np.array_equal(px, img)
+    finally:
+        orc.set_small_model(False)
