@@ -173,10 +173,39 @@ def test_error_codes(mi):
     with pytest.raises(mi.LlcompError) as e:
         mi.Codec(1, 32768, 32768, 3)  # w*h*c >= 2^31 (llcomp.hpp:359 `int size`)
     assert e.value.status == mi.OUT_OF_RANGE
+    # a legacy-sized giant (16384^2 RGB = 805 M samples, beyond the 13 B/sample scratch bound of one 32-bit-addressed slice)
+    # is accepted: the codec object can be built (round 1 returned BAD_ARGS here); coding it on one lane would take hours
+    big = mi.Codec(1, 16384, 16384, 3)
+    assert big.n_slices == 1
+    big.close()
     # sliced format has u32 dimensions: a 70000-pixel-wide strip is fine there
     img = (np.arange(70000 * 3) & 0xFF).astype(np.uint8).reshape(1, 70000, 3)
     s = mi.compress_image(img, 70000, 1, 3, format=mi.FORMAT_SLICED, tile_w=1000)
     assert np.array_equal(mi.decompress_image(s).pixels, img)
+
+
+def test_abi1_opts_struct_still_accepted(mi, orc):
+    """llcomp_mi_opts grew a trailing field in ABI 2 (small_model); a caller compiled against ABI 1 passes struct_size 24."""
+    import ctypes as C
+
+    from llcomp_amd import _lib
+
+    class Opts1(C.Structure):
+        _fields_ = [("struct_size", C.c_uint32), ("format", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32),
+                    ("planar", C.c_uint32), ("device", C.c_int32)]
+
+    img = make_image("mid", 50, 20, 3)
+    L = _lib.load()
+    o = Opts1(24, mi.FORMAT_SLICED, 16, 1, 1, -1)
+    out, n = _lib.u8p(), C.c_size_t()
+    rc = L.llcomp_mi_encode(img.ctypes.data_as(_lib.u8p), 50, 20, 3, C.cast(C.byref(o), C.POINTER(_lib.Opts)), C.byref(out), C.byref(n))
+    assert rc == mi.OK
+    try:
+        assert C.string_at(out, n.value) == orc.compress_sliced(img, 16, 1, True)
+    finally:
+        L.llcomp_mi_free(out)
+    o.struct_size = 20
+    assert L.llcomp_mi_encode(img.ctypes.data_as(_lib.u8p), 50, 20, 3, C.cast(C.byref(o), C.POINTER(_lib.Opts)), C.byref(out), C.byref(n)) == mi.BAD_ARGS
 
 
 # ---- stage A kernel alone vs the oracle's intermediate dump ------------------------------------------------------
