@@ -184,6 +184,34 @@ def test_error_codes(mi):
     assert np.array_equal(mi.decompress_image(s).pixels, img)
 
 
+@pytest.mark.parametrize("shape", [(65535, 1, 1), (1, 65535, 3), (65535, 2, 2)])
+def test_legacy_header_maximum_dimensions(mi, orc, shape):
+    """the largest width / height the reference's u16 header fields hold (llcomp.hpp:377-378); one more is OUT_OF_RANGE"""
+    w, h, c = shape
+    rng = np.random.default_rng(w + h)
+    img = (np.cumsum(rng.integers(-3, 4, size=(h, w, c)), axis=1 if w > 1 else 0) & 0xFF).astype(np.uint8)
+    s = mi.compress_image(img, w, h, c)
+    assert s == orc.compress_image(img)
+    out = mi.decompress_image(s)
+    assert (out.width, out.height, out.channels) == (w, h, c) and np.array_equal(out.pixels, img)
+    with pytest.raises(mi.LlcompError) as e:
+        mi.compress_image(np.zeros((h + (w == 1), w + (w > 1), c), np.uint8), w + (w > 1), h + (w == 1), c)
+    assert e.value.status == mi.OUT_OF_RANGE
+
+
+def test_empty_and_mismatched_inputs_are_rejected(mi):
+    for w, h, c in ((0, 4, 3), (4, 0, 3), (4, 4, 0)):
+        with pytest.raises(mi.LlcompError) as e:
+            mi.compress_image(np.zeros(0, np.uint8), w, h, c)
+        assert e.value.status == mi.BAD_ARGS
+    with pytest.raises(mi.LlcompError) as e:   # the reference only asserts size == w*h*c (llcomp.hpp:361)
+        mi.compress_image(np.zeros(47, np.uint8), 4, 4, 3)
+    assert e.value.status == mi.BAD_ARGS
+    with pytest.raises(mi.LlcompError) as e:   # degenerate header: zero width
+        mi.decompress_image(bytes([0x79, 3, 0, 0, 4, 0, 1, 2, 3]))
+    assert e.value.status == mi.BAD_ARGS
+
+
 def test_abi1_opts_struct_still_accepted(mi, orc):
     """llcomp_mi_opts grew a trailing field in ABI 2 (small_model); a caller compiled against ABI 1 passes struct_size 24."""
     import ctypes as C
@@ -369,6 +397,12 @@ def test_cli_roundtrip_matches_reference_behaviour(mi, orc, tmp_path):
     ppm = tmp_path / "a.ppm"
     ppm.write_bytes(b"P6\n# comment\n61 47\n255\n" + img.tobytes())
     assert subprocess.run([exe_c]).returncode == 1                      # usage
+    big = tmp_path / "big.pgm"                                          # > 1 MPix in the reference's format: a note on stderr
+    big.write_bytes(b"P5\n1100 1000\n255\n" + bytes(1100 * 1000))
+    r = subprocess.run([exe_c, str(big)], capture_output=True, text=True)
+    assert r.returncode == 0 and "single-stream format" in r.stderr
+    r = subprocess.run([exe_c, str(big), "--legacy"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stderr == "" and (tmp_path / "big.pgm.llcomp").read_bytes()[:6] == bytes([0x79, 1, 0x4C, 0x04, 0xE8, 0x03])
     assert subprocess.run([exe_c, str(tmp_path / "missing.ppm")]).returncode == 1
     assert subprocess.run([exe_c, str(ppm)]).returncode == 0
     stream = (tmp_path / "a.ppm.llcomp").read_bytes()                   # llcompc.cpp:34: <path> + ".llcomp"
