@@ -1,0 +1,158 @@
+// llcomp_stream [frames] [width] [height] [tile_w] [tile_h] [depth] [encodes_in_flight]
+//
+// BASELINE config 5 driven from C++ through the C ABI alone (include/llcomp_mi.h, llcomp_mi_stream_*): `frames` distinct
+// RGB8 noise frames stream host -> GPU -> host (SLICED container) -> GPU -> host with `depth` pipeline slots; every decoded
+// frame is compared with its source (memcmp on worker threads); prints one JSON line with the steady-state rate (first 4
+// frames excluded) and the compression ratio.  The reference's counterpart is a loop of llcompc / llcompd runs, one image
+// per process (llcompc.cpp:25-41, llcompd.cpp:17-31).  This is also the example INTEGRATION.md points at for the pipeline:
+// pinned source buffers, back-pressure (LLCOMP_MI_BUSY), an encode result handed to submit_decode as it is.
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "../include/llcomp_mi.h"
+
+namespace {
+
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+void fill_noise(uint8_t* p, size_t n, uint64_t seed) {  // xorshift64*: incompressible bytes, different per frame
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+        const uint64_t v = x * 0x2545F4914F6CDD1Dull;
+        std::memcpy(p + i, &v, 8);
+    }
+    for (; i < n; ++i) p[i] = uint8_t(x >> (8 * (i & 7)));
+}
+
+struct Check {  // a decoded frame waiting for its comparison; the slot is released by the main thread afterwards
+    uint32_t slot;
+    uint64_t tag;
+    const uint8_t* got;
+};
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    const uint32_t n = argc > 1 ? uint32_t(std::atoi(argv[1])) : 64;
+    const uint32_t w = argc > 2 ? uint32_t(std::atoi(argv[2])) : 3840, h = argc > 3 ? uint32_t(std::atoi(argv[3])) : 2160, c = 3;
+    const uint32_t tw = argc > 4 ? uint32_t(std::atoi(argv[4])) : 480, th = argc > 5 ? uint32_t(std::atoi(argv[5])) : 1;
+    const uint32_t depth = argc > 6 ? uint32_t(std::atoi(argv[6])) : 16, max_enc = argc > 7 ? uint32_t(std::atoi(argv[7])) : 6;
+    const size_t raw = size_t(w) * h * c;
+    if (!n || !raw) return 1;
+
+    llcomp_mi_stream* st = nullptr;
+    if (int rc = llcomp_mi_stream_create(&st, -1, w, h, c, tw, th, 1, depth)) {
+        std::fprintf(stderr, "llcomp_mi_stream_create: %s\n", llcomp_mi_strerror(rc));
+        return 1;
+    }
+    uint8_t* src = static_cast<uint8_t*>(llcomp_mi_host_alloc(raw * n));  // pinned: the H2D copies are plain DMA
+    if (!src) {
+        std::fprintf(stderr, "llcomp_mi_host_alloc failed\n");
+        return 1;
+    }
+    for (uint32_t i = 0; i < n; ++i) fill_noise(src + raw * i, raw, 1234 + i);
+
+    // comparison workers
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Check> todo, done;
+    std::atomic<bool> quit{false}, mismatch{false};
+    std::vector<std::thread> workers;
+    for (int t = 0; t < 3; ++t)
+        workers.emplace_back([&] {
+            for (;;) {
+                Check k;
+                {
+                    std::unique_lock<std::mutex> lock(mu);
+                    cv.wait(lock, [&] { return quit || !todo.empty(); });
+                    if (todo.empty()) return;
+                    k = todo.front();
+                    todo.pop_front();
+                }
+                if (std::memcmp(k.got, src + raw * k.tag, raw) != 0) mismatch = true;
+                std::lock_guard<std::mutex> lock(mu);
+                done.push_back(k);
+            }
+        });
+
+    std::vector<double> done_at(n, 0.0);
+    std::vector<llcomp_mi_stream_result> enc_held(n);  // encode results whose containers a decode job still reads
+    std::deque<llcomp_mi_stream_result> to_decode;
+    uint64_t container_bytes = 0;
+    uint32_t next = 0, finished = 0, enc_in_flight = 0, busy = 0;
+    int fail = 0;
+    const double t0 = now();
+    while (finished < n && !fail) {
+        bool progressed = false;
+        {  // frames whose comparison is done: give their slots back
+            std::lock_guard<std::mutex> lock(mu);
+            while (!done.empty()) {
+                llcomp_mi_stream_release(st, done.front().slot);
+                done.pop_front();
+                ++finished;
+                progressed = true;
+            }
+        }
+        while (!to_decode.empty()) {  // containers first: their decode frees two slots
+            const llcomp_mi_stream_result& r = to_decode.front();
+            const int rc = llcomp_mi_stream_submit_decode(st, r.data, size_t(r.len), r.tag);
+            if (rc == LLCOMP_MI_BUSY) { ++busy; break; }
+            if (rc) { fail = rc; break; }
+            enc_held[r.tag] = r;
+            to_decode.pop_front();
+            progressed = true;
+        }
+        while (!fail && next < n && enc_in_flight < max_enc && to_decode.empty()) {
+            const int rc = llcomp_mi_stream_submit_encode(st, src + raw * next, next);
+            if (rc == LLCOMP_MI_BUSY) { ++busy; break; }
+            if (rc) { fail = rc; break; }
+            ++next;
+            ++enc_in_flight;
+            progressed = true;
+        }
+        if (fail) break;
+        if (llcomp_mi_stream_pending(st) > 0 && (!progressed || llcomp_mi_stream_poll(st) == LLCOMP_MI_OK)) {
+            llcomp_mi_stream_result r;
+            if (int rc = llcomp_mi_stream_wait(st, &r)) { fail = rc; break; }
+            if (r.status) { fail = r.status; break; }
+            if (r.kind == LLCOMP_MI_JOB_ENCODE) {
+                --enc_in_flight;
+                container_bytes += r.len;
+                to_decode.push_back(r);
+            } else {
+                done_at[r.tag] = now() - t0;
+                llcomp_mi_stream_release(st, enc_held[r.tag].slot);
+                std::lock_guard<std::mutex> lock(mu);
+                todo.push_back({r.slot, r.tag, r.data});
+                cv.notify_one();
+            }
+        } else if (!progressed) {
+            std::this_thread::sleep_for(std::chrono::microseconds(50));  // every slot is held by a frame being compared
+        }
+    }
+    quit = true;
+    cv.notify_all();
+    for (auto& t : workers) t.join();
+    llcomp_mi_stream_destroy(st);
+    llcomp_mi_host_free(src);
+    if (fail || mismatch) {
+        std::fprintf(stderr, "llcomp_stream: %s\n", fail ? llcomp_mi_strerror(fail) : "a decoded frame differs from its source");
+        return 1;
+    }
+    const uint32_t skip = n > 8 ? 4 : 0;
+    const double steady = double(n - skip) * w * h / 1e6 / (done_at[n - 1] - (skip ? done_at[skip - 1] : 0.0));
+    std::printf("{\"frames\": %u, \"width\": %u, \"height\": %u, \"tile\": \"%ux%u\", \"depth\": %u, \"steady_mpix_s\": %.1f, \"compression_ratio\": %.4f, "
+                "\"backpressure_hits\": %u, \"verified\": true}\n",
+                n, w, h, tw, th, depth, steady, double(raw) * n / double(container_bytes), busy);
+    return 0;
+}
