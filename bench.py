@@ -222,23 +222,27 @@ def profile_numbers(F, tile_w, tile_h, planar, content, S, dom):
     return None, None, None
 
 
-def c5_stream(frames_np, tile_w, tile_h, planar, depth=16):
+def c5_stream(frames_np, tile_w, tile_h, planar, depth=8, frames_per_job=4):
     """BASELINE config 5, PCIe inclusive: the frames stream host -> GPU -> host (container) -> GPU -> host through the
-    product's pipeline (llcomp_mi_stream_*), twice over the batch; every frame verified bit-exact."""
+    product's pipeline (llcomp_mi_stream_*, jobs of `frames_per_job` frames), twice over the batch; every frame verified
+    bit-exact."""
     import llcomp_amd as mi
 
     F, h, w, c = frames_np.shape
-    pinned = mi.PinnedBuffer(frames_np.size)
-    pinned.array[:] = frames_np.reshape(-1)
+    F -= F % frames_per_job
+    pinned = mi.PinnedBuffer(F * h * w * c)
+    pinned.array[:] = frames_np[:F].reshape(-1)
     views = [pinned.array[i * h * w * c:(i + 1) * h * w * c].reshape(h, w, c) for i in range(F)]
-    st = mi.Stream(w, h, c, tile_w, tile_h, planar, depth=depth)
+    st = mi.Stream(w, h, c, tile_w, tile_h, planar, depth=depth, frames_per_job=frames_per_job)
     jobs = views + views
-    lens, done_at, busy = mi.pipeline_roundtrip(st, jobs, max_encodes_in_flight=6, verify=True, verify_threads=6)
+    lens, done_at, busy = mi.pipeline_roundtrip(st, jobs, max_encodes_in_flight=3, verify=True, verify_threads=6)
     st.close()
     n = len(jobs)
-    steady = (n - 4) * w * h / 1e6 / (done_at[-1] - done_at[3])
+    skip = max(4, frames_per_job)  # the first 4 frames = the first job
+    steady = (n - skip) * w * h / 1e6 / (done_at[-1] - done_at[skip - 1])
     pinned.close()
-    return {"value": round(steady, 1), "unit": "MPix/s", "frames": n, "depth": depth, "compression_ratio": round(n * h * w * c / sum(lens), 4),
+    return {"value": round(steady, 1), "unit": "MPix/s", "frames": n, "frames_per_job": frames_per_job, "depth": depth,
+            "compression_ratio": round(n * h * w * c / sum(lens), 4),
             "pcie_bytes_per_frame": int(2 * (h * w * c + sum(lens) / n)), "backpressure_hits": busy,
             "note": "end to end over PCIe from/to pinned host memory, steady state (first 4 frames excluded), every frame bit-exact; never part of `value`"}
 

@@ -183,6 +183,15 @@ typedef struct llcomp_mi_stream_result {
 } llcomp_mi_stream_result;
 int llcomp_mi_stream_create(llcomp_mi_stream** stream, int32_t device, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w,
                             uint32_t tile_h, uint32_t planar, uint32_t depth);
+/* Jobs of `frames_per_job` (1..64) frames: larger launches for the GPU, larger copies for the link.  submit_encode then
+ * takes frames_per_job frames back to back, llcomp_mi_stream_submit_decode_batch that many containers; a result describes
+ * the whole job (encode: all containers back to back, decode: all frames back to back) and llcomp_mi_stream_result_part
+ * hands out container / frame f of a result that has been returned by wait and not yet released. */
+int llcomp_mi_stream_create_ex(llcomp_mi_stream** stream, int32_t device, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w,
+                               uint32_t tile_h, uint32_t planar, uint32_t depth, uint32_t frames_per_job);
+uint32_t llcomp_mi_stream_frames_per_job(const llcomp_mi_stream* stream);
+int llcomp_mi_stream_submit_decode_batch(llcomp_mi_stream* stream, const uint8_t* const* data, const size_t* lens, uint64_t tag);
+int llcomp_mi_stream_result_part(llcomp_mi_stream* stream, uint32_t slot, uint32_t frame, const uint8_t** data, uint64_t* len);
 void llcomp_mi_stream_destroy(llcomp_mi_stream* stream);
 uint64_t llcomp_mi_stream_container_capacity(const llcomp_mi_stream* stream); /* largest container a slot can return */
 int llcomp_mi_stream_submit_encode(llcomp_mi_stream* stream, const uint8_t* px, uint64_t tag);

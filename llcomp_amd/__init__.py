@@ -132,15 +132,18 @@ StreamJob = namedtuple("StreamJob", "slot kind status tag data")
 
 
 class Stream:
-    """Streaming pipeline (llcomp_mi_stream_*): frames of one shape, host -> GPU -> host, `depth` jobs in flight.
-    submit_* return False instead of blocking when every slot is occupied (back-pressure); wait() returns the oldest
-    job as StreamJob whose .data is a numpy view of the stream's pinned output buffer, valid until release(job)."""
+    """Streaming pipeline (llcomp_mi_stream_*): frames of one shape, host -> GPU -> host, `depth` jobs in flight, a job =
+    `frames_per_job` frames.  submit_* return False instead of blocking when every slot is occupied (back-pressure);
+    wait() returns the oldest job as StreamJob, valid until release(job).  Its .data is a numpy view of the stream's pinned
+    output buffer: frames_per_job == 1: the container (encode) / the frame [h,w,c] (decode); more frames per job: a list of
+    containers (encode) / the frames [F,h,w,c] (decode)."""
 
-    def __init__(self, w, h, c, tile_w=0, tile_h=0, planar=True, depth=4, device=-1):
+    def __init__(self, w, h, c, tile_w=0, tile_h=0, planar=True, depth=4, device=-1, frames_per_job=1):
         self._L = _lib.load()
         self._h = C.c_void_p()
-        _check(self._L.llcomp_mi_stream_create(C.byref(self._h), device, w, h, c, tile_w, tile_h, int(bool(planar)), depth))
+        _check(self._L.llcomp_mi_stream_create_ex(C.byref(self._h), device, w, h, c, tile_w, tile_h, int(bool(planar)), depth, frames_per_job))
         self.shape = (h, w, c)
+        self.frames_per_job = frames_per_job
         self.container_capacity = self._L.llcomp_mi_stream_container_capacity(self._h)
 
     def close(self):
@@ -157,14 +160,19 @@ class Stream:
         return True
 
     def submit_encode(self, px, tag=0):
-        """px: numpy uint8 [h,w,c] (C-contiguous); must stay alive and unchanged until its result came back."""
-        assert px.flags["C_CONTIGUOUS"] and px.dtype == np.uint8 and px.size == self.shape[0] * self.shape[1] * self.shape[2]
+        """px: numpy uint8, frames_per_job frames [h,w,c] back to back (C-contiguous); must stay alive and unchanged until
+        the job's result came back."""
+        assert px.flags["C_CONTIGUOUS"] and px.dtype == np.uint8 and px.size == self.frames_per_job * self.shape[0] * self.shape[1] * self.shape[2]
         return self._submit(self._L.llcomp_mi_stream_submit_encode(self._h, px.ctypes.data, tag))
 
     def submit_decode(self, data, tag=0):
-        """data: numpy uint8 container (e.g. the .data of an encode job that has not been released yet)."""
-        assert data.flags["C_CONTIGUOUS"] and data.dtype == np.uint8
-        return self._submit(self._L.llcomp_mi_stream_submit_decode(self._h, data.ctypes.data, data.size, tag))
+        """data: numpy uint8 container (frames_per_job == 1) or a list of frames_per_job containers -- e.g. the .data of an
+        encode job that has not been released yet."""
+        parts = [data] if self.frames_per_job == 1 and not isinstance(data, (list, tuple)) else list(data)
+        assert len(parts) == self.frames_per_job and all(p.flags["C_CONTIGUOUS"] and p.dtype == np.uint8 for p in parts)
+        ptrs = (C.c_void_p * len(parts))(*[p.ctypes.data for p in parts])
+        lens = (C.c_size_t * len(parts))(*[p.size for p in parts])
+        return self._submit(self._L.llcomp_mi_stream_submit_decode_batch(self._h, ptrs, lens, tag))
 
     def pending(self):
         return self._L.llcomp_mi_stream_pending(self._h)
@@ -177,9 +185,17 @@ class Stream:
         _check(self._L.llcomp_mi_stream_wait(self._h, C.byref(r)))
         data = None
         if r.status == OK:
-            data = np.ctypeslib.as_array(C.cast(r.data, _lib.u8p), shape=(max(int(r.len), 1),))[: int(r.len)]
+            whole = np.ctypeslib.as_array(C.cast(r.data, _lib.u8p), shape=(max(int(r.len), 1),))[: int(r.len)]
             if r.kind == JOB_DECODE:
-                data = data.reshape(self.shape)
+                data = whole.reshape(self.shape) if self.frames_per_job == 1 else whole.reshape((self.frames_per_job,) + self.shape)
+            elif self.frames_per_job == 1:
+                data = whole
+            else:
+                data = []
+                for f in range(self.frames_per_job):
+                    p, n = C.c_void_p(), C.c_uint64()
+                    _check(self._L.llcomp_mi_stream_result_part(self._h, r.slot, f, C.byref(p), C.byref(n)))
+                    data.append(np.ctypeslib.as_array(C.cast(p, _lib.u8p), shape=(max(int(n.value), 1),))[: int(n.value)])
         return StreamJob(r.slot, r.kind, r.status, r.tag, data)
 
     def release(self, job):
@@ -198,18 +214,32 @@ def _same_bytes(a, b):
 
 def pipeline_roundtrip(stream, frames, max_encodes_in_flight=3, on_container=None, verify=True, verify_threads=4):
     """Drives BASELINE config 5 through a Stream: every frame host -> GPU -> host (container) -> GPU -> host.  An encode
-    result (pinned container) is handed to submit_decode as it is and released only when that decode has come back;
+    result (pinned containers) is handed to submit_decode as it is and released only when that decode has come back;
     submit_* returning False (back-pressure) makes the loop take a finished job first.  frames: list of C-contiguous
-    uint8 arrays (pinned for DMA).  Returns (container lengths, completion time of every frame in seconds, number of
-    times back-pressure was hit).  on_container(i, bytes_view) sees every container; verify compares every decoded frame
-    with its source bit for bit -- on a few worker threads (numpy releases the GIL), the slot is released afterwards."""
+    uint8 arrays (pinned for DMA); with frames_per_job > 1 consecutive frames of a job must be adjacent in memory (views
+    of one buffer) and len(frames) a multiple of it.  Returns (container lengths, completion time of every frame in
+    seconds, number of times back-pressure was hit).  on_container(i, bytes_view) sees every container; verify compares
+    every decoded frame with its source bit for bit -- on a few worker threads (numpy releases the GIL), the slot is
+    released afterwards."""
     import time
     from concurrent.futures import ThreadPoolExecutor
 
+    F = stream.frames_per_job
     n = len(frames)
+    assert n % F == 0, "the number of frames must be a multiple of frames_per_job"
+    n_jobs = n // F
+    raw = frames[0].size
+    jobs_px = []
+    for j in range(n_jobs):
+        if F == 1:
+            jobs_px.append(frames[j])
+        else:
+            base = frames[j * F].ctypes.data
+            assert all(frames[j * F + f].ctypes.data == base + f * raw for f in range(F)), "the frames of a job must be adjacent in memory"
+            jobs_px.append(np.ctypeslib.as_array(C.cast(base, _lib.u8p), shape=(F * raw,)))
     lens, done_at, busy_seen = [0] * n, [0.0] * n, 0
     enc_held, to_decode, checking = {}, [], []
-    next_frame = finished = enc_in_flight = 0
+    next_job = finished = enc_in_flight = 0
     pool = ThreadPoolExecutor(max_workers=verify_threads) if verify and verify_threads > 0 else None
 
     def reap(block):
@@ -217,14 +247,14 @@ def pipeline_roundtrip(stream, frames, max_encodes_in_flight=3, on_container=Non
         while checking and (block or checking[0][0].done()):
             fut, job = checking.pop(0)
             if not fut.result():
-                raise AssertionError(f"frame {job.tag} is not bit-exact after the round trip")
+                raise AssertionError(f"job {job.tag} (frames {job.tag * F}..{job.tag * F + F - 1}) is not bit-exact after the round trip")
             stream.release(job)
             finished += 1
             block = False
 
     t0 = time.perf_counter()
     try:
-        while finished < n:
+        while finished < n_jobs:
             progressed = False
             reap(False)
             while to_decode:  # containers first: their decode frees two slots
@@ -235,11 +265,11 @@ def pipeline_roundtrip(stream, frames, max_encodes_in_flight=3, on_container=Non
                 enc_held[job.tag] = job
                 to_decode.pop(0)
                 progressed = True
-            while next_frame < n and enc_in_flight < max_encodes_in_flight and not to_decode:
-                if not stream.submit_encode(frames[next_frame], tag=next_frame):
+            while next_job < n_jobs and enc_in_flight < max_encodes_in_flight and not to_decode:
+                if not stream.submit_encode(jobs_px[next_job], tag=next_job):
                     busy_seen += 1
                     break
-                next_frame += 1
+                next_job += 1
                 enc_in_flight += 1
                 progressed = True
             if stream.pending() and (not progressed or stream.ready()):
@@ -248,22 +278,25 @@ def pipeline_roundtrip(stream, frames, max_encodes_in_flight=3, on_container=Non
                     raise LlcompError(job.status)
                 if job.kind == JOB_ENCODE:
                     enc_in_flight -= 1
-                    lens[job.tag] = job.data.size
-                    if on_container:
-                        on_container(job.tag, job.data)
+                    for f, cont in enumerate([job.data] if F == 1 else job.data):
+                        lens[job.tag * F + f] = cont.size
+                        if on_container:
+                            on_container(job.tag * F + f, cont)
                     to_decode.append(job)
                 else:
-                    done_at[job.tag] = time.perf_counter() - t0
+                    now = time.perf_counter() - t0
+                    for f in range(F):
+                        done_at[job.tag * F + f] = now
                     stream.release(enc_held.pop(job.tag))
                     if pool:
-                        checking.append((pool.submit(_same_bytes, job.data, frames[job.tag]), job))
+                        checking.append((pool.submit(_same_bytes, job.data, jobs_px[job.tag]), job))
                     else:
-                        if verify and not _same_bytes(job.data, frames[job.tag]):
-                            raise AssertionError(f"frame {job.tag} is not bit-exact after the round trip")
+                        if verify and not _same_bytes(job.data, jobs_px[job.tag]):
+                            raise AssertionError(f"job {job.tag} is not bit-exact after the round trip")
                         stream.release(job)
                         finished += 1
             elif not progressed:
-                reap(True)  # every slot is held by a frame that is being compared
+                reap(True)  # every slot is held by frames that are being compared
     finally:
         if pool:
             pool.shutdown(wait=True)

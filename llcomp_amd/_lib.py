@@ -18,7 +18,8 @@ SYMBOLS = [
     "llcomp_mi_codec_set_profiling", "llcomp_mi_codec_get_profile",
     "llcomp_mi_encode_into", "llcomp_mi_decode_into", "llcomp_mi_host_alloc", "llcomp_mi_host_free",
     "llcomp_mi_reload_tuning", "llcomp_mi_device_copy_segments", "llcomp_mi_decode_flags", "llcomp_mi_codec_create_ex",
-    "llcomp_mi_stream_create", "llcomp_mi_stream_destroy", "llcomp_mi_stream_container_capacity",
+    "llcomp_mi_stream_create", "llcomp_mi_stream_create_ex", "llcomp_mi_stream_frames_per_job", "llcomp_mi_stream_submit_decode_batch",
+    "llcomp_mi_stream_result_part", "llcomp_mi_stream_destroy", "llcomp_mi_stream_container_capacity",
     "llcomp_mi_stream_submit_encode", "llcomp_mi_stream_submit_decode", "llcomp_mi_stream_pending",
     "llcomp_mi_stream_poll", "llcomp_mi_stream_wait", "llcomp_mi_stream_release",
 ]
@@ -135,6 +136,14 @@ def load():
     L.llcomp_mi_reload_tuning.argtypes = []
     L.llcomp_mi_stream_create.restype = C.c_int
     L.llcomp_mi_stream_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32] + [C.c_uint32] * 7
+    L.llcomp_mi_stream_create_ex.restype = C.c_int
+    L.llcomp_mi_stream_create_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int32] + [C.c_uint32] * 8
+    L.llcomp_mi_stream_frames_per_job.restype = C.c_uint32
+    L.llcomp_mi_stream_frames_per_job.argtypes = [C.c_void_p]
+    L.llcomp_mi_stream_submit_decode_batch.restype = C.c_int
+    L.llcomp_mi_stream_submit_decode_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_uint64]
+    L.llcomp_mi_stream_result_part.restype = C.c_int
+    L.llcomp_mi_stream_result_part.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.llcomp_mi_stream_destroy.restype = None
     L.llcomp_mi_stream_destroy.argtypes = [C.c_void_p]
     L.llcomp_mi_stream_container_capacity.restype = C.c_uint64

@@ -68,25 +68,27 @@ struct HostLane {
     uint8_t* d_px = nullptr;
     uint8_t* d_container = nullptr;  // [header][u32 length table (sliced only)][payload capacity]
     uint32_t* d_len_legacy = nullptr;  // the legacy format has no table on the wire: its single length lives here
-    uint64_t* d_meta = nullptr;      // [0] payload bytes (u64)  [1] low dword: status bits of the last call
+    uint64_t* d_meta = nullptr;      // [0] payload bytes (u64)  [1] low dword: status bits of the last call  [2 + f] payload bytes of frame f
     uint64_t* h_meta = nullptr;      // pinned mirror of d_meta
+    uint32_t frames = 1;             // frames per call (> 1 only in the streaming pipeline)
     uint64_t payload_cap = 0;
-    uint32_t head_bytes = 0;         // 6 (legacy) or 24 + 4 * slices
+    uint32_t head_bytes = 0;         // 6 (legacy) or 24 + 4 * slices (all frames' tables back to back)
     bool legacy = false;
     uint64_t bytes = 0;              // device bytes held (idle-cache budget)
 
     uint32_t* d_len() const { return legacy ? d_len_legacy : reinterpret_cast<uint32_t*>(d_container + LLCOMP_MI_SLICED_HEADER_BYTES); }
     uint8_t* d_payload() const { return d_container + head_bytes; }
-    uint64_t raw_bytes() const { return uint64_t(k->g.w) * k->g.h * k->g.c; }
+    uint64_t raw_bytes() const { return uint64_t(k->g.w) * k->g.h * k->g.c * frames; }
+    size_t meta_bytes() const { return 16 + 8 * size_t(frames); }
 };
 // builds a lane for this shape on `dev` (geometry + tuning hooks are fixed here); payload capacity `cap` bytes
 int lane_create(HostLane** out, int dev, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar,
-                bool legacy, uint64_t payload_cap, bool small_model = false);
+                bool legacy, uint64_t payload_cap, bool small_model = false, uint32_t frames = 1);
 int lane_grow(HostLane* l, uint64_t payload_cap);  // reallocates the container buffer (contents lost)
 void lane_destroy(HostLane* l);
 // enqueue on the lane's stream (asynchronous): frame in d_px -> container in d_container, {bytes, status} -> h_meta
 int lane_enqueue_encode(HostLane* l);
-// container in d_container (`len` bytes including the header) -> frame in d_px, status -> h_meta
-int lane_enqueue_decode(HostLane* l, uint64_t len);
+// container in d_container (header + tables + `payload_bytes` of payload) -> frame(s) in d_px, status -> h_meta
+int lane_enqueue_decode(HostLane* l, uint64_t payload_bytes);
 
 }  // namespace llcomp_mi

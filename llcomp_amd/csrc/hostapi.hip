@@ -66,12 +66,13 @@ int lane_grow(HostLane* l, uint64_t payload_cap) {
 }
 
 int lane_create(HostLane** out, int dev, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar,
-                bool legacy, uint64_t payload_cap, bool small_model) {
+                bool legacy, uint64_t payload_cap, bool small_model, uint32_t frames) {
     *out = nullptr;
     HostLane* l = new (std::nothrow) HostLane;
     if (!l) return LLCOMP_MI_NOMEM;
     l->legacy = legacy;
-    if (int rc = llcomp_mi_codec_create_ex(&l->k, dev, 1, w, h, c, tile_w, tile_h, planar, small_model ? LLCOMP_MI_FLAG_SMALL_MODEL : 0)) {
+    l->frames = frames;
+    if (int rc = llcomp_mi_codec_create_ex(&l->k, dev, frames, w, h, c, tile_w, tile_h, planar, small_model ? LLCOMP_MI_FLAG_SMALL_MODEL : 0)) {
         delete l;
         return rc;
     }
@@ -82,8 +83,8 @@ int lane_create(HostLane** out, int dev, uint32_t w, uint32_t h, uint32_t c, uin
     const bool ok = guard.ok && hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) == hipSuccess &&
                     hipMalloc(reinterpret_cast<void**>(&l->d_px), raw + 4) == hipSuccess &&
                     hipMalloc(reinterpret_cast<void**>(&l->d_len_legacy), 4) == hipSuccess &&
-                    hipMalloc(reinterpret_cast<void**>(&l->d_meta), 16) == hipSuccess &&
-                    hipHostMalloc(reinterpret_cast<void**>(&l->h_meta), 16, hipHostMallocDefault) == hipSuccess;
+                    hipMalloc(reinterpret_cast<void**>(&l->d_meta), l->meta_bytes()) == hipSuccess &&
+                    hipHostMalloc(reinterpret_cast<void**>(&l->h_meta), l->meta_bytes(), hipHostMallocDefault) == hipSuccess;
     if (!ok) {
         lane_destroy(l);
         return LLCOMP_MI_NOMEM;
@@ -100,12 +101,12 @@ int lane_create(HostLane** out, int dev, uint32_t w, uint32_t h, uint32_t c, uin
 int lane_enqueue_encode(HostLane* l) {
     if (int rc = llcomp_mi_codec_encode(l->k, l->d_px, l->d_payload(), l->payload_cap, l->d_len(), l->d_meta, l->d_meta + 1, l->stream))
         return rc;
-    LLMI_HIP_TRY(hipMemcpyAsync(l->h_meta, l->d_meta, 16, hipMemcpyDeviceToHost, l->stream));
+    if (l->frames > 1) LLMI_HIP_TRY(launch_frame_bytes(l->k->g, l->d_len(), l->d_meta + 2, l->stream));
+    LLMI_HIP_TRY(hipMemcpyAsync(l->h_meta, l->d_meta, l->meta_bytes(), hipMemcpyDeviceToHost, l->stream));
     return LLCOMP_MI_OK;
 }
 
-int lane_enqueue_decode(HostLane* l, uint64_t len) {
-    const uint64_t payload_bytes = len - l->head_bytes;
+int lane_enqueue_decode(HostLane* l, uint64_t payload_bytes) {
     if (l->legacy) {
         const uint32_t one = uint32_t(std::min<uint64_t>(payload_bytes, 0xFFFFFFFFull));
         LLMI_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(l->d_len_legacy), int(one), 1, l->stream));
@@ -260,7 +261,7 @@ int decode_common(const uint8_t* data, size_t len, int32_t device, uint32_t flag
     if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
     // the container goes to HBM as it is: the slice table is read where it lies (offset 24, dword aligned)
     LLMI_HIP_TRY(hipMemcpyAsync(l->d_container, data, len, hipMemcpyHostToDevice, l->stream));
-    if (int rc = lane_enqueue_decode(l, len)) return rc;
+    if (int rc = lane_enqueue_decode(l, len - l->head_bytes)) return rc;
     LLMI_HIP_TRY(hipStreamSynchronize(l->stream));
     if (int rc = status_from_bits(uint32_t(l->h_meta[1]))) return rc;
     uint8_t* dst = px;

@@ -50,6 +50,8 @@ hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* 
 bool encoder_writes_group_sums(const Geometry& g);
 hipError_t launch_group_sums(const Geometry& g, const uint32_t* d_slice_len, uint64_t* d_group_off, hipStream_t stream);
 hipError_t launch_scan_groups(const Geometry& g, uint64_t* d_group_off, uint64_t* d_total, hipStream_t stream);
+// u64[frames]: payload bytes of every frame (sum of its slices' lengths)
+hipError_t launch_frame_bytes(const Geometry& g, const uint32_t* d_slice_len, uint64_t* d_frame_bytes, hipStream_t stream);
 // Slice streams live in STREAM LANE ORDER for the serial kernels: 16-byte units [group][unit][lane], slice_cap/16 units
 // per slice (model_kernels.hip).  pack: that order -> payload (slices back to back, capacity payload_cap);
 // stage: payload -> that order.

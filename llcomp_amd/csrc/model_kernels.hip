@@ -253,6 +253,19 @@ __global__ __launch_bounds__(256) void k_group_sums(const uint32_t* __restrict__
     if ((i & ((1u << lane_shift) - 1)) == 0 && i < n) group_sum[i >> lane_shift] = v;
 }
 
+// payload bytes of every frame of a batch (sum of its slices' lengths): what a host needs to cut a batch's packed
+// payload into per-frame containers (stream.hip, jobs of several frames)
+__global__ __launch_bounds__(256) void k_frame_bytes(const uint32_t* __restrict__ len, uint32_t slices_per_frame, uint64_t* __restrict__ out) {
+    __shared__ unsigned long long part[4];
+    const uint32_t* p = len + size_t(blockIdx.x) * slices_per_frame;
+    unsigned long long v = 0;
+    for (uint32_t i = threadIdx.x; i < slices_per_frame; i += 256) v += p[i];
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
 constexpr uint32_t kScanThreads = 256, kScanPerThread = 4;
 // in: sums[0 .. ng)   out: sums[g] = sum of the groups before g, sums[ng] = *total = sum of all
 __global__ __launch_bounds__(kScanThreads) void k_scan_groups(uint64_t* __restrict__ sums, uint32_t ng, uint64_t* total) {
@@ -794,6 +807,11 @@ hipError_t launch_model_inv(const Geometry& g, const int16_t* d_rec, uint8_t* d_
 
 hipError_t launch_group_sums(const Geometry& g, const uint32_t* d_slice_len, uint64_t* d_group_off, hipStream_t stream) {
     k_group_sums<<<dim3((g.n_slices + 255) / 256), dim3(256), 0, stream>>>(d_slice_len, g.n_slices, g.lane_shift, d_group_off);
+    return hipGetLastError();
+}
+
+hipError_t launch_frame_bytes(const Geometry& g, const uint32_t* d_slice_len, uint64_t* d_frame_bytes, hipStream_t stream) {
+    k_frame_bytes<<<dim3(g.frames), dim3(256), 0, stream>>>(d_slice_len, g.slices_per_frame, d_frame_bytes);
     return hipGetLastError();
 }
 

@@ -2,8 +2,9 @@
 // host -> GPU -> host with several jobs in flight (BASELINE config 5).  The reference codes one image in
 // RAM per call (llcompc.cpp:25-41, llcompd.cpp:17-31); this is the same operation as a pipeline.
 //
-// `depth` slots, each a HostLane (codec object for one frame, private HIP stream, frame + container in HBM in wire
-// layout) plus a pinned output buffer.  A job is one frame:
+// `depth` slots, each a HostLane (codec object for the frames of one job, private HIP stream, frames + containers in HBM)
+// plus a pinned output buffer.  A job is `frames_per_job` frames (1 by default; a few frames per job give the GPU larger
+// launches and the link larger copies), every frame its own SLICED container:
 //   encode  H2D frame -> kernels -> D2H {payload bytes, status} (16 B, event e1) -> D2H container of the EXACT size (event e2)
 //   decode  H2D container -> kernels -> D2H frame + status (event e2)
 // The size of a container is known on the GPU only.  Nobody waits for it at submit time: the 16-byte mailbox copy is
@@ -28,6 +29,7 @@
 
 #include "../../include/llcomp_mi.h"
 #include "codec_internal.hpp"
+#include "container.hpp"
 
 using namespace llcomp_mi;
 
@@ -35,7 +37,8 @@ namespace {
 enum SlotState : int { kFree = 0, kEncSizing, kCopying, kFailed, kHeld };
 struct Slot {
     HostLane* lane = nullptr;
-    uint8_t* h_out = nullptr;  // pinned: a container (encode) or a frame (decode)
+    uint8_t* h_out = nullptr;  // pinned: the job's containers back to back (encode) or its frames (decode)
+    std::vector<uint64_t> part_off, part_len;  // encode: where container f sits in h_out
     hipEvent_t e1 = nullptr, e2 = nullptr;
     SlotState state = kFree;
     uint32_t kind = 0;
@@ -48,8 +51,9 @@ struct Slot {
 struct llcomp_mi_stream {
     std::mutex mu;
     int device = 0;
-    uint32_t w = 0, h = 0, c = 0, tile_w = 0, tile_h = 0, planar = 0;
-    uint64_t raw = 0, out_cap = 0;
+    uint32_t w = 0, h = 0, c = 0, tile_w = 0, tile_h = 0, planar = 0, fpj = 1, spf = 0;
+    uint64_t raw = 0, out_cap = 0;  // raw: bytes of ONE frame
+    uint8_t header[LLCOMP_MI_SLICED_HEADER_BYTES] = {};
     std::vector<Slot> slots;
     std::deque<uint32_t> fifo;  // slots in submission order that have not been handed out by wait() yet
     uint64_t jobs_done = 0;
@@ -57,7 +61,7 @@ struct llcomp_mi_stream {
 
 namespace {
 
-// encode job whose size mailbox has arrived: queue the container copy (exact size) or fail the job
+// encode job whose size mailbox has arrived: queue the container copies (exact sizes) or fail the job
 int start_container_copy(llcomp_mi_stream* s, Slot& sl) {
     HostLane* l = sl.lane;
     const int rc = status_from_bits(uint32_t(l->h_meta[1]));
@@ -66,13 +70,32 @@ int start_container_copy(llcomp_mi_stream* s, Slot& sl) {
         sl.state = kFailed;
         return LLCOMP_MI_OK;
     }
-    sl.out_len = uint64_t(l->head_bytes) + l->h_meta[0];
+    const uint64_t head1 = uint64_t(LLCOMP_MI_SLICED_HEADER_BYTES) + 4ull * s->spf;  // header + table of ONE container
+    sl.out_len = head1 * s->fpj + l->h_meta[0];
     if (sl.out_len > s->out_cap) {  // cannot happen (payload capacity <= out_cap), but never write past a buffer
         sl.status = LLCOMP_MI_OUTPUT_OVERFLOW;
         sl.state = kFailed;
         return LLCOMP_MI_OK;
     }
-    LLMI_HIP_TRY(hipMemcpyAsync(sl.h_out, l->d_container, sl.out_len, hipMemcpyDeviceToHost, l->stream));
+    if (s->fpj == 1) {  // the frame's container sits in HBM exactly as on the wire: one copy
+        sl.part_off[0] = 0;
+        sl.part_len[0] = sl.out_len;
+        LLMI_HIP_TRY(hipMemcpyAsync(sl.h_out, l->d_container, sl.out_len, hipMemcpyDeviceToHost, l->stream));
+    } else {  // [header][table f][payload f] per frame, back to back: two copies per frame, the header from the host
+        uint64_t at = 0, before = 0;
+        for (uint32_t f = 0; f < s->fpj; ++f) {
+            const uint64_t bytes = l->h_meta[2 + f];
+            sl.part_off[f] = at;
+            sl.part_len[f] = head1 + bytes;
+            std::memcpy(sl.h_out + at, s->header, LLCOMP_MI_SLICED_HEADER_BYTES);
+            LLMI_HIP_TRY(hipMemcpyAsync(sl.h_out + at + LLCOMP_MI_SLICED_HEADER_BYTES, l->d_len() + size_t(f) * s->spf, 4ull * s->spf,
+                                        hipMemcpyDeviceToHost, l->stream));
+            if (bytes)
+                LLMI_HIP_TRY(hipMemcpyAsync(sl.h_out + at + head1, l->d_payload() + before, bytes, hipMemcpyDeviceToHost, l->stream));
+            at += head1 + bytes;
+            before += bytes;
+        }
+    }
     LLMI_HIP_TRY(hipEventRecord(sl.e2, l->stream));
     sl.state = kCopying;
     return LLCOMP_MI_OK;
@@ -102,9 +125,14 @@ extern "C" {
 
 int llcomp_mi_stream_create(llcomp_mi_stream** out, int32_t device, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w,
                             uint32_t tile_h, uint32_t planar, uint32_t depth) {
+    return llcomp_mi_stream_create_ex(out, device, w, h, c, tile_w, tile_h, planar, depth, 1);
+}
+
+int llcomp_mi_stream_create_ex(llcomp_mi_stream** out, int32_t device, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w,
+                               uint32_t tile_h, uint32_t planar, uint32_t depth, uint32_t frames_per_job) {
     if (!out) return LLCOMP_MI_BAD_ARGS;
     *out = nullptr;
-    if (depth < 1 || depth > 16) return LLCOMP_MI_BAD_ARGS;
+    if (depth < 1 || depth > 16 || frames_per_job < 1 || frames_per_job > 64) return LLCOMP_MI_BAD_ARGS;
     if (int rc = check_shape(w, h, c, false)) return rc;
     int dev = 0;
     if (int rc = resolve_device(device, &dev)) return rc;
@@ -116,6 +144,8 @@ int llcomp_mi_stream_create(llcomp_mi_stream** out, int32_t device, uint32_t w, 
     s->tile_h = tile_h == 0 || tile_h > h ? h : tile_h;
     s->planar = planar ? 1 : 0;
     s->raw = uint64_t(w) * h * c;
+    s->fpj = frames_per_job;
+    s->spf = llcomp_mi_slice_count(w, h, c, s->tile_w, s->tile_h, s->planar);
     s->slots.resize(depth);
     DeviceGuard guard(dev);
     int rc = guard.ok ? LLCOMP_MI_OK : LLCOMP_MI_HIP_ERROR;
@@ -123,10 +153,13 @@ int llcomp_mi_stream_create(llcomp_mi_stream** out, int32_t device, uint32_t w, 
         Slot& sl = s->slots[i];
         // room for 2x raw (noise needs ~1.25x); a frame that needs more fails with OUTPUT_OVERFLOW and can go through
         // llcomp_mi_encode, which retries with the proven worst case of 13 bytes per sample
-        const uint64_t cap = 2 * s->raw + 64ull * llcomp_mi_slice_count(w, h, c, s->tile_w, s->tile_h, s->planar) + 4096;
-        rc = lane_create(&sl.lane, dev, w, h, c, s->tile_w, s->tile_h, s->planar, false, cap);
+        const uint64_t cap = (2 * s->raw + 64ull * s->spf + 4096) * s->fpj;
+        rc = lane_create(&sl.lane, dev, w, h, c, s->tile_w, s->tile_h, s->planar, false, cap, false, s->fpj);
         if (rc) break;
-        s->out_cap = std::max<uint64_t>(s->raw, sl.lane->head_bytes + sl.lane->payload_cap);
+        if (i == 0) write_sliced_header(s->header, sl.lane->k->g);
+        sl.part_off.assign(s->fpj, 0);
+        sl.part_len.assign(s->fpj, 0);
+        s->out_cap = std::max<uint64_t>(s->raw * s->fpj, uint64_t(LLCOMP_MI_SLICED_HEADER_BYTES) * s->fpj + 4ull * s->spf * s->fpj + sl.lane->payload_cap);
         if (hipHostMalloc(reinterpret_cast<void**>(&sl.h_out), s->out_cap, hipHostMallocDefault) != hipSuccess) rc = LLCOMP_MI_NOMEM;
         else if (hipEventCreateWithFlags(&sl.e1, hipEventDisableTiming) != hipSuccess ||
                  hipEventCreateWithFlags(&sl.e2, hipEventDisableTiming) != hipSuccess)
@@ -165,7 +198,7 @@ int llcomp_mi_stream_submit_encode(llcomp_mi_stream* s, const uint8_t* px, uint6
     if (i < 0) return LLCOMP_MI_BUSY;
     Slot& sl = s->slots[size_t(i)];
     HostLane* l = sl.lane;
-    LLMI_HIP_TRY(hipMemcpyAsync(l->d_px, px, s->raw, hipMemcpyHostToDevice, l->stream));
+    LLMI_HIP_TRY(hipMemcpyAsync(l->d_px, px, s->raw * s->fpj, hipMemcpyHostToDevice, l->stream));  // the job's frames, back to back
     if (int rc = lane_enqueue_encode(l)) return rc;
     LLMI_HIP_TRY(hipEventRecord(sl.e1, l->stream));
     sl.state = kEncSizing;
@@ -178,12 +211,28 @@ int llcomp_mi_stream_submit_encode(llcomp_mi_stream* s, const uint8_t* px, uint6
 }
 
 int llcomp_mi_stream_submit_decode(llcomp_mi_stream* s, const uint8_t* data, size_t len, uint64_t tag) {
-    if (!s || !data) return LLCOMP_MI_BAD_ARGS;
-    llcomp_mi_info info;
-    if (int rc = llcomp_mi_probe(data, len, &info)) return rc;
-    if (info.format != LLCOMP_MI_FORMAT_SLICED || info.width != s->w || info.height != s->h || info.channels != s->c ||
-        info.tile_w != s->tile_w || info.tile_h != s->tile_h || info.planar != s->planar || info.small_model)
-        return LLCOMP_MI_BAD_ARGS;  // a stream object codes ONE geometry
+    if (!s || s->fpj != 1) return LLCOMP_MI_BAD_ARGS;  // jobs of several frames: llcomp_mi_stream_submit_decode_batch
+    return llcomp_mi_stream_submit_decode_batch(s, &data, &len, tag);
+}
+
+int llcomp_mi_stream_submit_decode_batch(llcomp_mi_stream* s, const uint8_t* const* data, const size_t* lens, uint64_t tag) {
+    if (!s || !data || !lens) return LLCOMP_MI_BAD_ARGS;
+    const uint64_t head1 = uint64_t(LLCOMP_MI_SLICED_HEADER_BYTES) + 4ull * s->spf;
+    std::vector<uint64_t> pay(s->fpj);  // payload bytes every frame's slice table promises
+    for (uint32_t f = 0; f < s->fpj; ++f) {
+        if (!data[f]) return LLCOMP_MI_BAD_ARGS;
+        llcomp_mi_info info;
+        if (int rc = llcomp_mi_probe(data[f], lens[f], &info)) return rc;
+        if (info.format != LLCOMP_MI_FORMAT_SLICED || info.width != s->w || info.height != s->h || info.channels != s->c ||
+            info.tile_w != s->tile_w || info.tile_h != s->tile_h || info.planar != s->planar || info.small_model)
+            return LLCOMP_MI_BAD_ARGS;  // a stream object codes ONE geometry
+        if (s->fpj > 1) {  // the frames' payloads are laid side by side in HBM at the offsets their tables imply
+            uint64_t sum = 0;
+            for (uint32_t i = 0; i < s->spf; ++i) sum += get_u32le(data[f] + LLCOMP_MI_SLICED_HEADER_BYTES + 4ull * i);
+            if (head1 + sum > lens[f]) return LLCOMP_MI_TRUNCATED;  // (a lone frame is bounds-checked on the GPU instead)
+            pay[f] = sum;
+        }
+    }
     std::lock_guard<std::mutex> lock(s->mu);
     DeviceGuard guard(s->device);
     if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
@@ -192,18 +241,49 @@ int llcomp_mi_stream_submit_decode(llcomp_mi_stream* s, const uint8_t* data, siz
     if (i < 0) return LLCOMP_MI_BUSY;
     Slot& sl = s->slots[size_t(i)];
     HostLane* l = sl.lane;
-    // a container longer than the slot's buffer carries bytes no slice can use (the table is bounds-checked on the GPU)
-    const uint64_t n = std::min<uint64_t>(len, uint64_t(l->head_bytes) + l->payload_cap);
-    LLMI_HIP_TRY(hipMemcpyAsync(l->d_container, data, n, hipMemcpyHostToDevice, l->stream));
-    if (int rc = lane_enqueue_decode(l, n)) return rc;
-    LLMI_HIP_TRY(hipMemcpyAsync(sl.h_out, l->d_px, s->raw, hipMemcpyDeviceToHost, l->stream));
+    uint64_t payload_bytes = 0;
+    if (s->fpj == 1) {
+        // a container longer than the slot's buffer carries bytes no slice can use (the table is bounds-checked on the GPU)
+        const uint64_t n = std::min<uint64_t>(lens[0], uint64_t(l->head_bytes) + l->payload_cap);
+        LLMI_HIP_TRY(hipMemcpyAsync(l->d_container, data[0], n, hipMemcpyHostToDevice, l->stream));
+        payload_bytes = n - l->head_bytes;
+    } else {
+        for (uint32_t f = 0; f < s->fpj; ++f) {
+            if (payload_bytes + pay[f] > l->payload_cap) return LLCOMP_MI_OUTPUT_OVERFLOW;
+            LLMI_HIP_TRY(hipMemcpyAsync(l->d_len() + size_t(f) * s->spf, data[f] + LLCOMP_MI_SLICED_HEADER_BYTES, 4ull * s->spf,
+                                        hipMemcpyHostToDevice, l->stream));
+            if (pay[f])
+                LLMI_HIP_TRY(hipMemcpyAsync(l->d_payload() + payload_bytes, data[f] + head1, pay[f], hipMemcpyHostToDevice, l->stream));
+            payload_bytes += pay[f];
+        }
+    }
+    if (int rc = lane_enqueue_decode(l, payload_bytes)) return rc;
+    LLMI_HIP_TRY(hipMemcpyAsync(sl.h_out, l->d_px, s->raw * s->fpj, hipMemcpyDeviceToHost, l->stream));
     LLMI_HIP_TRY(hipEventRecord(sl.e2, l->stream));
     sl.state = kCopying;
     sl.kind = LLCOMP_MI_JOB_DECODE;
     sl.tag = tag;
     sl.status = LLCOMP_MI_OK;
-    sl.out_len = s->raw;
+    sl.out_len = s->raw * s->fpj;
     s->fifo.push_back(uint32_t(i));
+    return LLCOMP_MI_OK;
+}
+
+uint32_t llcomp_mi_stream_frames_per_job(const llcomp_mi_stream* s) { return s ? s->fpj : 0; }
+
+int llcomp_mi_stream_result_part(llcomp_mi_stream* s, uint32_t slot, uint32_t frame, const uint8_t** data, uint64_t* len) {
+    if (!s || !data || !len) return LLCOMP_MI_BAD_ARGS;
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (slot >= s->slots.size() || frame >= s->fpj) return LLCOMP_MI_BAD_ARGS;
+    const Slot& sl = s->slots[slot];
+    if (sl.state != kHeld || sl.status != LLCOMP_MI_OK) return LLCOMP_MI_BAD_ARGS;
+    if (sl.kind == LLCOMP_MI_JOB_ENCODE) {
+        *data = sl.h_out + sl.part_off[frame];
+        *len = sl.part_len[frame];
+    } else {
+        *data = sl.h_out + s->raw * frame;
+        *len = s->raw;
+    }
     return LLCOMP_MI_OK;
 }
 

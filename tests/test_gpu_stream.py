@@ -25,11 +25,11 @@ def golden(gen, w, tw, th, planar):
     return [v for v in SLC if v["gen"] == gen and v["w"] == w and v["tile_w"] == tw and v["tile_h"] == th and v["planar"] == planar][0]
 
 
-def run_stream(mi, frames, tw, th, planar, depth, max_encodes_in_flight, check=None):
+def run_stream(mi, frames, tw, th, planar, depth, max_encodes_in_flight, check=None, frames_per_job=1):
     """Streams every frame through encode and straight back through decode (llcomp_amd.pipeline_roundtrip: the loop
     bench.py's C5 leg uses too); every decoded frame is compared with its source inside."""
     h, w, c = frames[0].shape
-    st = mi.Stream(w, h, c, tw, th, planar, depth=depth)
+    st = mi.Stream(w, h, c, tw, th, planar, depth=depth, frames_per_job=frames_per_job)
     lens, done_at, busy_seen = mi.pipeline_roundtrip(st, frames, max_encodes_in_flight, on_container=check, verify=True)
     assert st.pending() == 0
     st.close()
@@ -49,6 +49,38 @@ def test_stream_small_frames_match_oracle(mi, orc):
         lens, _, busy = run_stream(mi, frames, tw, th, planar, depth=3, max_encodes_in_flight=2, check=check)
         assert lens == [len(x) for x in want]
         assert busy > 0, "11 frames through 3 slots must have hit back-pressure"
+
+
+@pytest.mark.parametrize("fpj", [2, 3])
+def test_stream_jobs_of_several_frames_match_oracle(mi, orc, fpj):
+    """frames_per_job > 1: one launch set and two copies per frame instead of a whole pipeline pass per frame; every
+    frame still gets its own container, equal to the oracle's."""
+    for (w, h, c, tw, th, planar) in ((200, 37, 3, 50, 1, True), (131, 40, 4, 32, 16, True), (97, 21, 1, 97, 1, False)):
+        n = 4 * fpj
+        buf = np.empty((n, h, w, c), np.uint8)  # the frames of a job must be adjacent in memory
+        for i in range(n):
+            buf[i] = np.roll(make_image(("g3", "mid", "g1", "checker")[i % 4], w, h, c), 3 * i, axis=1)
+        frames = [buf[i] for i in range(n)]
+        want = [orc.compress_sliced(f, tw, th, planar) for f in frames]
+
+        def check(i, data):
+            assert data.tobytes() == want[i], f"frame {i}: container differs from the oracle's"
+
+        lens, _, _ = run_stream(mi, frames, tw, th, planar, depth=3, max_encodes_in_flight=2, check=check, frames_per_job=fpj)
+        assert lens == [len(x) for x in want]
+    st = mi.Stream(64, 16, 3, 16, 1, True, depth=2, frames_per_job=2)
+    with pytest.raises(mi.LlcompError):  # the one-container call does not fit jobs of two frames
+        mi._lib.load() and mi._check(mi._lib.load().llcomp_mi_stream_submit_decode(st._h, want[0], len(want[0]), 0))
+    a = np.zeros((2, 16, 64, 3), np.uint8)
+    assert st.submit_encode(a, 5)
+    job = st.wait()
+    assert job.tag == 5 and len(job.data) == 2 and job.data[0].tobytes() == job.data[1].tobytes()
+    cut = job.data[1][: job.data[1].size - 1].copy()  # a container shorter than its table promises
+    with pytest.raises(mi.LlcompError) as e:
+        st.submit_decode([job.data[0], cut], 6)
+    assert e.value.status == mi.TRUNCATED
+    st.release(job)
+    st.close()
 
 
 def test_stream_api_errors_and_backpressure(mi):
@@ -121,7 +153,8 @@ def test_c3_4k_bench_slicing_golden(mi, orc, gen):
     assert np.array_equal(mi.decompress_image(s).pixels, img)
 
 
-def test_c5_stream_64_frames_4k(mi, orc):
+@pytest.mark.parametrize("fpj", [1, 4])
+def test_c5_stream_64_frames_4k(mi, orc, fpj):
     """BASELINE config 5: 64 distinct 4K RGB8 noise frames (std::mt19937 seeds 1234+i) streamed host -> GPU -> host ->
     GPU -> host through llcomp_mi_stream_*.  Every frame bit-exact; frames 0 and 63 pinned to golden container hashes made
     with the real reference; steady state (first 4 frames excluded) and compression ratio reported."""
@@ -140,10 +173,10 @@ def test_c5_stream_64_frames_4k(mi, orc):
         if i in pins:
             assert data.size == pins[i]["container_len"] and fnv_hex(orc, data.tobytes()) == pins[i]["container_fnv1a64"], f"frame {i}: golden mismatch"
 
-    lens, done_at, _ = run_stream(mi, frames, 480, 1, True, depth=8, max_encodes_in_flight=3, check=check)
-    steady = (N - 4) * W * H / 1e6 / (done_at[-1] - done_at[3])
+    lens, done_at, _ = run_stream(mi, frames, 480, 1, True, depth=8 if fpj == 1 else 6, max_encodes_in_flight=3 if fpj == 1 else 2, check=check, frames_per_job=fpj)
+    steady = (N - 4) * W * H / 1e6 / (done_at[-1] - done_at[3])  # (jobs of 4 frames: the first job is excluded)
     ratio = N * W * H * C / sum(lens)
-    print(f"\nC5 stream: {N} frames, steady state {steady:.0f} MPix/s end to end over PCIe (first 4 frames excluded), ratio {ratio:.4f} "
+    print(f"\nC5 stream ({fpj} frame(s) per job): {N} frames, steady state {steady:.0f} MPix/s end to end over PCIe (first 4 frames excluded), ratio {ratio:.4f} "
           f"(reference whole-image stream of frame 0: 0.8026)")
     assert 0.76 < ratio < 0.79
     assert steady > 500  # one pageable 4K frame through the round-1 host calls ran at 640 MPix/s; a pipeline must not be slower

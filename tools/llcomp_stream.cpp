@@ -1,4 +1,4 @@
-// llcomp_stream [frames] [width] [height] [tile_w] [tile_h] [depth] [encodes_in_flight]
+// llcomp_stream [frames] [width] [height] [tile_w] [tile_h] [depth] [encodes_in_flight] [frames_per_job]
 //
 // BASELINE config 5 driven from C++ through the C ABI alone (include/llcomp_mi.h, llcomp_mi_stream_*): `frames` distinct
 // RGB8 noise frames stream host -> GPU -> host (SLICED container) -> GPU -> host with `depth` pipeline slots; every decoded
@@ -43,15 +43,19 @@ struct Check {  // a decoded frame waiting for its comparison; the slot is relea
 }  // namespace
 
 int main(int argc, char** argv) {
-    const uint32_t n = argc > 1 ? uint32_t(std::atoi(argv[1])) : 64;
+    uint32_t n = argc > 1 ? uint32_t(std::atoi(argv[1])) : 64;
     const uint32_t w = argc > 2 ? uint32_t(std::atoi(argv[2])) : 3840, h = argc > 3 ? uint32_t(std::atoi(argv[3])) : 2160, c = 3;
     const uint32_t tw = argc > 4 ? uint32_t(std::atoi(argv[4])) : 480, th = argc > 5 ? uint32_t(std::atoi(argv[5])) : 1;
     const uint32_t depth = argc > 6 ? uint32_t(std::atoi(argv[6])) : 16, max_enc = argc > 7 ? uint32_t(std::atoi(argv[7])) : 6;
-    const size_t raw = size_t(w) * h * c;
-    if (!n || !raw) return 1;
+    const uint32_t fpj = argc > 8 ? uint32_t(std::atoi(argv[8])) : 1;  // frames per job
+    const size_t raw1 = size_t(w) * h * c;
+    if (!n || !raw1 || !fpj || n % fpj) return 1;
+    const uint32_t frames_total = n;
+    n /= fpj;                       // from here on: jobs
+    const size_t raw = raw1 * fpj;  // bytes of one job's frames
 
     llcomp_mi_stream* st = nullptr;
-    if (int rc = llcomp_mi_stream_create(&st, -1, w, h, c, tw, th, 1, depth)) {
+    if (int rc = llcomp_mi_stream_create_ex(&st, -1, w, h, c, tw, th, 1, depth, fpj)) {
         std::fprintf(stderr, "llcomp_mi_stream_create: %s\n", llcomp_mi_strerror(rc));
         return 1;
     }
@@ -105,7 +109,15 @@ int main(int argc, char** argv) {
         }
         while (!to_decode.empty()) {  // containers first: their decode frees two slots
             const llcomp_mi_stream_result& r = to_decode.front();
-            const int rc = llcomp_mi_stream_submit_decode(st, r.data, size_t(r.len), r.tag);
+            std::vector<const uint8_t*> ptrs(fpj);
+            std::vector<size_t> lens(fpj);
+            for (uint32_t f = 0; f < fpj; ++f) {  // the job's containers, straight out of the encode result's pinned buffer
+                uint64_t len = 0;
+                if (llcomp_mi_stream_result_part(st, r.slot, f, &ptrs[f], &len)) { fail = LLCOMP_MI_BAD_ARGS; break; }
+                lens[f] = size_t(len);
+            }
+            if (fail) break;
+            const int rc = llcomp_mi_stream_submit_decode_batch(st, ptrs.data(), lens.data(), r.tag);
             if (rc == LLCOMP_MI_BUSY) { ++busy; break; }
             if (rc) { fail = rc; break; }
             enc_held[r.tag] = r;
@@ -149,10 +161,10 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "llcomp_stream: %s\n", fail ? llcomp_mi_strerror(fail) : "a decoded frame differs from its source");
         return 1;
     }
-    const uint32_t skip = n > 8 ? 4 : 0;
-    const double steady = double(n - skip) * w * h / 1e6 / (done_at[n - 1] - (skip ? done_at[skip - 1] : 0.0));
-    std::printf("{\"frames\": %u, \"width\": %u, \"height\": %u, \"tile\": \"%ux%u\", \"depth\": %u, \"steady_mpix_s\": %.1f, \"compression_ratio\": %.4f, "
-                "\"backpressure_hits\": %u, \"verified\": true}\n",
-                n, w, h, tw, th, depth, steady, double(raw) * n / double(container_bytes), busy);
+    const uint32_t skip = n * fpj > 8 ? (4 + fpj - 1) / fpj : 0;  // jobs that hold the first 4 frames
+    const double steady = double(n - skip) * fpj * w * h / 1e6 / (done_at[n - 1] - (skip ? done_at[skip - 1] : 0.0));
+    std::printf("{\"frames\": %u, \"frames_per_job\": %u, \"width\": %u, \"height\": %u, \"tile\": \"%ux%u\", \"depth\": %u, \"steady_mpix_s\": %.1f, "
+                "\"compression_ratio\": %.4f, \"backpressure_hits\": %u, \"verified\": true}\n",
+                frames_total, fpj, w, h, tw, th, depth, steady, double(raw) * n / double(container_bytes), busy);
     return 0;
 }
