@@ -309,11 +309,18 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks = []
     for _ in range(steps):
         conts, outs = step()
+        if os.environ.get("LLCOMP_BENCH_DEBUG"):
+            torch.cuda.synchronize()
+            marks.append(time.perf_counter())
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
+    if marks and rank == 0:
+        print("c4 step times (ms):", [round(1e3 * (b - a), 1) for a, b in zip([t0] + marks[:-1], marks)], "reserved GB", round(torch.cuda.memory_reserved() / 1e9, 1),
+              "free GB", round(torch.cuda.mem_get_info()[0] / 1e9, 1), file=sys.stderr, flush=True)
     for k in range(halves):
         assert torch.equal(outs[k], bands[k])
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -471,15 +478,6 @@ def main():
         },
         "kernel_ms_per_step": {k: round(v / max(1, args.steps), 4) for k, v in prof.items()},
     }
-    if not args.no_cpu_baseline:  # the CPU reference is timed at N=1 only
-        res["cpu_baseline"] = cpu_baseline(frames_np[0], f"3840x2160 RGB8 {args.content}", args.tile_w, args.tile_h, planar, same_slicing=True)
-        res["speedup_vs_cpu_baseline"] = round(m["mpix"] / res["cpu_baseline"]["value"], 1)
-        if "same_slicing_port" in res["cpu_baseline"]:
-            res["speedup_vs_cpu_same_slicing"] = round(m["mpix"] / res["cpu_baseline"]["same_slicing_port"]["value"], 1)
-        res["cpu_baseline"]["note"] = ("the reference codes one whole-image stream; the GPU figure is on independent slices (ratio in config.compression_ratio vs "
-                                       "the whole-image ratio in `sample`), so speedup_vs_cpu_baseline is throughput at unequal compression; same_slicing_port / "
-                                       "speedup_vs_cpu_same_slicing is the like-for-like figure (identical container bytes)")
-
     if not args.no_also:
         also = {}
         sub = max(3, args.steps // 3)
@@ -508,8 +506,7 @@ def main():
             leg = make_frames("mid", 512, 0, w=256, h=256, c=3, distinct=16)
             ml = measure(leg, 256, 256, False, 1, 1, 1, local_rank)
             also["legacy_streams_batched"] = brief(ml, workload="512 frames 256x256 RGB8 mid, one whole-image stream each (payload == reference stream), one GPU lane per stream")
-            if not args.no_cpu_baseline:
-                also["legacy_streams_batched"]["cpu_reference"] = cpu_baseline(leg[0], "256x256 RGB8 mid", 256, 256, False)
+            legacy_frame = leg[0].copy()
         # BASELINE config 5 through the streaming pipeline, PCIe inclusive
         if want("c5"):
             also["c5_stream_pcie"] = c5_stream(frames_np, args.tile_w, args.tile_h, planar)
@@ -523,6 +520,19 @@ def main():
                                           "workload": f"C4 {args.c4_images} x 8192x8192 RGB8 uniform noise, {args.c4_tile_w}x{args.c4_tile_h} planar, the sharded code path on 1 GPU"}
         also["seconds"] = round(time.perf_counter() - t_also, 1)
         res["also"] = also
+    # The CPU legs run LAST: seconds of single-thread coding churn gigabytes of host memory, and pinned buffers allocated
+    # after that are slower to DMA (measured: the PCIe-inclusive C5 leg drops from 4.7 to 3.8 GPix/s when it runs behind them).
+    if not args.no_cpu_baseline:  # the CPU reference is timed at N=1 only
+        res["cpu_baseline"] = cpu_baseline(frames_np[0], f"3840x2160 RGB8 {args.content}", args.tile_w, args.tile_h, planar, same_slicing=True)
+        res["speedup_vs_cpu_baseline"] = round(m["mpix"] / res["cpu_baseline"]["value"], 1)
+        if "same_slicing_port" in res["cpu_baseline"]:
+            res["speedup_vs_cpu_same_slicing"] = round(m["mpix"] / res["cpu_baseline"]["same_slicing_port"]["value"], 1)
+        res["cpu_baseline"]["note"] = ("the reference codes one whole-image stream; the GPU figure is on independent slices (ratio in config.compression_ratio vs "
+                                       "the whole-image ratio in `sample`), so speedup_vs_cpu_baseline is throughput at unequal compression; same_slicing_port / "
+                                       "speedup_vs_cpu_same_slicing is the like-for-like figure (identical container bytes)")
+
+        if not args.no_also and "legacy_streams_batched" in res.get("also", {}):
+            res["also"]["legacy_streams_batched"]["cpu_reference"] = cpu_baseline(legacy_frame, "256x256 RGB8 mid", 256, 256, False)
     print(json.dumps(res), flush=True)
     dist.destroy_process_group()
 
