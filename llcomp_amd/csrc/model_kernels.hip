@@ -527,6 +527,19 @@ __global__ __launch_bounds__(256) void k_from_lane_order(const Geometry g, const
     }
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (workgroup i runs on XCD i % 8), each with its own L2.  The 64-sample
+// chunks of one lane group touch neighbouring pieces of the same pixel rows (shared cache lines) and of the same lane-order
+// rows, so they should meet in ONE L2: lane group g goes to XCD g % 8 and its chunks occupy consecutive slots there.
+// Returns false for the padding workgroups of the last, incomplete round of groups.
+constexpr uint32_t kXcds = 8;
+__device__ __forceinline__ bool xcd_group_chunk(uint32_t n_groups, uint32_t chunks, uint32_t& group, uint32_t& chunk) {
+    const uint32_t xcd = blockIdx.x % kXcds, slot = blockIdx.x / kXcds;
+    group = (slot / chunks) * kXcds + xcd;
+    chunk = slot - (slot / chunks) * chunks;
+    return group < n_groups;
+}
+__host__ inline uint64_t xcd_grid(uint32_t n_groups, uint32_t chunks) { return uint64_t((n_groups + kXcds - 1) / kXcds) * kXcds * chunks; }
+
 // ---- fused stage A for planar 1-row slices (tile_h == 1, planar) -------------------------------------------------------
 // The headline configuration.  One block = one lane group (64 consecutive slice ids = ~64/C tiles x C channel planes)
 // x 64 consecutive samples: the pixel runs of those tiles are staged raw in LDS (coalesced reads of 66*C bytes each),
@@ -573,7 +586,9 @@ __global__ __launch_bounds__(256) void k_model_rows_fwd(const Geometry g, const 
     __shared__ __attribute__((aligned(4))) uint16_t otile[K][64 + 2];  // symbols [sample][group-relative lane]
     __shared__ RowTile tiles[TPG];
     const uint32_t chunks = (g.tile_w + K - 1) / K;
-    const uint32_t group = blockIdx.x / chunks, k0 = (blockIdx.x - group * chunks) * K;
+    uint32_t group, chunk;
+    if (!xcd_group_chunk((g.n_slices + (1u << g.lane_shift) - 1) >> g.lane_shift, chunks, group, chunk)) return;  // (uniform per block)
+    const uint32_t k0 = chunk * K;
     const uint32_t gw = 1u << g.lane_shift;
     const uint32_t first_id = group << g.lane_shift;
     const uint32_t end_id = first_id + gw < g.n_slices ? first_id + gw : g.n_slices;
@@ -663,7 +678,9 @@ __global__ __launch_bounds__(256) void k_model_rows_inv(const Geometry g, const 
     __shared__ __attribute__((aligned(4))) int16_t tile[K][64 + C + 1 + ((C + 1) & 1)];  // even row length: dword rows
     __shared__ RowTile tiles[TPG];
     const uint32_t chunks = (g.tile_w + K - 1) / K;
-    const uint32_t group = blockIdx.x / chunks, k0 = (blockIdx.x - group * chunks) * K;
+    uint32_t group, chunk;
+    if (!xcd_group_chunk((g.n_slices + (1u << g.lane_shift) - 1) >> g.lane_shift, chunks, group, chunk)) return;  // (uniform per block)
+    const uint32_t k0 = chunk * K;
     const uint32_t gw = 1u << g.lane_shift;
     const uint32_t first_id = group << g.lane_shift;
     const uint32_t end_id = first_id + gw < g.n_slices ? first_id + gw : g.n_slices;
@@ -781,14 +798,14 @@ hipError_t launch_from_lane_order_i16(const Geometry& g, const int16_t* d_lanes,
 bool model_is_fused(const Geometry& g) { return g.planar && rows_mode(g) && g.c <= 4; }
 
 hipError_t launch_model_rows_fwd(const Geometry& g, const uint8_t* d_px, uint16_t* d_lanes, hipStream_t stream) {
-    const uint64_t blocks = uint64_t(lane_groups(g)) * ((g.tile_w + 63) / 64);
+    const uint64_t blocks = xcd_grid(lane_groups(g), (g.tile_w + 63) / 64);
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     LLMI_DISPATCH_C(g.c, (k_model_rows_fwd<C><<<dim3(uint32_t(blocks)), dim3(256), 0, stream>>>(g, d_px, d_lanes)));
     return hipGetLastError();
 }
 
 hipError_t launch_model_rows_inv(const Geometry& g, const int16_t* d_lanes, uint8_t* d_px, hipStream_t stream) {
-    const uint64_t blocks = uint64_t(lane_groups(g)) * ((g.tile_w + 63) / 64);
+    const uint64_t blocks = xcd_grid(lane_groups(g), (g.tile_w + 63) / 64);
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     LLMI_DISPATCH_C(g.c, (k_model_rows_inv<C><<<dim3(uint32_t(blocks)), dim3(256), 0, stream>>>(g, d_lanes, d_px)));
     return hipGetLastError();
