@@ -304,17 +304,13 @@ class ShardedCodec:
         n_out = int(sum(M_h[s][self.rank] for s in range(self.world)))
         send = torch.zeros(n_out + 16, dtype=torch.uint8, device=self.device)
         if self.my_images:
-            sizes = [int(containers[b].numel()) for b in self.my_images]
-            bases = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-            src = torch.cat([containers[b] for b in self.my_images]) if len(self.my_images) > 1 else containers[self.my_images[0]]
-            base_of = torch.zeros(self.images, dtype=torch.int64, device=self.device)
-            end_of = torch.zeros(self.images, dtype=torch.int64, device=self.device)
-            for j, b in enumerate(self.my_images):
-                base_of[b], end_of[b] = int(bases[j]), int(bases[j + 1])
-            mine = self.seg_mine
-            src_off = base_of[self.seg_image[mine]] + head + in_image[mine]
-            seg_clip = torch.minimum(seg_len[mine], torch.clamp(end_of[self.seg_image[mine]] - src_off, min=0))
-            _copy_segments(src, send, src_off, in_exchange[mine].contiguous(), seg_clip.contiguous(), max(sizes))
+            n_ch = len(self.chunks)
+            for b in self.my_images:  # one concatenator launch per container: its (image, chunk) segments are consecutive
+                cont = containers[b]
+                idx = torch.arange(b * n_ch, (b + 1) * n_ch, device=self.device)
+                src_off = head + in_image[idx]
+                seg_clip = torch.minimum(seg_len[idx], torch.clamp(int(cont.numel()) - src_off, min=0))
+                _copy_segments(cont, send, src_off, in_exchange[idx].contiguous(), seg_clip.contiguous(), int(cont.numel()))
         # collective 2: every rank gets the bytes of its slices, already in its codec's order
         recv = self._exchange(send, [M_h[s][self.rank] for s in range(self.world)], M_h[self.rank])
         out = torch.empty((self.images, self.local_h, self.w, self.c), dtype=torch.uint8, device=self.device)
