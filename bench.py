@@ -249,8 +249,8 @@ def c5_stream(frames_np, tile_w, tile_h, planar, depth=8, frames_per_job=4):
 
 def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank, check_one_piece=True):
     """BASELINE config 4: `images` noise images of size x size RGB8, each sharded over all ranks; encode (+ exchange of the
-    bitstream) and decode (+ exchange back) per step.  The batch is coded as two halves on two HIP streams (a ShardedCodec
-    each) so that the exchange of one half overlaps the coding of the other.  Returns the max-over-ranks wall time."""
+    bitstream) and decode (+ exchange back) per step.  The batch is coded as up to three part batches on as many HIP streams
+    (a ShardedCodec each) so that the exchange of one part overlaps the coding of the others.  Returns the max-over-ranks wall time."""
     import torch
     import torch.distributed as dist
 
@@ -258,7 +258,8 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     from llcomp_amd import sharding
 
     dev = torch.device("cuda", local_rank)
-    halves = 2 if images % 2 == 0 and (images // 2) % world == 0 else 1  # every half spreads its containers evenly over the ranks
+    # 3, 2 or 1 part batches, each spreading its containers evenly over the ranks
+    halves = next(p for p in (3, 2, 1) if images % p == 0 and (images // p) % world == 0 or p == 1)
     per = images // halves
     scs = [sharding.ShardedCodec(size, size, 3, tile_w, tile_h, True, images=per, device=dev) for _ in range(halves)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(halves)]
@@ -290,6 +291,10 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
         for k in range(halves):
             with torch.cuda.stream(streams[k]):
                 outs[k] = scs[k].decode(conts[k], validate=False)  # straight from encode: no header round trip
+        # every part has drained its own stream by now (decode ends with its status check); the device-wide wait costs
+        # microseconds and keeps steps from interleaving in the runtime's queues (without it some runs of this leg took
+        # twice as long per step, with identical kernels and allocator statistics)
+        torch.cuda.synchronize()
         return conts, outs
 
     conts, outs = step()
@@ -318,6 +323,10 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("LLCOMP_BENCH_ALLOC") and rank == 0:
+        st_ = torch.cuda.memory_stats()
+        print("c4 allocator:", {k: st_.get(k) for k in ("num_alloc_retries", "num_device_alloc", "num_device_free", "reserved_bytes.all.peak", "allocated_bytes.all.peak")},
+              "ms/step", round(1e3 * dt / steps, 1), file=sys.stderr, flush=True)
     if marks and rank == 0:
         print("c4 step times (ms):", [round(1e3 * (b - a), 1) for a, b in zip([t0] + marks[:-1], marks)], "reserved GB", round(torch.cuda.memory_reserved() / 1e9, 1),
               "free GB", round(torch.cuda.mem_get_info()[0] / 1e9, 1), file=sys.stderr, flush=True)
@@ -345,7 +354,7 @@ def main():
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra one-pipeline-at-a-time launches behind the timed region (profiler runs)")
     ap.add_argument("--no-also", action="store_true", help="only the headline workload (profiler runs, sweeps)")
     ap.add_argument("--also-only", default="", help="comma-separated subset of the `also` legs: contents,tiles,latency,legacy,c5,c4 (profiling)")
-    ap.add_argument("--c4-images", type=int, default=16, help="8192x8192 images per step of the sharded (config 4) workload (fixed total: strong scaling)")
+    ap.add_argument("--c4-images", type=int, default=24, help="8192x8192 images per step of the sharded (config 4) workload (fixed total: strong scaling)")
     ap.add_argument("--c4-tile-w", type=int, default=512)
     ap.add_argument("--c4-tile-h", type=int, default=1)
     ap.add_argument("--rehearse-one-gpu", action="store_true",
