@@ -147,6 +147,8 @@ def measure(frames_np, tile_w, tile_h, planar, streams, steps, warmup, local_ran
     for p in parts:
         p["total"] = int(p["tot"].item())
     total = sum(p["total"] for p in parts)
+    spf0 = parts[0]["codec"].n_slices // parts[0]["n"]
+    frame0_container = 24 + 4 * spf0 + int(parts[0]["len"][:spf0].to(torch.int64).sum().item())  # bytes of frame 0's container
     for _ in range(max(0, warmup - 1)):
         step()
     torch.cuda.synchronize()
@@ -195,7 +197,7 @@ def measure(frames_np, tile_w, tile_h, planar, streams, steps, warmup, local_ran
     torch.cuda.empty_cache()
     container_bytes = total + 24 * F + 4 * n_slices  # per-frame container headers + slice tables
     return dict(dt=dt, steps=steps, F=F, S=S, w=w, h=h, c=c, n_slices=n_slices, payload=total, container_bytes=container_bytes,
-                raw_bytes=int(frames_np.size), prof=prof, n_enc=n_enc, n_dec=n_dec, iso=iso, iso_enc=iso_enc, iso_dec=iso_dec,
+                raw_bytes=int(frames_np.size), prof=prof, frame0_container=frame0_container, n_enc=n_enc, n_dec=n_dec, iso=iso, iso_enc=iso_enc, iso_dec=iso_dec,
                 mpix=F * w * h * steps / dt / 1e6, ratio=frames_np.size / container_bytes)
 
 
@@ -487,12 +489,37 @@ def main():
         },
         "kernel_ms_per_step": {k: round(v / max(1, args.steps), 4) for k, v in prof.items()},
     }
+    # byte-level pin of the measured workload: frame 0 of the default batch is the golden vector's image (std::mt19937(1234)),
+    # its container length must be the one the real reference's per-slice streams add up to (tests/golden, also hashed in
+    # tests/test_gpu_stream.py::test_c3_4k_bench_slicing_golden)
+    try:
+        gold = [v for v in json.load(open(os.path.join(ROOT, "tests", "golden", "slice_payloads.json")))["vectors"]
+                if (v["gen"], v["w"], v["tile_w"], v["tile_h"], v["planar"]) == (args.content, W4K, args.tile_w, args.tile_h, planar)]
+        if gold:
+            res["golden_pin"] = {"frame0_container_bytes": m["frame0_container"], "reference": gold[0]["container_len"],
+                                 "match": m["frame0_container"] == gold[0]["container_len"]}
+            assert res["golden_pin"]["match"], "frame 0's container length differs from the reference's"
+    except OSError:
+        pass
     if not args.no_also:
         also = {}
         sub = max(3, args.steps // 3)
         t_also = time.perf_counter()
         only = set(x for x in args.also_only.split(",") if x)
         want = lambda leg: not only or leg in only  # noqa: E731
+        # BASELINE config 5 through the streaming pipeline, PCIe inclusive.  The two big legs go first, before the
+        # allocate / free cycles of the others fragment HBM (the same kernels then ran up to 2x slower: TLB reach)
+        if want("c5"):
+            also["c5_stream_pcie"] = c5_stream(frames_np, args.tile_w, args.tile_h, planar)
+        # BASELINE config 4 on one GPU: the N = 1 point of the strong-scaling curve the N > 1 runs report (>100 GB of workspace)
+        if want("c4"):
+            n4 = max(4, sub // 2)
+            dt4, pay4 = c4_run(args.c4_images, 8192, args.c4_tile_w, args.c4_tile_h, n4, 3, local_rank, world, rank)
+            mi.trim()  # the one-piece check went through a host-buffer call: give its cached lane (10 GB) back
+            also["c4_sharded_one_gpu"] = {"value": round(args.c4_images * 8192 * 8192 * n4 / dt4 / 1e6, 1), "unit": "MPix/s",
+                                          "ms_per_step": round(dt4 / n4 * 1e3, 3), "steps": n4, "images_per_step": args.c4_images,
+                                          "compression_ratio": round(args.c4_images * 8192 * 8192 * 3 / pay4, 4),
+                                          "workload": f"C4 {args.c4_images} x 8192x8192 RGB8 uniform noise, {args.c4_tile_w}x{args.c4_tile_h} planar, the sharded code path on 1 GPU"}
         # other contents at the default slicing (4 distinct frames, the rest rotations)
         for content in ("g2", "mid") if want("contents") else ():
             if content != args.content:
@@ -516,17 +543,6 @@ def main():
             ml = measure(leg, 256, 256, False, 1, 1, 1, local_rank)
             also["legacy_streams_batched"] = brief(ml, workload="512 frames 256x256 RGB8 mid, one whole-image stream each (payload == reference stream), one GPU lane per stream")
             legacy_frame = leg[0].copy()
-        # BASELINE config 5 through the streaming pipeline, PCIe inclusive
-        if want("c5"):
-            also["c5_stream_pcie"] = c5_stream(frames_np, args.tile_w, args.tile_h, planar)
-        # BASELINE config 4 on one GPU: the N = 1 point of the strong-scaling curve the N > 1 runs report
-        if want("c4"):
-            n4 = max(4, sub // 2)
-            dt4, pay4 = c4_run(args.c4_images, 8192, args.c4_tile_w, args.c4_tile_h, n4, 3, local_rank, world, rank)
-            also["c4_sharded_one_gpu"] = {"value": round(args.c4_images * 8192 * 8192 * n4 / dt4 / 1e6, 1), "unit": "MPix/s",
-                                          "ms_per_step": round(dt4 / n4 * 1e3, 3), "steps": n4, "images_per_step": args.c4_images,
-                                          "compression_ratio": round(args.c4_images * 8192 * 8192 * 3 / pay4, 4),
-                                          "workload": f"C4 {args.c4_images} x 8192x8192 RGB8 uniform noise, {args.c4_tile_w}x{args.c4_tile_h} planar, the sharded code path on 1 GPU"}
         also["seconds"] = round(time.perf_counter() - t_also, 1)
         res["also"] = also
     # The CPU legs run LAST: seconds of single-thread coding churn gigabytes of host memory, and pinned buffers allocated

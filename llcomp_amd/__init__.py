@@ -76,6 +76,11 @@ def decompress_image(data, *, device=-1, small_model=False):
     return RawImage(pixels, w.value, h.value, c.value)
 
 
+def trim():
+    """Release the idle coding lanes the host-buffer calls keep for the next call of the same shape (GBs of HBM)."""
+    _lib.load().llcomp_mi_trim()
+
+
 def reload_tuning():
     """Have the library read its test / tuning hooks (LLCOMP_MI_*) from the environment again."""
     _lib.load().llcomp_mi_reload_tuning()

@@ -17,7 +17,7 @@ SYMBOLS = [
     "llcomp_mi_codec_decode", "llcomp_mi_codec_model", "llcomp_mi_status_from_bits",
     "llcomp_mi_codec_set_profiling", "llcomp_mi_codec_get_profile",
     "llcomp_mi_encode_into", "llcomp_mi_decode_into", "llcomp_mi_host_alloc", "llcomp_mi_host_free",
-    "llcomp_mi_reload_tuning", "llcomp_mi_device_copy_segments", "llcomp_mi_decode_flags", "llcomp_mi_codec_create_ex",
+    "llcomp_mi_reload_tuning", "llcomp_mi_trim", "llcomp_mi_device_copy_segments", "llcomp_mi_decode_flags", "llcomp_mi_codec_create_ex",
     "llcomp_mi_stream_create", "llcomp_mi_stream_create_ex", "llcomp_mi_stream_frames_per_job", "llcomp_mi_stream_submit_decode_batch",
     "llcomp_mi_stream_result_part", "llcomp_mi_stream_destroy", "llcomp_mi_stream_container_capacity",
     "llcomp_mi_stream_submit_encode", "llcomp_mi_stream_submit_decode", "llcomp_mi_stream_pending",
@@ -132,6 +132,8 @@ def load():
     L.llcomp_mi_decode_flags.argtypes = [u8p, C.c_size_t, C.c_int32, C.c_uint32, C.POINTER(u8p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.llcomp_mi_codec_create_ex.restype = C.c_int
     L.llcomp_mi_codec_create_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int32] + [C.c_uint32] * 8
+    L.llcomp_mi_trim.restype = None
+    L.llcomp_mi_trim.argtypes = []
     L.llcomp_mi_reload_tuning.restype = None
     L.llcomp_mi_reload_tuning.argtypes = []
     L.llcomp_mi_stream_create.restype = C.c_int

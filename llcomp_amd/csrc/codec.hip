@@ -68,6 +68,15 @@ namespace {
 
 #define HIP_TRY(expr) LLMI_HIP_TRY(expr)
 
+// Workspace buffers are tens of GB and every wavefront walks its own region of them: with HBM handed out in small physical
+// fragments (after many allocate / free cycles) the same kernels ran up to 2x slower (TLB reach).  Ask for physically
+// contiguous memory first; any refusal falls back to a plain hipMalloc.
+hipError_t ws_alloc(void** p, uint64_t bytes) {
+    if (bytes >= (64ull << 20) && hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();
+    return hipMalloc(p, bytes);
+}
+
 // brackets a group of launches with two events when profiling is on
 struct Timed {
     llcomp_mi_codec* k;
@@ -149,13 +158,15 @@ int llcomp_mi_codec_create_ex(llcomp_mi_codec** out, int32_t device, uint32_t fr
     k->device = dev;
     const uint64_t samples = uint64_t(frames) * w * h * c;
     k->need_states = slices_need_state_tables(g);
-    const uint64_t b_sym = samples * 4, b_states = k->need_states ? (uint64_t(lane_groups(g)) * kContexts << g.lane_shift) * 8 : 8,
+    // the fused row path (planar 1-row slices) has no image-order intermediate and 16-bit lane-order arrays in both directions
+    const bool fused = model_is_fused(g);
+    const uint64_t b_sym = fused ? 8 : samples * 4, b_states = k->need_states ? (uint64_t(lane_groups(g)) * kContexts << g.lane_shift) * 8 : 8,
                    b_scratch = (uint64_t(lane_groups(g)) << g.lane_shift) * g.slice_cap, b_off = (uint64_t(lane_groups(g)) + 1) * 8;
-    const uint64_t b_lanes = (uint64_t(lane_groups(g)) * slice_capacity_samples(g) << g.lane_shift) * 4;
+    const uint64_t b_lanes = (uint64_t(lane_groups(g)) * slice_capacity_samples(g) << g.lane_shift) * (fused ? 2 : 4);
     k->workspace_bytes = b_sym + b_lanes + b_states + b_scratch + b_off + 8;
-    bool ok = hipMalloc(&k->d_sym_or_rec, b_sym) == hipSuccess && hipMalloc(&k->d_lane_order, b_lanes) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void**>(&k->d_states), b_states) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void**>(&k->d_scratch), b_scratch) == hipSuccess &&
+    bool ok = ws_alloc(&k->d_sym_or_rec, b_sym) == hipSuccess && ws_alloc(&k->d_lane_order, b_lanes) == hipSuccess &&
+              ws_alloc(reinterpret_cast<void**>(&k->d_states), b_states) == hipSuccess &&
+              ws_alloc(reinterpret_cast<void**>(&k->d_scratch), b_scratch) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&k->d_group_off), b_off) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&k->d_total_tmp), 8) == hipSuccess;
     if (!ok) {

@@ -157,6 +157,15 @@ struct LaneCache {
         for (auto* d : drop) lane_destroy(d);
     }
 };
+void drop_idle_lanes(LaneCache& c) {
+    std::vector<HostLane*> drop;
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        for (auto& it : c.idle) drop.push_back(it.l);
+        c.idle.clear();
+    }
+    for (auto* d : drop) lane_destroy(d);
+}
 LaneCache& lane_cache() {
     static LaneCache* c = new LaneCache;  // leaked deliberately
     return *c;
@@ -313,6 +322,8 @@ int llcomp_mi_decode_into(const uint8_t* data, size_t len, int32_t device, uint8
     if (!data || !px || !w || !h || !c) return LLCOMP_MI_BAD_ARGS;
     return decode_common(data, len, device, 0, px, px_cap, nullptr, w, h, c);
 }
+
+void llcomp_mi_trim(void) { drop_idle_lanes(lane_cache()); }
 
 void* llcomp_mi_host_alloc(size_t bytes) {
     void* p = nullptr;
