@@ -2,7 +2,7 @@
 // Models the state-bank access of the 2-D slice kernels (one u64 bank per sample out of a private 63 KB table per
 // lane): every lane owns a 63408-byte table, picks a pseudo-random bank that depends on the value
 // it has just loaded (serial chain, like the decoder), adds one and writes it back.
-//   rand_table <waves> <steps> <alloc: 0 hipMalloc | 1 uncached | 2 fine-grained> <layout: 0 [group][ctx][lane] | 1 [slice][ctx]>
+//   rand_table <waves> <steps> <alloc: 0 hipMalloc | 1 uncached | 2 fine-grained | 3 physically contiguous> <layout: 0 [group][ctx][lane] | 1 [slice][ctx]>
 //              <flavour: 0 plain | 1 nontemporal load+store | 2 plain load, nontemporal store>
 // Prints accesses/s and the implied line traffic; run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE for bytes per access.
 #include <hip/hip_runtime.h>
@@ -44,7 +44,8 @@ int main(int argc, char** argv) {
     const size_t bytes = size_t(waves) * 64 * kCtx * 8;
     unsigned long long *tab = nullptr, *sink = nullptr;
     if (alloc == 0) CK(hipMalloc(&tab, bytes));
-    else CK(hipExtMallocWithFlags(reinterpret_cast<void**>(&tab), bytes, alloc == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
+    else CK(hipExtMallocWithFlags(reinterpret_cast<void**>(&tab), bytes,
+                                  alloc == 1 ? hipDeviceMallocUncached : (alloc == 2 ? hipDeviceMallocFinegrained : hipDeviceMallocContiguous)));
     CK(hipMalloc(&sink, 8));
     CK(hipMemset(tab, 0, bytes));
     hipEvent_t a, b;
