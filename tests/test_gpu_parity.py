@@ -438,6 +438,15 @@ def test_cli_roundtrip_matches_reference_behaviour(mi, orc, tmp_path):
     # sliced container through the CLI, damaged input -> exit code 1 with the reference's message
     assert subprocess.run([exe_c, str(ppm), "--sliced", "16x1"]).returncode == 0
     assert (tmp_path / "a.ppm.llcomp").read_bytes() == orc.compress_sliced(img, 16, 1, True)
+    # the LargeModel = false variant through the CLIs: the sliced container carries the flag, the reference format needs it said
+    orc.set_small_model(True)
+    try:
+        assert subprocess.run([exe_c, str(ppm), "--small-model"]).returncode == 0
+        assert (tmp_path / "a.ppm.llcomp").read_bytes() == orc.compress_image(img)
+    finally:
+        orc.set_small_model(False)
+    assert subprocess.run([exe_d, str(tmp_path / "a.ppm.llcomp"), "--small-model"]).returncode == 0
+    assert (tmp_path / "a.ppm.llcomp.png").read_bytes() == png
     bad = tmp_path / "bad.llcomp"
     bad.write_bytes(bytes([0x42]) + stream[1:])
     r = subprocess.run([exe_d, str(bad)], capture_output=True, text=True)

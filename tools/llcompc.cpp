@@ -1,4 +1,4 @@
-// llcompc <image> [--sliced TWxTH] [--interleaved]
+// llcompc <image> [--sliced TWxTH] [--interleaved] [--legacy] [--small-model]
 //
 // Compressor front end on libllcomp_mi.so with the observable behaviour of the reference tool
 // (/root/reference/llcompc.cpp:14-43): exactly one required positional argument, output written next to the input as
@@ -26,6 +26,8 @@ bool parse_flags(int argc, char** argv, llcomp::Options& opt, bool& explicit_leg
             opt.planar = false;
         } else if (flag == "--legacy") {
             explicit_legacy = true;
+        } else if (flag == "--small-model") {  // the bitstream of a reference built with LargeModel = false (llcomp.hpp:21)
+            opt.small_model = true;
         } else if (flag == "--sliced" && i + 1 < argc) {
             unsigned tw = 0, th = 0;
             if (std::sscanf(argv[++i], "%ux%u", &tw, &th) != 2) return false;
@@ -69,7 +71,7 @@ int main(int argc, char** argv) {
     llcomp::Options opt;
     bool explicit_legacy = false;
     if (argc < 2 || !parse_flags(argc, argv, opt, explicit_legacy)) {
-        std::fprintf(stderr, "Usage: %s <image_path> [--sliced TWxTH] [--interleaved] [--legacy]\n", argc ? argv[0] : "llcompc");
+        std::fprintf(stderr, "Usage: %s <image_path> [--sliced TWxTH] [--interleaved] [--legacy] [--small-model]\n", argc ? argv[0] : "llcompc");
         return cli::kFailed;
     }
     return compress_file(argv[1], opt, explicit_legacy);

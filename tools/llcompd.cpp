@@ -1,10 +1,12 @@
-// llcompd <file.llcomp>
+// llcompd <file.llcomp> [--small-model]
 //
 // Decompressor front end on libllcomp_mi.so with the observable behaviour of the reference tool
 // (/root/reference/llcompd.cpp:11-41): one positional argument, the picture is written as "<file>.png", exit status 1
 // when the input cannot be read or the stream is rejected with a std::exception (message printed), 2 for any other
 // exception, and -- faithfully -- still 0 when only writing the PNG failed (llcompd.cpp:29-31).  stb_image_write is not
-// available; tools/image_io.hpp writes the PNG (stored deflate blocks).  Reads both wire formats.
+// available; tools/image_io.hpp writes the PNG (stored deflate blocks).  Reads both wire formats.  --small-model: the file is a
+// reference-format stream written by a reference built with `LargeModel = false` (llcomp.hpp:21) -- that header does not
+// record the variant (a sliced container does).
 #include <cstdio>
 #include <exception>
 #include <string>
@@ -16,7 +18,7 @@
 
 namespace {
 
-int expand_file(const std::string& stream_path) {
+int expand_file(const std::string& stream_path, bool legacy_small_model) {
     std::vector<uint8_t> stream;
     if (!cli::slurp(stream_path, stream)) {
         std::fprintf(stderr, "Error opening input file: %s\n", stream_path.c_str());
@@ -24,7 +26,7 @@ int expand_file(const std::string& stream_path) {
     }
     llcomp::RawImage picture;
     try {
-        picture = llcomp::decompressImage(stream);
+        picture = llcomp::decompressImage(stream, -1, legacy_small_model);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "Error decompressing image: %s\n", e.what());
         return cli::kFailed;
@@ -43,8 +45,10 @@ int expand_file(const std::string& stream_path) {
 
 int main(int argc, char** argv) {
     if (argc < 2) {
-        std::fprintf(stderr, "Usage: %s <image_path>\n", argc ? argv[0] : "llcompd");
+        std::fprintf(stderr, "Usage: %s <image_path> [--small-model]\n", argc ? argv[0] : "llcompd");
         return cli::kFailed;
     }
-    return expand_file(argv[1]);
+    bool small = false;
+    for (int i = 2; i < argc; ++i) small = small || std::string(argv[i]) == "--small-model";
+    return expand_file(argv[1], small);
 }
