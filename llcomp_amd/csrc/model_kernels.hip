@@ -539,6 +539,18 @@ __device__ __forceinline__ bool xcd_group_chunk(uint32_t n_groups, uint32_t chun
     return group < n_groups;
 }
 __host__ inline uint64_t xcd_grid(uint32_t n_groups, uint32_t chunks) { return uint64_t((n_groups + kXcds - 1) / kXcds) * kXcds * chunks; }
+// The other way round for the decode side: there a workgroup also reads a few lanes of the NEXT lane group's rows (the
+// channel planes of a tile that straddles two groups), i.e. the same lane-order rows as workgroup (group + 1, same chunk).
+// Chunk c of every group goes to XCD c % 8, so those rows are fetched into one L2 only (measured: 2x the fetch traffic
+// with the group-major mapping above).
+__device__ __forceinline__ bool xcd_chunk_group(uint32_t n_groups, uint32_t chunks, uint32_t& group, uint32_t& chunk) {
+    const uint32_t xcd = blockIdx.x % kXcds, slot = blockIdx.x / kXcds;
+    const uint32_t per_class = (chunks + kXcds - 1) / kXcds;  // chunks c with c % 8 == xcd
+    group = slot / per_class;
+    chunk = xcd + kXcds * (slot - group * per_class);
+    return group < n_groups && chunk < chunks;
+}
+__host__ inline uint64_t xcd_chunk_grid(uint32_t n_groups, uint32_t chunks) { return uint64_t(n_groups) * ((chunks + kXcds - 1) / kXcds) * kXcds; }
 
 // ---- fused stage A for planar 1-row slices (tile_h == 1, planar) -------------------------------------------------------
 // The headline configuration.  One block = one lane group (64 consecutive slice ids = ~64/C tiles x C channel planes)
@@ -679,7 +691,7 @@ __global__ __launch_bounds__(256) void k_model_rows_inv(const Geometry g, const 
     __shared__ RowTile tiles[TPG];
     const uint32_t chunks = (g.tile_w + K - 1) / K;
     uint32_t group, chunk;
-    if (!xcd_group_chunk((g.n_slices + (1u << g.lane_shift) - 1) >> g.lane_shift, chunks, group, chunk)) return;  // (uniform per block)
+    if (!xcd_chunk_group((g.n_slices + (1u << g.lane_shift) - 1) >> g.lane_shift, chunks, group, chunk)) return;  // (uniform per block)
     const uint32_t k0 = chunk * K;
     const uint32_t gw = 1u << g.lane_shift;
     const uint32_t first_id = group << g.lane_shift;
@@ -805,7 +817,7 @@ hipError_t launch_model_rows_fwd(const Geometry& g, const uint8_t* d_px, uint16_
 }
 
 hipError_t launch_model_rows_inv(const Geometry& g, const int16_t* d_lanes, uint8_t* d_px, hipStream_t stream) {
-    const uint64_t blocks = xcd_grid(lane_groups(g), (g.tile_w + 63) / 64);
+    const uint64_t blocks = xcd_chunk_grid(lane_groups(g), (g.tile_w + 63) / 64);
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     LLMI_DISPATCH_C(g.c, (k_model_rows_inv<C><<<dim3(uint32_t(blocks)), dim3(256), 0, stream>>>(g, d_lanes, d_px)));
     return hipGetLastError();
