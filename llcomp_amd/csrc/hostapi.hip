@@ -182,6 +182,14 @@ int acquire_lane(HostLane** out, int32_t device, uint32_t w, uint32_t h, uint32_
     return lane_create(out, dev, w, h, c, tile_w, tile_h, planar, legacy, min_cap, small_model);
 }
 
+// Copies between a CALLER's buffer and HBM, stream-ordered on the lane's private stream and complete on return (staged by
+// the runtime for pageable memory, plain DMA for pinned memory).  Measured on a 4K noise frame, buffers reused across
+// calls: 2.1 ms encode + 2.1 ms decode with pageable and with pinned buffers alike; what makes the allocating calls
+// slower is the first touch of a fresh 30 MB malloc per call, not the copy.
+inline hipError_t copy_user(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t s) {
+    return n ? hipMemcpyWithStream(dst, src, n, kind, s) : hipSuccess;
+}
+
 struct LaneLease {  // returns the lane to the cache on every exit path
     HostLane* l = nullptr;
     ~LaneLease() { if (l) lane_cache().give(l); }
@@ -217,7 +225,7 @@ int encode_common(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, const l
     if (int rc = lane_grow(l, std::min(first_cap, max_payload))) return rc;
     DeviceGuard guard(l->k->device);
     if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
-    LLMI_HIP_TRY(hipMemcpyAsync(l->d_px, px, raw, hipMemcpyHostToDevice, l->stream));
+    LLMI_HIP_TRY(copy_user(l->d_px, px, raw, hipMemcpyHostToDevice, l->stream));
     int rc = LLCOMP_MI_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = lane_enqueue_encode(l))) return rc;
@@ -240,8 +248,7 @@ int encode_common(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, const l
         return LLCOMP_MI_OUTPUT_OVERFLOW;  // *out_len tells the caller what it takes
     }
     // header, slice table and payload sit in HBM exactly as on the wire (little-endian u32 on both sides): one copy
-    if (hipMemcpyAsync(dst, l->d_container, n, hipMemcpyDeviceToHost, l->stream) != hipSuccess ||
-        hipStreamSynchronize(l->stream) != hipSuccess) {
+    if (copy_user(dst, l->d_container, n, hipMemcpyDeviceToHost, l->stream) != hipSuccess) {
         if (!out) std::free(dst);
         return LLCOMP_MI_HIP_ERROR;
     }
@@ -269,7 +276,7 @@ int decode_common(const uint8_t* data, size_t len, int32_t device, uint32_t flag
     DeviceGuard guard(l->k->device);
     if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
     // the container goes to HBM as it is: the slice table is read where it lies (offset 24, dword aligned)
-    LLMI_HIP_TRY(hipMemcpyAsync(l->d_container, data, len, hipMemcpyHostToDevice, l->stream));
+    LLMI_HIP_TRY(copy_user(l->d_container, data, len, hipMemcpyHostToDevice, l->stream));
     if (int rc = lane_enqueue_decode(l, len - l->head_bytes)) return rc;
     LLMI_HIP_TRY(hipStreamSynchronize(l->stream));
     if (int rc = status_from_bits(uint32_t(l->h_meta[1]))) return rc;
@@ -278,7 +285,7 @@ int decode_common(const uint8_t* data, size_t len, int32_t device, uint32_t flag
         dst = static_cast<uint8_t*>(std::malloc(raw ? raw : 1));
         if (!dst) return LLCOMP_MI_NOMEM;
     }
-    if (hipMemcpyAsync(dst, l->d_px, raw, hipMemcpyDeviceToHost, l->stream) != hipSuccess || hipStreamSynchronize(l->stream) != hipSuccess) {
+    if (copy_user(dst, l->d_px, raw, hipMemcpyDeviceToHost, l->stream) != hipSuccess) {
         if (!px) std::free(dst);
         return LLCOMP_MI_HIP_ERROR;
     }
