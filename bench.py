@@ -385,10 +385,23 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
         sk.close()
-    if args.rehearse_one_gpu:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    else:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    # RCCL prints a version banner on STDOUT when its communicator comes up; stdout carries exactly one JSON line, so the
+    # file descriptor points at stderr until the communicator exists (init + a first collective)
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        warm = torch.zeros(1, device="cuda")
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
     barrier = dist.barrier if world > 1 else None
 
     planar = not args.interleaved
