@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""How far apart are the uses of one context's state bank inside a 2-D slice?  ("2-D tiles".)
+
+Not a test (pytest does not collect it): an analysis on the oracle's context traces that decides whether a small exact
+per-lane cache of state banks in LDS could take the random HBM accesses off the 2-D slice kernels.  For 64x64 planes of
+4K frames it replays each slice's context sequence through LRU caches of 1..512 entries at 8-byte (one bank), 32-, 64- and
+128-byte (slice-major table, one cache line) granularity and prints the hit rates.
+
+    python tests/analyse_context_reuse.py > profiles/r02_context_reuse.txt        (CPU only, about two minutes)
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import orc as orc_mod  # noqa: E402  (the checker: this script lives under tests/)
+from llcomp_amd import synth  # noqa: E402
+
+W, H = 3840, 2160
+SIZES = (1, 2, 4, 8, 32, 64, 128, 512)
+
+
+def lru_hits(seq, n):
+    cache, hit = [], 0
+    for c in seq:
+        if c in cache:
+            hit += 1
+            cache.remove(c)
+        elif len(cache) >= n:
+            cache.pop(0)
+        cache.append(c)
+    return hit
+
+
+def main():
+    orc = orc_mod.Orc()
+    print("LRU hit rates of per-slice state-bank caches, 64x64 planar slices of a 3840x2160 RGB8 frame (20 random slices per content)")
+    for gen in ("nat", "mid", "g3", "g2"):
+        rct = orc.forward_rct(synth.GENERATORS[gen](W, H, 3))
+        rng = np.random.default_rng(1)
+        hits, total, distinct = {}, 0, []
+        for _ in range(20):
+            tx, ty, ch = int(rng.integers(0, W // 64)), int(rng.integers(0, H // 64)), int(rng.integers(0, 3))
+            ctx, _res = orc.model_samples(rct[ty * 64:(ty + 1) * 64, tx * 64:(tx + 1) * 64, ch:ch + 1])
+            seq = ctx.reshape(-1).astype(np.int64)
+            total += seq.size
+            distinct.append((len(np.unique(seq)), len(np.unique(seq >> 4))))
+            for shift in (0, 2, 3, 4):
+                s = list(seq >> shift)
+                for n in SIZES:
+                    hits[(shift, n)] = hits.get((shift, n), 0) + lru_hits(s, n)
+        d = np.mean(distinct, axis=0)
+        print(f"\n{gen}: {d[0]:.0f} distinct contexts per slice (of 4096 samples), {d[1]:.0f} distinct 128-byte lines in a slice-major table")
+        print("   entries:        " + "".join(f"{n:>8d}" for n in SIZES))
+        for shift in (0, 2, 3, 4):
+            print(f"   {8 << shift:3d}-byte units: " + "".join(f"{hits[(shift, n)] / total:8.3f}" for n in SIZES))
+    print("\nWhat a lane can afford in LDS at full occupancy is about 8 banks (64 bytes): 10 % hits on photo-like content, 3 % on the dithered")
+    print("gradient, 19 % on noise -- and the lanes of a wavefront run in lock-step, so one miss in 64 stalls all of them.")
+
+
+if __name__ == "__main__":
+    main()
