@@ -41,13 +41,14 @@ def _worker(rank, world, backend, port, cases, q):
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        for (gen, w, h, c), (tw, th), planar, images, cpr in cases:
+        for (gen, w, h, c), (tw, th), planar, images, cpr, *rest in cases:
+            root = rest[0] if rest else None
             full = np.stack([np.roll(synth.GENERATORS[gen](w, h, c), 5 * b, axis=1) for b in range(images)])
-            sc = sharding.ShardedCodec(w, h, c, tw, th, planar, images=images, chunks_per_rank=cpr, device=dev)
+            sc = sharding.ShardedCodec(w, h, c, tw, th, planar, images=images, chunks_per_rank=cpr, root=root, device=dev)
             assert sc.band is None or type(sc.band).__name__ == "_HipBand"
             band = sc.take_local(full)
             conts = sc.encode(band)
-            assert sorted(conts) == [b for b in range(images) if b % world == rank]   # containers spread round-robin
+            assert sorted(conts) == [b for b in range(images) if (b % world if root is None else root) == rank]   # spread round-robin, or funnelled
             for b in conts:
                 want = mi.compress_image(full[b], w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar, device=0)
                 assert conts[b].is_cuda and bytes(conts[b].cpu().numpy()) == want, f"{gen} {w}x{h}: image {b} differs from the one-piece container"
@@ -91,4 +92,5 @@ def test_sharded_path_world2_hip_coder_gloo_exchange():
     _run(2, "gloo", [(("mid", 2048, 1024, 3), (128, 128), True, 2, 4),
                      (("g3", 1000, 333, 4), (480, 1), True, 2, 3),
                      (("nat", 777, 130, 3), (64, 16), False, 1, 1),
+                     (("mid", 640, 360, 3), (64, 64), True, 3, 2, 1),                 # every container funnelled to rank 1
                      (("g3", 8192, 2048, 3), (480, 1), True, 1, 4)])      # a quarter of config 4, noise
