@@ -181,3 +181,23 @@ def test_c5_stream_64_frames_4k(mi, orc, fpj):
     assert 0.76 < ratio < 0.79
     assert steady > 500  # one pageable 4K frame through the round-1 host calls ran at 640 MPix/s; a pipeline must not be slower
     pinned.close()
+
+
+def test_cpp_stream_driver(mi):
+    """tools/llcomp_stream: BASELINE config 5's loop written in C++ against the C ABI alone (pinned sources, back-pressure,
+    encode results handed to submit_decode_batch, memcmp on worker threads); it exits non-zero on any mismatch."""
+    import json
+    import os
+    import subprocess
+
+    from conftest import ROOT
+
+    exe = os.path.join(ROOT, "tools", "llcomp_stream")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")])
+    for args in (["12", "300", "200", "50", "1", "3", "2", "1"], ["12", "300", "200", "64", "16", "3", "2", "3"], ["8", "3840", "2160", "480", "1", "4", "2", "2"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        assert out["verified"] is True and out["frames"] == int(args[0]) and out["frames_per_job"] == int(args[7])
+        assert 0.5 < out["compression_ratio"] < 0.85  # xorshift noise
