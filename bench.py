@@ -527,7 +527,7 @@ def main():
     try:
         gold = [v for v in json.load(open(os.path.join(ROOT, "tests", "golden", "slice_payloads.json")))["vectors"]
                 if (v["gen"], v["w"], v["tile_w"], v["tile_h"], v["planar"]) == (args.content, W4K, args.tile_w, args.tile_h, planar)]
-        if gold:
+        if gold and args.content in ("g3", "g2"):  # frame 0 of these two IS the golden vector's image (mid / nat use other seeds here)
             res["golden_pin"] = {"frame0_container_bytes": m["frame0_container"], "reference": gold[0]["container_len"],
                                  "match": m["frame0_container"] == gold[0]["container_len"]}
             assert res["golden_pin"]["match"], "frame 0's container length differs from the reference's"

@@ -805,6 +805,8 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
             }
         } else {
         const ptrdiff_t up = ptrdiff_t(r.sw) * NCH * GW;  // one slice row back, in lane-order elements
+        uint32_t held_ctx = ~0u;   // context of the previous sample; its updated bank is still in registers
+        uint64_t held_bank = 0;
         for (uint32_t y = 0; y < r.sh; ++y) {
             int16_t* row = p0 + ptrdiff_t(y) * up;
             int l[NCH], L[NCH], t[NCH], tl[NCH], tr[NCH], T[NCH];
@@ -830,8 +832,13 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                     int ctx = context_hash(n, small_model);
                     const bool neg = ctx < 0;  // llcomp.hpp:511-515
                     if (neg) ctx = -ctx;
-                    const uint64_t b64 = banks[size_t(ctx) << bsh];
-                    Bank bank{{uint32_t(b64), uint32_t(b64 >> 32)}, nullptr};
+                    // The bank just updated stays in registers next to its write-through copy in the table.  On smooth content
+                    // most samples stay in the context of their predecessor, and when EVERY lane of the wavefront does, the
+                    // table read -- the one memory round trip that hangs on the sample just decoded -- is skipped.  The test
+                    // is wave-uniform: lanes never diverge here, and rough content pays one compare.
+                    if (__builtin_amdgcn_ballot_w64(uint32_t(ctx) != held_ctx) != 0) held_bank = banks[size_t(ctx) << bsh];
+                    held_ctx = uint32_t(ctx);
+                    Bank bank{{uint32_t(held_bank), uint32_t(held_bank >> 32)}, nullptr};
                     uint32_t v;
                     const bool ok = dec_sample<false>(d, bank, tab, hot, replay_always, v);
                     if (!ok) {
@@ -839,7 +846,8 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                         return;  // this lane's slice is unusable; the whole call reports the error
                     }
                     hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true)));
-                    banks[size_t(ctx) << bsh] = uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32);
+                    held_bank = uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32);
+                    banks[size_t(ctx) << bsh] = held_bank;
                     if (neg) v = 0u - v;
                     const int val = int(int16_t(uint32_t(predict(n)) + v));
                     q[k * GW] = int16_t(val);
