@@ -88,7 +88,9 @@ int llcomp_mi_encode_into(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c,
 int llcomp_mi_decode_into(const uint8_t* data, size_t len, int32_t device, uint8_t* px, size_t px_cap, uint32_t* w,
                           uint32_t* h, uint32_t* c);
 /* The host-buffer calls keep a few idle coding lanes (GBs of HBM workspace for a 4K frame) for the next call of the same
- * shape; this releases them. */
+ * shape, and the library parks the device memory of destroyed codecs / streams / lanes for reuse instead of returning it
+ * to the driver (up to 64 GiB; released by itself when an allocation fails).  This releases both.  Codec and stream
+ * objects in use are not touched. */
 void llcomp_mi_trim(void);
 void* llcomp_mi_host_alloc(size_t bytes); /* pinned host memory, NULL on failure */
 void llcomp_mi_host_free(void* p);

@@ -77,7 +77,8 @@ def decompress_image(data, *, device=-1, small_model=False):
 
 
 def trim():
-    """Release the idle coding lanes the host-buffer calls keep for the next call of the same shape (GBs of HBM)."""
+    """Release the idle coding lanes the host-buffer calls keep for the next call of the same shape (GBs of HBM) and
+    the device memory the library parks for reuse instead of returning it to the driver (csrc/devmem.hip)."""
     _lib.load().llcomp_mi_trim()
 
 

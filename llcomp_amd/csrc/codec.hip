@@ -68,15 +68,6 @@ namespace {
 
 #define HIP_TRY(expr) LLMI_HIP_TRY(expr)
 
-// Workspace buffers are tens of GB and every wavefront walks its own region of them: with HBM handed out in small physical
-// fragments (after many allocate / free cycles) the same kernels ran up to 2x slower (TLB reach).  Ask for physically
-// contiguous memory first; any refusal falls back to a plain hipMalloc.
-hipError_t ws_alloc(void** p, uint64_t bytes) {
-    if (bytes >= (64ull << 20) && hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous) == hipSuccess) return hipSuccess;
-    (void)hipGetLastError();
-    return hipMalloc(p, bytes);
-}
-
 // brackets a group of launches with two events when profiling is on
 struct Timed {
     llcomp_mi_codec* k;
@@ -96,6 +87,22 @@ struct Timed {
 };
 
 }  // namespace
+
+namespace llcomp_mi {
+// frees a codec whose work is known to be complete (the lanes synchronise their own stream instead of the whole device)
+void codec_release(llcomp_mi_codec* k) {
+    if (!k) return;
+    DeviceGuard guard(k->device);
+    dev_free(k->d_sym_or_rec);
+    dev_free(k->d_lane_order);
+    dev_free(k->d_states);
+    dev_free(k->d_scratch);
+    dev_free(k->d_group_off);
+    dev_free(k->d_total_tmp);
+    for (auto& sp : k->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    delete k;
+}
+}  // namespace llcomp_mi
 
 extern "C" {
 
@@ -164,11 +171,11 @@ int llcomp_mi_codec_create_ex(llcomp_mi_codec** out, int32_t device, uint32_t fr
                    b_scratch = (uint64_t(lane_groups(g)) << g.lane_shift) * g.slice_cap, b_off = (uint64_t(lane_groups(g)) + 1) * 8;
     const uint64_t b_lanes = (uint64_t(lane_groups(g)) * slice_capacity_samples(g) << g.lane_shift) * (fused ? 2 : 4);
     k->workspace_bytes = b_sym + b_lanes + b_states + b_scratch + b_off + 8;
-    bool ok = ws_alloc(&k->d_sym_or_rec, b_sym) == hipSuccess && ws_alloc(&k->d_lane_order, b_lanes) == hipSuccess &&
-              ws_alloc(reinterpret_cast<void**>(&k->d_states), b_states) == hipSuccess &&
-              ws_alloc(reinterpret_cast<void**>(&k->d_scratch), b_scratch) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void**>(&k->d_group_off), b_off) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void**>(&k->d_total_tmp), 8) == hipSuccess;
+    bool ok = dev_alloc(&k->d_sym_or_rec, b_sym) == hipSuccess && dev_alloc(&k->d_lane_order, b_lanes) == hipSuccess &&
+              dev_alloc(reinterpret_cast<void**>(&k->d_states), b_states) == hipSuccess &&
+              dev_alloc(reinterpret_cast<void**>(&k->d_scratch), b_scratch) == hipSuccess &&
+              dev_alloc(reinterpret_cast<void**>(&k->d_group_off), b_off) == hipSuccess &&
+              dev_alloc(reinterpret_cast<void**>(&k->d_total_tmp), 8) == hipSuccess;
     if (!ok) {
         llcomp_mi_codec_destroy(k);
         return LLCOMP_MI_NOMEM;
@@ -179,15 +186,13 @@ int llcomp_mi_codec_create_ex(llcomp_mi_codec** out, int32_t device, uint32_t fr
 
 void llcomp_mi_codec_destroy(llcomp_mi_codec* k) {
     if (!k) return;
-    DeviceGuard guard(k->device);
-    (void)hipFree(k->d_sym_or_rec);
-    (void)hipFree(k->d_lane_order);
-    (void)hipFree(k->d_states);
-    (void)hipFree(k->d_scratch);
-    (void)hipFree(k->d_group_off);
-    (void)hipFree(k->d_total_tmp);
-    for (auto& sp : k->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
-    delete k;
+    {
+        // the buffers go back to the library's cache (devmem.hip), which does not wait for the device the way hipFree
+        // does: whatever the caller still has in flight on its streams must be done first
+        DeviceGuard guard(k->device);
+        (void)hipDeviceSynchronize();
+    }
+    llcomp_mi::codec_release(k);
 }
 
 uint32_t llcomp_mi_codec_slices(const llcomp_mi_codec* k) { return k ? k->g.n_slices : 0; }

@@ -91,4 +91,14 @@ int lane_enqueue_encode(HostLane* l);
 // container in d_container (header + tables + `payload_bytes` of payload) -> frame(s) in d_px, status -> h_meta
 int lane_enqueue_decode(HostLane* l, uint64_t payload_bytes);
 
+void codec_release(llcomp_mi_codec* k);  // codec.hip: destroy without the device-wide wait (its work is known to be done)
+
+// devmem.hip: every device buffer of the library comes from here.  dev_alloc is hipMalloc on the current device through a
+// cache of parked blocks; dev_free parks a block (no device synchronisation: the caller makes sure nothing in flight
+// still uses it); dev_release_idle hands the parked blocks back to the driver.
+hipError_t dev_alloc(void** p, uint64_t bytes);
+void dev_free(void* p);
+void dev_release_idle();
+uint64_t dev_idle_bytes();
+
 }  // namespace llcomp_mi

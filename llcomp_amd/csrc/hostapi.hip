@@ -29,14 +29,14 @@ void lane_destroy(HostLane* l) {
     {
         DeviceGuard guard(l->k ? l->k->device : 0);
         if (l->stream) (void)hipStreamSynchronize(l->stream);
-        (void)hipFree(l->d_px);
-        (void)hipFree(l->d_container);
-        (void)hipFree(l->d_len_legacy);
-        (void)hipFree(l->d_meta);
+        dev_free(l->d_px);
+        dev_free(l->d_container);
+        dev_free(l->d_len_legacy);
+        dev_free(l->d_meta);
         if (l->h_meta) (void)hipHostFree(l->h_meta);
         if (l->stream) (void)hipStreamDestroy(l->stream);
     }
-    llcomp_mi_codec_destroy(l->k);
+    codec_release(l->k);  // the lane's stream was synchronised above; nothing else runs on this codec
     delete l;
 }
 
@@ -55,11 +55,11 @@ int lane_grow(HostLane* l, uint64_t payload_cap) {
     DeviceGuard guard(l->k->device);
     if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
     (void)hipStreamSynchronize(l->stream);
-    (void)hipFree(l->d_container);
+    dev_free(l->d_container);
     l->d_container = nullptr;
     l->bytes -= l->head_bytes + l->payload_cap;
     l->payload_cap = 0;
-    if (hipMalloc(reinterpret_cast<void**>(&l->d_container), l->head_bytes + payload_cap + 16) != hipSuccess) return LLCOMP_MI_NOMEM;
+    if (dev_alloc(reinterpret_cast<void**>(&l->d_container), l->head_bytes + payload_cap + 16) != hipSuccess) return LLCOMP_MI_NOMEM;
     l->payload_cap = payload_cap;
     l->bytes += l->head_bytes + payload_cap;
     return lane_write_header(l);
@@ -81,9 +81,9 @@ int lane_create(HostLane** out, int dev, uint32_t w, uint32_t h, uint32_t c, uin
     l->head_bytes = legacy ? 6u : uint32_t(LLCOMP_MI_SLICED_HEADER_BYTES) + 4u * g.n_slices;
     const uint64_t raw = l->raw_bytes();
     const bool ok = guard.ok && hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) == hipSuccess &&
-                    hipMalloc(reinterpret_cast<void**>(&l->d_px), raw + 4) == hipSuccess &&
-                    hipMalloc(reinterpret_cast<void**>(&l->d_len_legacy), 4) == hipSuccess &&
-                    hipMalloc(reinterpret_cast<void**>(&l->d_meta), l->meta_bytes()) == hipSuccess &&
+                    dev_alloc(reinterpret_cast<void**>(&l->d_px), raw + 4) == hipSuccess &&
+                    dev_alloc(reinterpret_cast<void**>(&l->d_len_legacy), 4) == hipSuccess &&
+                    dev_alloc(reinterpret_cast<void**>(&l->d_meta), l->meta_bytes()) == hipSuccess &&
                     hipHostMalloc(reinterpret_cast<void**>(&l->h_meta), l->meta_bytes(), hipHostMallocDefault) == hipSuccess;
     if (!ok) {
         lane_destroy(l);
@@ -330,7 +330,10 @@ int llcomp_mi_decode_into(const uint8_t* data, size_t len, int32_t device, uint8
     return decode_common(data, len, device, 0, px, px_cap, nullptr, w, h, c);
 }
 
-void llcomp_mi_trim(void) { drop_idle_lanes(lane_cache()); }
+void llcomp_mi_trim(void) {
+    drop_idle_lanes(lane_cache());
+    dev_release_idle();
+}
 
 void* llcomp_mi_host_alloc(size_t bytes) {
     void* p = nullptr;

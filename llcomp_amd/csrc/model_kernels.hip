@@ -498,10 +498,11 @@ __global__ __launch_bounds__(256) void k_to_lane_order(const Geometry g, const u
     }
     __syncthreads();
     const uint32_t gw = 1u << g.lane_shift;
-    for (uint32_t kk = b; kk < 64; kk += 4) {  // write: lanes run along the slice index
-        const uint32_t k = k0 + kk;
-        if (k < max_n && a < gw) lanes[((size_t(group) * max_n + k) << g.lane_shift) + a] = tile[a][kk];
-    }
+    // write: the block's 64 rows of `gw` lanes are one contiguous piece of the lane-order array; consecutive threads take
+    // consecutive elements, so a wavefront always stores whole 128-byte lines whatever the group width
+    T* out = lanes + ((size_t(group) * max_n + k0) << g.lane_shift);
+    const uint32_t n_el = min(64u, max_n - k0) << g.lane_shift;
+    for (uint32_t el = threadIdx.x; el < n_el; el += 256) out[el] = tile[el & (gw - 1)][el >> g.lane_shift];
 }
 
 template <typename T>
@@ -515,10 +516,11 @@ __global__ __launch_bounds__(256) void k_from_lane_order(const Geometry g, const
     const size_t rs = slice_row_stride(g);
     const uint32_t a = threadIdx.x & 63, b = threadIdx.x >> 6;
     const uint32_t gw = 1u << g.lane_shift;
-    for (uint32_t kk = b; kk < 64; kk += 4) {
-        const uint32_t k = k0 + kk;
-        tile[a][kk] = (k < max_n && a < gw) ? lanes[((size_t(group) * max_n + k) << g.lane_shift) + a] : T(0);
-    }
+    // read: the block's 64 rows of `gw` lanes are one contiguous piece (see k_to_lane_order); rows of lanes beyond the
+    // group width do not exist and their tile entries are never looked at (those spans are empty)
+    const T* in = lanes + ((size_t(group) * max_n + k0) << g.lane_shift);
+    const uint32_t n_el = min(64u, max_n - k0) << g.lane_shift;
+    for (uint32_t el = threadIdx.x; el < (64u << g.lane_shift); el += 256) tile[el & (gw - 1)][el >> g.lane_shift] = el < n_el ? in[el] : T(0);
     __syncthreads();
     for (uint32_t j = b; j < 64; j += 4) {
         const SliceSpan sp = spans[j];

@@ -586,3 +586,25 @@ def test_lane_group_width_does_not_change_bytes(mi, orc, shift, set_hook):
         s = mi.compress_image(img, 190, 21, 3, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar)
         assert s == orc.compress_sliced(img, tw, th, planar)
         assert np.array_equal(mi.decompress_image(s).pixels, img)
+
+
+# ---- device-memory cache (devmem.hip): nothing goes back to the driver until trim() --------------------------------
+def test_lane_churn_reuses_parked_blocks_and_trim_returns_them(mi, orc):
+    """Shapes come and go (the host API keeps 4 idle lanes): the buffers of dropped lanes are parked and reused, not
+    hipFree'd (a buffer taken right after a hipFree showed zeroed cache lines on this stack, see devmem.hip); trim()
+    hands everything back.  Containers must equal the oracle's throughout."""
+    import torch
+
+    mi.trim()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    rng = np.random.default_rng(77)
+    for i in range(12):  # 12 distinct shapes: lanes are dropped from the 5th on
+        w, h = 200 + 37 * i, 120 + 11 * i
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        s = mi.compress_image(img, w, h, 3, format=mi.FORMAT_SLICED, tile_w=64, tile_h=32, planar=bool(i & 1))
+        assert s == orc.compress_sliced(img, 64, 32, bool(i & 1))
+        assert np.array_equal(mi.decompress_image(s).pixels, img)
+    held = free0 - torch.cuda.mem_get_info(0)[0]
+    assert held > (8 << 20), "lanes and parked blocks should hold device memory here"
+    mi.trim()
+    assert torch.cuda.mem_get_info(0)[0] >= free0 - (64 << 20), "trim() must return lanes and parked blocks to the driver"

@@ -41,6 +41,10 @@ def make(rng, w, h, c, kind):
 def run_case(mi, orc, seed, check_legacy):
     rng = np.random.default_rng(seed)
     w, h, c = int(rng.integers(1, 700)), int(rng.integers(1, 300)), int(rng.integers(1, 5))
+    extra = np.random.default_rng(seed ^ 0x5A5A)  # (separate stream: the draws above define the same cases as before)
+    if extra.random() < 0.08:  # more than four channels: the generic kernels (llcomp.hpp:407-409, 541-543)
+        c, w, h = int(extra.integers(5, 10)), min(w, 160), min(h, 80)
+    small = bool(extra.random() < 0.12)  # the LargeModel = false bitstream
     img = make(rng, w, h, c, int(rng.integers(0, 5)))
     mode = int(rng.integers(0, 4))
     if mode == 0:
@@ -65,16 +69,18 @@ def run_case(mi, orc, seed, check_legacy):
         os.environ.pop(k, None)
     os.environ.update(env)
     mi.reload_tuning()  # the library reads its hooks once per process unless told otherwise
+    orc.set_small_model(small)
     try:
         want = orc.compress_sliced(img, tw, th, planar)
-        got = mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar)
-        assert got == want, f"case {seed}: container differs ({w}x{h}x{c} tile {tw}x{th} planar={planar} env={env})"
+        got = mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar, small_model=small)
+        assert got == want, f"case {seed}: container differs ({w}x{h}x{c} tile {tw}x{th} planar={planar} small={small} env={env})"
         assert np.array_equal(mi.decompress_image(got).pixels, img), f"case {seed}: round trip"
         if check_legacy and w * h * c <= 120000:
-            leg = mi.compress_image(img, w, h, c)
+            leg = mi.compress_image(img, w, h, c, small_model=small)
             assert leg == orc.compress_image(img), f"case {seed}: legacy stream differs"
-            assert np.array_equal(mi.decompress_image(leg).pixels, img)
+            assert np.array_equal(mi.decompress_image(leg, small_model=small).pixels, img)
     finally:
+        orc.set_small_model(False)
         for k in HOOKS:
             os.environ.pop(k, None)
         mi.reload_tuning()
