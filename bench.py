@@ -268,7 +268,7 @@ def c5_stream(frames_np, tile_w, tile_h, planar, depth=8, frames_per_job=4):
             "note": "end to end over PCIe from/to pinned host memory, steady state (first 4 frames excluded), every frame bit-exact; never part of `value`"}
 
 
-def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank, check_one_piece=True):
+def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank, check_one_piece=True, parts=0):
     """BASELINE config 4: `images` noise images of size x size RGB8, each sharded over all ranks; encode (+ exchange of the
     bitstream) and decode (+ exchange back) per step.  The batch is coded as up to three part batches on as many HIP streams
     (a ShardedCodec each) so that the exchange of one part overlaps the coding of the others.  Returns the max-over-ranks wall time."""
@@ -279,8 +279,8 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     from llcomp_amd import sharding
 
     dev = torch.device("cuda", local_rank)
-    # 3, 2 or 1 part batches, each spreading its containers evenly over the ranks
-    halves = next(p for p in (3, 2, 1) if images % p == 0 and (images // p) % world == 0 or p == 1)
+    # 3, 2 or 1 part batches (measured on one GPU: 2, 3 and 6 parts all take 82 ms per step), each spreading its containers evenly over the ranks
+    halves = next(p for p in ((parts,) if parts else ()) + (3, 2, 1) if images % p == 0 and (images // p) % world == 0 or p == 1)
     per = images // halves
     scs = [sharding.ShardedCodec(size, size, 3, tile_w, tile_h, True, images=per, device=dev) for _ in range(halves)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(halves)]
@@ -302,17 +302,24 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     torch.cuda.synchronize()
 
     def step():
+        """software pipeline over the parts: while the host waits for one part's sizes (the exchange needs them) the GPU
+        already holds the next part's coding, and a part's decode is queued as soon as its containers exist -- so encode
+        and decode kernels of different parts, memory-bound and issue-bound ones, run beside each other."""
         conts, outs = [None] * halves, [None] * halves
-        for k in range(halves):  # local coding of both halves is queued first ...
+
+        def on(k, fn, *a, **kw):
             with torch.cuda.stream(streams[k]):
-                scs[k].encode_begin(bands[k])
-        for k in range(halves):  # ... so the exchange of half 0 runs beside the coding of half 1
-            with torch.cuda.stream(streams[k]):
-                conts[k] = scs[k].encode_finish()
-        for k in range(halves):
-            with torch.cuda.stream(streams[k]):
-                outs[k] = scs[k].decode(conts[k], validate=False)  # straight from encode: no header round trip
-        # every part has drained its own stream by now (decode ends with its status check); the device-wide wait costs
+                return fn(*a, **kw)
+
+        for k in range(halves + 2):
+            if k < halves:
+                on(k, scs[k].encode_begin, bands[k])
+            if 1 <= k <= halves:
+                conts[k - 1] = on(k - 1, scs[k - 1].encode_finish)
+                on(k - 1, scs[k - 1].decode_begin, conts[k - 1], validate=False)  # straight from encode: no header round trip
+            if k >= 2:
+                outs[k - 2] = on(k - 2, scs[k - 2].decode_finish)
+        # every part has drained its own stream by now (decode_finish reads its status); the device-wide wait costs
         # microseconds and keeps steps from interleaving in the runtime's queues (without it some runs of this leg took
         # twice as long per step, with identical kernels and allocator statistics)
         torch.cuda.synchronize()
@@ -375,6 +382,7 @@ def main():
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra one-pipeline-at-a-time launches behind the timed region (profiler runs)")
     ap.add_argument("--no-also", action="store_true", help="only the headline workload (profiler runs, sweeps)")
     ap.add_argument("--also-only", default="", help="comma-separated subset of the `also` legs: contents,tiles,latency,legacy,c5,c4 (profiling)")
+    ap.add_argument("--c4-parts", type=int, default=0, help="part batches (ShardedCodec objects on their own HIP streams) of the config-4 step; 0 = three where the image count allows")
     ap.add_argument("--c4-images", type=int, default=24, help="8192x8192 images per step of the sharded (config 4) workload (fixed total: strong scaling)")
     ap.add_argument("--c4-tile-w", type=int, default=512)
     ap.add_argument("--c4-tile-h", type=int, default=1)
@@ -429,7 +437,7 @@ def main():
     if world > 1:
         # ---- BASELINE config 4: strong scaling of sharded 8192^2 images, gather + scatter inside the timed region ----
         size, B = 8192, args.c4_images
-        dt, payload = c4_run(B, size, args.c4_tile_w, args.c4_tile_h, args.steps, args.warmup, local_rank, world, rank)
+        dt, payload = c4_run(B, size, args.c4_tile_w, args.c4_tile_h, args.steps, args.warmup, local_rank, world, rank, parts=args.c4_parts)
         # second key: the config-3 workload, frames sharded over the ranks (independent objects, no collective)
         m = measure(make_frames(args.content, F, rank, distinct=min(F, 8)), args.tile_w, args.tile_h, planar, args.streams, max(2, args.steps // 3), 1,
                     local_rank, barrier=barrier)
@@ -546,7 +554,7 @@ def main():
         # BASELINE config 4 on one GPU: the N = 1 point of the strong-scaling curve the N > 1 runs report (>100 GB of workspace)
         if want("c4"):
             n4 = max(4, sub // 2)
-            dt4, pay4 = c4_run(args.c4_images, 8192, args.c4_tile_w, args.c4_tile_h, n4, 3, local_rank, world, rank)
+            dt4, pay4 = c4_run(args.c4_images, 8192, args.c4_tile_w, args.c4_tile_h, n4, 3, local_rank, world, rank, parts=args.c4_parts)
             mi.trim()  # the one-piece check went through a host-buffer call: give its cached lane (10 GB) back
             also["c4_sharded_one_gpu"] = {"value": round(args.c4_images * 8192 * 8192 * n4 / dt4 / 1e6, 1), "unit": "MPix/s",
                                           "ms_per_step": round(dt4 / n4 * 1e3, 3), "steps": n4, "images_per_step": args.c4_images,

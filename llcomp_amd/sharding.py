@@ -169,6 +169,7 @@ class ShardedCodec:
         self.xorder = t(sorted(range(len(seg)), key=lambda i: key[i]))
         self.seg_mine = t([i for i, (b, ci) in enumerate(seg) if self.root_of[b] == self.rank])  # segments of the images I gather
         self._pending = None
+        self._pending_decode = None
         self.header = torch.tensor(list(bytes([MAGIC_SLICED, 1, c, 1 if self.planar else 0]) + b"".join(
             int(v).to_bytes(4, "little") for v in (w, h, self.tile_w, self.tile_h, self.spf))), dtype=torch.uint8, device=device)
 
@@ -279,7 +280,24 @@ class ShardedCodec:
         """containers: {image index: uint8 device tensor} for the images this rank holds (what encode returned).  Every rank
         returns its decoded rows [images, local_h, w, c] (uint8, on its device; frames in frame_images order).
         validate=False skips the comparison of the 24 header bytes with this object's geometry (a host round trip per
-        container) -- for containers that come straight from encode()."""
+        container) -- for containers that come straight from encode().
+        = decode_begin + decode_finish; several ShardedCodec objects on their own HIP streams queue all their decodes before
+        anyone waits for a status (bench.py does)."""
+        self.decode_begin(containers, validate)
+        return self.decode_finish()
+
+    def decode_finish(self):
+        """wait for the decode queued by decode_begin (on the stream it was queued on), raise on a damaged stream, return
+        this rank's rows"""
+        out, status = self._pending_decode[:2]
+        self._pending_decode = None
+        if status is not None:
+            self.band.check(status)
+        return out
+
+    def decode_begin(self, containers, validate=True):
+        """the exchange back (slice-table all_gather, message sizes to the host, all-to-all of the payloads) and the local
+        decode, enqueued on the current stream; nothing waits for the decoded pixels"""
         head = HEADER + 4 * self.spf
         per_root = max(1, max(sum(1 for b in range(self.images) if self.root_of[b] == r) for r in range(self.world)))
         mine_tab = torch.zeros(per_root * self.spf, dtype=torch.int32, device=self.comm_device)
@@ -315,16 +333,16 @@ class ShardedCodec:
         recv = self._exchange(send, [M_h[s][self.rank] for s in range(self.world)], M_h[self.rank])
         out = torch.empty((self.images, self.local_h, self.w, self.c), dtype=torch.uint8, device=self.device)
         if self.band is None:
-            return out
+            self._pending_decode = (out, None)
+            return
         # this rank's slice lengths in ITS codec's order (frame, local tile rows): the inverse of the permutation
         all_order = torch.empty(self.world * self.images * self.max_local, dtype=torch.int64, device=self.device)
         all_order[self.perm] = lens_c
         per = self.local_slices[self.rank]
         base = self.rank * self.images * self.max_local
         my_lens = all_order[base: base + self.images * per].to(torch.int32).contiguous()
-        status = self.band.decode(recv, int(sum(M_h[self.rank])), my_lens, out)
-        self.band.check(status)
-        return out
+        # (recv and my_lens stay referenced until decode_finish: the kernels that read them are only queued here)
+        self._pending_decode = (out, self.band.decode(recv, int(sum(M_h[self.rank])), my_lens, out), recv, my_lens)
 
     def gather_pixels(self, local_out, dst=0):
         """rank `dst`: the full batch [images, h, w, c] assembled from every rank's decoded rows (one message per rank);

@@ -97,6 +97,23 @@ def _worker(rank, world, port, case, q):
         px = sc.gather_pixels(out)
         if rank == 0:
             assert np.array_equal(px.numpy(), full)
+        # two part batches in bench.py's software-pipelined order (begin / finish halves interleaved): same bytes, same rows
+        sc2 = sharding.ShardedCodec(w, h, c, tw, th, planar, images=images, chunks_per_rank=cpr, root=root, device=torch.device("cpu"),
+                                    band_factory=oracle_band_factory(orc))
+        full2 = np.ascontiguousarray(full[:, ::-1])  # the second part: the images upside down
+        band2 = sc2.take_local(full2)
+        sc.encode_begin(band)
+        sc2.encode_begin(band2)
+        c1 = sc.encode_finish()
+        sc.decode_begin(c1)
+        c2 = sc2.encode_finish()
+        sc2.decode_begin(c2)
+        o1 = sc.decode_finish()
+        o2 = sc2.decode_finish()
+        for b in want_mine:
+            assert bytes(c1[b].numpy()) == bytes(conts[b].numpy())
+            assert bytes(c2[b].numpy()) == orc.compress_sliced(full2[b], tw, th, planar)
+        assert np.array_equal(o1.numpy(), full[sc.frame_images][:, rows]) and np.array_equal(o2.numpy(), full2[sc2.frame_images][:, rows])
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
