@@ -364,11 +364,17 @@ __global__ __launch_bounds__(256) void k_pack_payload(const Geometry g, const ui
     const uint32_t cap16 = g.slice_cap >> 4;
     const uint32_t a = threadIdx.x & 63, b = threadIdx.x >> 6;
     for (uint32_t c0 = 0; c0 * 256 < gs.max_len; ++c0) {
-        for (uint32_t uu = b; uu < 16; uu += 4) {  // 1 KiB rows of units
-            const uint32_t u = c0 * 16 + uu;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (u < cap16 && a < (1u << g.lane_shift)) v = units[((size_t(group) * cap16 + u) << g.lane_shift) + a];
-            tile[a][uu * 4 + 0] = v.x; tile[a][uu * 4 + 1] = v.y; tile[a][uu * 4 + 2] = v.z; tile[a][uu * 4 + 3] = v.w;
+        uint4 v[4];  // 1 KiB rows of units; all four loads are in flight before the first is stored (see k_model_rows_inv)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t u = c0 * 16 + b + 4 * t;
+            v[t] = make_uint4(0, 0, 0, 0);
+            if (u < cap16 && a < (1u << g.lane_shift)) v[t] = units[((size_t(group) * cap16 + u) << g.lane_shift) + a];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t uu = b + 4 * t;
+            tile[a][uu * 4 + 0] = v[t].x; tile[a][uu * 4 + 1] = v[t].y; tile[a][uu * 4 + 2] = v[t].z; tile[a][uu * 4 + 3] = v[t].w;
         }
         __syncthreads();
         for (uint32_t j = b; j < 64; j += 4) {  // 256-byte runs of one slice
@@ -400,15 +406,25 @@ __global__ __launch_bounds__(256) void k_stage_streams(const Geometry g, const u
     const uint32_t a = threadIdx.x & 63, b = threadIdx.x >> 6;
     // "+ 4": the dword right behind every stream is staged too (as zeros) -- the decoder clamps its reads to it
     for (uint32_t c0 = 0; c0 * 256 < gs.max_len + 4; ++c0) {
-        for (uint32_t j = b; j < 64; j += 4) {
-            const uint32_t n = gs.len[j], p = c0 * 256 + a * 4;
-            uint32_t w = 0;
+        // all sixteen loads of a thread are in flight before the first is stored.  The last, partial dword of a stream is
+        // read as a whole dword and masked wherever the payload has the bytes (always, except at its very end).
+        uint32_t w[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t j = b + 4 * t, n = gs.len[j], p = c0 * 256 + a * 4;
+            w[t] = 0;
             if (p < n) {
-                const uint8_t* src = payload + gs.off[j] + p;
-                if (p + 4 <= n) __builtin_memcpy(&w, src, 4);
-                else w = load_bytes_le(src, n - p);
+                const unsigned long long at = gs.off[j] + p;
+                const uint8_t* src = payload + at;
+                if (at + 4 <= payload_bytes) __builtin_memcpy(&w[t], src, 4);
+                else w[t] = load_bytes_le(src, n - p);
             }
-            tile[j][a] = w;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {  // (the mask is applied here, not above: nothing waits for a load before all are issued)
+            const uint32_t j = b + 4 * t, n = gs.len[j], p = c0 * 256 + a * 4;
+            const uint32_t keep = n >= p + 4 ? 0xFFFFFFFFu : n > p ? 0xFFFFFFFFu >> (8 * (p + 4 - n)) : 0u;
+            tile[j][a] = w[t] & keep;
         }
         __syncthreads();
         for (uint32_t uu = b; uu < 16; uu += 4) {
@@ -491,10 +507,16 @@ __global__ __launch_bounds__(256) void k_to_lane_order(const Geometry g, const u
     load_spans(g, group, spans);
     const size_t rs = slice_row_stride(g);
     const uint32_t a = threadIdx.x & 63, b = threadIdx.x >> 6;
-    for (uint32_t j = b; j < 64; j += 4) {  // read: lanes run along k (contiguous in image order)
-        const SliceSpan sp = spans[j];
-        const uint32_t k = k0 + a;
-        tile[j][a] = k < sp.n ? img[span_index(sp, k, rs)] : T(0);
+    {   // read: lanes run along k (contiguous in image order); sixteen loads in flight, then sixteen LDS stores
+        T v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const SliceSpan sp = spans[b + 4 * t];
+            const uint32_t k = k0 + a;
+            v[t] = k < sp.n ? img[span_index(sp, k, rs)] : T(0);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) tile[b + 4 * t][a] = v[t];
     }
     __syncthreads();
     const uint32_t gw = 1u << g.lane_shift;
@@ -520,7 +542,19 @@ __global__ __launch_bounds__(256) void k_from_lane_order(const Geometry g, const
     // group width do not exist and their tile entries are never looked at (those spans are empty)
     const T* in = lanes + ((size_t(group) * max_n + k0) << g.lane_shift);
     const uint32_t n_el = min(64u, max_n - k0) << g.lane_shift;
-    for (uint32_t el = threadIdx.x; el < (64u << g.lane_shift); el += 256) tile[el & (gw - 1)][el >> g.lane_shift] = el < n_el ? in[el] : T(0);
+    {   // (sixteen loads in flight, then sixteen LDS stores)
+        T v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t el = threadIdx.x + 256 * t;
+            v[t] = el < n_el ? in[el] : T(0);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t el = threadIdx.x + 256 * t;
+            if (el < (64u << g.lane_shift)) tile[el & (gw - 1)][el >> g.lane_shift] = v[t];
+        }
+    }
     __syncthreads();
     for (uint32_t j = b; j < 64; j += 4) {
         const SliceSpan sp = spans[j];
@@ -591,13 +625,25 @@ __device__ __forceinline__ void load_row_tiles(const Geometry& g, uint32_t first
     }
 }
 
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// (hipcc turns min(x, 1) on 16-bit pairs into two compares, two selects and a byte permute)
+__device__ __forceinline__ u16x2 pk_min_u16(u16x2 a, u16x2 b) {
+    u16x2 d;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void k_model_rows_fwd(const Geometry g, const uint8_t* __restrict__ px,
                                                         uint16_t* __restrict__ lanes) {
     constexpr int K = 64, RUN = (K + 2) * C, TPG = 64 / C + 2;
     constexpr int RUNW = (RUN + 3) / 4 + 1;  // dwords that cover a run at any byte alignment
+    // otile columns: PADL columns of padding, the group's 64 lanes, C-1 more.  The first and the last tile of a group may
+    // have channel planes that belong to the neighbouring groups: their symbols land in the padding, no range test per store.
+    constexpr int PADL = (C - 1 + 1) & ~1, OCOLS = (PADL + 64 + C - 1 + 1) & ~1;
     __shared__ uint32_t raw[TPG][RUNW + 1];
-    __shared__ __attribute__((aligned(4))) uint16_t otile[K][64 + 2];  // symbols [sample][group-relative lane]
+    __shared__ __attribute__((aligned(4))) uint16_t otile[K][OCOLS];  // symbols [sample][PADL + group-relative lane]
     __shared__ RowTile tiles[TPG];
     const uint32_t chunks = (g.tile_w + K - 1) / K;
     uint32_t group, chunk;
@@ -610,58 +656,107 @@ __global__ __launch_bounds__(256) void k_model_rows_fwd(const Geometry g, const 
     const uint32_t first_tile = first_id / C, ntiles = (end_id - 1) / C - first_tile + 1;
     load_row_tiles<C>(g, first_tile, ntiles, tiles);
     __syncthreads();
-    // stage the pixel runs [k0-2, k0+64) of every tile as aligned dwords (coalesced); consumers add the byte skew
+    // stage the pixel runs [k0-2, k0+64) of every tile as aligned dwords (coalesced); consumers add the byte skew.
+    // One wavefront per tile, lane = dword of the run: the run's address is wave-uniform, so the common case (the whole
+    // run inside the caller's buffer) is a 32-bit lane offset from a scalar base.
     const size_t total_bytes = size_t(g.frames) * g.h * g.w * C;
-    for (uint32_t i = threadIdx.x; i < ntiles * RUNW; i += 256) {
-        const uint32_t tt = i / RUNW, d = i - tt * RUNW;
-        const long long start = (long long)tiles[tt].base + (long long)(int(k0) - 2) * C;  // may be < 0 for the first run
-        const long long al = (start & ~3ll) + 4ll * d;
-        // never a byte beyond the caller's buffer: the last partial dword is assembled from byte loads
-        uint32_t v = 0;
-        if (al >= 0 && size_t(al) + 4 <= total_bytes) __builtin_memcpy(&v, px + al, 4);  // (px itself may be unaligned)
-        else if (al >= 0 && size_t(al) < total_bytes) v = load_bytes_le(px + al, uint32_t(total_bytes - size_t(al)));
-        raw[tt][d] = v;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (every load of a wavefront is issued before the first result is stored to LDS: one memory latency per block instead
+    // of one per tile -- the kernel is bound by the latency of its phases, not by bandwidth or arithmetic)
+    constexpr int TPW = (TPG + 3) / 4, DPT = (RUNW + 63) / 64;  // tiles per wavefront, dwords per lane and tile
+    uint32_t got[TPW][DPT];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const uint32_t tt = wave + 4 * t;
+#pragma unroll
+        for (int e = 0; e < DPT; ++e) got[t][e] = 0;
+        if (tt < ntiles) {
+            const long long start = (long long)tiles[tt].base + (long long)(int(k0) - 2) * C;  // may be < 0 for the first run
+            const unsigned long long a0u = (unsigned long long)(start & ~3ll);
+            const long long a0 = (long long)((unsigned long long)__builtin_amdgcn_readfirstlane(uint32_t(a0u)) |
+                                             ((unsigned long long)__builtin_amdgcn_readfirstlane(uint32_t(a0u >> 32)) << 32));
+            if (a0 >= 0 && size_t(a0) + 4 * size_t(RUNW) <= total_bytes) {
+#pragma unroll
+                for (int e = 0; e < DPT; ++e) {
+                    const uint32_t d = lane + 64 * e;
+                    if (d < uint32_t(RUNW)) __builtin_memcpy(&got[t][e], px + a0 + 4 * d, 4);  // (px itself may be unaligned)
+                }
+            } else {  // first / last run of the buffer: never a byte outside it, the partial dword comes from byte loads
+#pragma unroll
+                for (int e = 0; e < DPT; ++e) {
+                    const long long al = a0 + 4ll * (lane + 64 * e);
+                    if (al >= 0 && size_t(al) + 4 <= total_bytes) __builtin_memcpy(&got[t][e], px + al, 4);
+                    else if (al >= 0 && size_t(al) < total_bytes) got[t][e] = load_bytes_le(px + al, uint32_t(total_bytes - size_t(al)));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const uint32_t tt = wave + 4 * t;
+#pragma unroll
+        for (int e = 0; e < DPT; ++e) {
+            const uint32_t d = lane + 64 * e;
+            if (tt < ntiles && d < uint32_t(RUNW)) raw[tt][d] = got[t][e];
+        }
     }
     __syncthreads();
-    // this thread: pixels k0 + 8*q + i, i = 0..7, of tile tt, walking left to right so l and L come from registers
+    // this thread: pixels k0 + 8*q + i, i = 0..7, of tile tt.  Two pixels per register (packed 16-bit arithmetic: every
+    // value of the path fits -- samples 0..255, Co/Cg and L - l in [-255, 255], residuals in [-510, 510]); pair j of a
+    // channel holds pixels kb-2+2j and kb-1+2j, so the pair of current samples, of their left neighbours l and of their
+    // left-left neighbours L are registers j+1, (j, j+1) shifted by one sample, and j.
     const uint32_t q = threadIdx.x & 7;
+    const bool small = (g.flags & kGeoSmallModel) != 0;
     for (uint32_t tt = threadIdx.x >> 3; tt < ntiles; tt += 32) {  // one pass for 3 and 4 channels (<= 23 tiles)
         const uint32_t sw = tiles[tt].sw;
         const uint32_t kb = k0 + 8 * q;
-        if (kb < sw) {
-            const uint32_t skew = uint32_t(((long long)tiles[tt].base + (long long)(int(k0) - 2) * C) & 3);
-            const uint8_t* p = reinterpret_cast<const uint8_t*>(&raw[tt][0]) + skew + (8 * q + 2) * C;  // pixel kb
-            int l[C], L[C], cur[C];
-            if (kb > 0) rct_pixel<C>(p - C, l);  // llcomp.hpp:417
-            else {
+        if (kb >= sw) continue;
+        const uint32_t skew = uint32_t(((long long)tiles[tt].base + (long long)(int(k0) - 2) * C) & 3);
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(&raw[tt][0]) + skew + 8 * q * C;  // pixel kb - 2
+        s16x2 V[C][5];
 #pragma unroll
-                for (int ch = 0; ch < C; ++ch) l[ch] = 128;
+        for (int j = 0; j < 5; ++j) {
+            const uint8_t* a = p + 2 * j * C;
+            if constexpr (C >= 3) {  // llcomp.hpp:396-409: [r - g, g + (b - g + r - g) / 4 (truncating), b - g, extras]
+                const s16x2 R = {short(a[0]), short(a[C])}, G = {short(a[1]), short(a[C + 1])}, B = {short(a[2]), short(a[C + 2])};
+                const s16x2 cr = R - G, cb = B - G, sum = cb + cr;
+                V[0][j] = cr;
+                V[1][j] = G + ((sum + ((sum >> 15) & short(3))) >> 2);
+                V[2][j] = cb;
+                if constexpr (C == 4) V[3][j] = s16x2{short(a[3]), short(a[C + 3])};
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) V[ch][j] = s16x2{short(a[ch]), short(a[C + ch])};
             }
-            if (kb > 1) rct_pixel<C>(p - 2 * C, L);  // llcomp.hpp:419
-            else {
+        }
+        // slice start (llcomp.hpp:417-419): l of sample 0 is 128 and L = l for samples 0 and 1, i.e. L - l = 0 there
+        uint32_t first_mask = ~0u;
+        if (kb == 0) {
+            first_mask = 0;
 #pragma unroll
-                for (int ch = 0; ch < C; ++ch) L[ch] = l[ch];
-            }
-            // group-relative lane of this tile's channel 0 (negative / beyond gw: that plane is another group's)
-            const int col0 = int((first_tile + tt) * C) - int(first_id);
-            const uint32_t n = sw - kb < 8 ? sw - kb : 8;
-            const bool small = (g.flags & kGeoSmallModel) != 0;
-            for (uint32_t i = 0; i < n; ++i, p += C) {
-                rct_pixel<C>(p, cur);
-                const bool has_L = (kb + i) > 1;
+            for (int ch = 0; ch < C; ++ch) V[ch][0] = s16x2{128, 128};
+        }
+        if (small) first_mask = 0;  // LargeModel = false: no quant5 term at all, context 0 (handled below for all pairs)
+        // group-relative lane of this tile's channel 0, + PADL (never negative: see otile)
+        const uint32_t colp = uint32_t(int((first_tile + tt) * C) - int(first_id) + PADL);
 #pragma unroll
-                for (int ch = 0; ch < C; ++ch) {
-                    const int dq = (has_L && !small) ? L[ch] - l[ch] : 0;  // LargeModel = false: no quant5 term, context 0
-                    const uint32_t aq = uint32_t(dq < 0 ? -dq : dq);
-                    const uint32_t cidx = min(aq, 1u) + (aq > 3 ? 1u : 0u);  // |quant5(L - l)|: context 0 / 605 / 1210
-                    int res = cur[ch] - l[ch];
-                    if (dq < 0) res = -res;  // llcomp.hpp:433-436
-                    // 16-bit symbol of the fused path: bits 12..13 = |quant5|, bits 0..11 = residual
-                    const int col = col0 + ch;
-                    if (col >= 0 && col < int(gw)) otile[8 * q + i][col] = uint16_t((cidx << 12) | (uint32_t(res) & 0xFFF));
-                    L[ch] = l[ch];
-                    l[ch] = cur[ch];
-                }
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) {
+                const s16x2 cur = V[ch][m + 1], Lp = V[ch][m];
+                const s16x2 lp = {V[ch][m].y, V[ch][m + 1].x};  // left neighbours of the two current samples
+                s16x2 dq = Lp - lp;
+                uint32_t dqb = __builtin_bit_cast(uint32_t, dq) & ((m == 0 || small) ? first_mask : ~0u);
+                dq = __builtin_bit_cast(s16x2, dqb);
+                const s16x2 neg = dq >> 15;                          // hash = 605*quant5(L - l) < 0: llcomp.hpp:433-436
+                const u16x2 aq = __builtin_bit_cast(u16x2, (dq ^ neg) - neg);
+                const u16x2 one = {1, 1};
+                const u16x2 cidx = pk_min_u16(aq, one) + pk_min_u16(aq >> 2, one);  // |quant5|: 0 / 1 / 2
+                const s16x2 res = ((cur - lp) ^ neg) - neg;
+                // 16-bit symbol of the fused path: bits 12..13 = |quant5|, bits 0..11 = residual
+                const u16x2 sym = (__builtin_bit_cast(u16x2, res) & (unsigned short)0xFFF) + (cidx << 12);
+                otile[8 * q + 2 * m][colp + ch] = sym.x;
+                otile[8 * q + 2 * m + 1][colp + ch] = sym.y;
             }
         }
     }
@@ -672,12 +767,12 @@ __global__ __launch_bounds__(256) void k_model_rows_fwd(const Geometry g, const 
             const uint32_t kk = i >> 5, d = i & 31, k = k0 + kk;
             if (k < g.tile_w)
                 *reinterpret_cast<uint32_t*>(lanes + lane_order_index(g, first_id + 2 * d, k)) =
-                    *reinterpret_cast<const uint32_t*>(&otile[kk][2 * d]);
+                    *reinterpret_cast<const uint32_t*>(&otile[kk][PADL + 2 * d]);
         }
     } else {  // fewer than 64 slices in total: narrow group, plain element stores
         for (uint32_t i = threadIdx.x; i < uint32_t(K) * gw; i += 256) {
             const uint32_t kk = i / gw, col = i - kk * gw, k = k0 + kk;
-            if (k < g.tile_w && first_id + col < end_id) lanes[lane_order_index(g, first_id + col, k)] = otile[kk][col];
+            if (k < g.tile_w && first_id + col < end_id) lanes[lane_order_index(g, first_id + col, k)] = otile[kk][PADL + col];
         }
     }
 }
@@ -705,12 +800,21 @@ __global__ __launch_bounds__(256) void k_model_rows_inv(const Geometry g, const 
     load_row_tiles<C>(g, first_tile, ntiles, tiles);
     // LDS column = lane index relative to this group (0..gw-1), columns gw.. = first C-1 lanes of the NEXT group.
     // Rows of this group are read as whole 128-byte pieces (32 dwords = 64 samples); the few extra lanes one by one.
-    for (uint32_t i = threadIdx.x; i < uint32_t(K) * 32; i += 256) {
-        const uint32_t kk = i >> 5, d = i & 31, k = k0 + kk;
-        uint32_t w = 0;
-        if (k < g.tile_w && g.lane_shift == 6)
-            w = *reinterpret_cast<const uint32_t*>(lanes + lane_order_index(g, first_id + 2 * d, k));
-        *reinterpret_cast<uint32_t*>(&tile[kk][2 * d]) = w;
+    {   // (all eight loads of a thread are in flight before the first one is stored to LDS: the kernel is bound by the
+        // latency of its phases, one memory round trip per block instead of eight)
+        uint32_t w[K * 32 / 256];
+#pragma unroll
+        for (int it = 0; it < K * 32 / 256; ++it) {
+            const uint32_t i = threadIdx.x + 256 * it, kk = i >> 5, d = i & 31, k = k0 + kk;
+            w[it] = 0;
+            if (k < g.tile_w && g.lane_shift == 6)
+                w[it] = *reinterpret_cast<const uint32_t*>(lanes + lane_order_index(g, first_id + 2 * d, k));
+        }
+#pragma unroll
+        for (int it = 0; it < K * 32 / 256; ++it) {
+            const uint32_t i = threadIdx.x + 256 * it, kk = i >> 5, d = i & 31;
+            *reinterpret_cast<uint32_t*>(&tile[kk][2 * d]) = w[it];
+        }
     }
     if (g.lane_shift != 6) {  // fewer than 64 slices in total: narrow group, plain element loads
         __syncthreads();
