@@ -363,20 +363,26 @@ __global__ __launch_bounds__(256) void k_pack_payload(const Geometry g, const ui
     load_group_streams(g, group, slice_len, off, payload_cap, status, kStOverflow, gs);
     const uint32_t cap16 = g.slice_cap >> 4;
     const uint32_t a = threadIdx.x & 63, b = threadIdx.x >> 6;
-    for (uint32_t c0 = 0; c0 * 256 < gs.max_len; ++c0) {
-        uint4 v[4];  // 1 KiB rows of units; all four loads are in flight before the first is stored (see k_model_rows_inv)
+    // 1 KiB rows of units.  All four loads of a thread are in flight before the first is stored (see k_model_rows_inv),
+    // and the loads of the NEXT 256-byte chunk are issued before this chunk's stores: they fly during the store phase.
+    uint4 v[4];
+    auto request = [&](uint32_t c0) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const uint32_t u = c0 * 16 + b + 4 * t;
             v[t] = make_uint4(0, 0, 0, 0);
             if (u < cap16 && a < (1u << g.lane_shift)) v[t] = units[((size_t(group) * cap16 + u) << g.lane_shift) + a];
         }
+    };
+    if (gs.max_len) request(0);
+    for (uint32_t c0 = 0; c0 * 256 < gs.max_len; ++c0) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const uint32_t uu = b + 4 * t;
             tile[a][uu * 4 + 0] = v[t].x; tile[a][uu * 4 + 1] = v[t].y; tile[a][uu * 4 + 2] = v[t].z; tile[a][uu * 4 + 3] = v[t].w;
         }
         __syncthreads();
+        if ((c0 + 1) * 256 < gs.max_len) request(c0 + 1);
         for (uint32_t j = b; j < 64; j += 4) {  // 256-byte runs of one slice
             const uint32_t n = gs.len[j], p = c0 * 256 + a * 4;
             if (p < n) {
@@ -404,11 +410,12 @@ __global__ __launch_bounds__(256) void k_stage_streams(const Geometry g, const u
     load_group_streams(g, group, slice_len, off, payload_bytes, status, kStTruncated, gs);
     const uint32_t cap16 = g.slice_cap >> 4;
     const uint32_t a = threadIdx.x & 63, b = threadIdx.x >> 6;
-    // "+ 4": the dword right behind every stream is staged too (as zeros) -- the decoder clamps its reads to it
-    for (uint32_t c0 = 0; c0 * 256 < gs.max_len + 4; ++c0) {
-        // all sixteen loads of a thread are in flight before the first is stored.  The last, partial dword of a stream is
-        // read as a whole dword and masked wherever the payload has the bytes (always, except at its very end).
-        uint32_t w[16];
+    // "+ 4": the dword right behind every stream is staged too (as zeros) -- the decoder clamps its reads to it.
+    // All sixteen loads of a thread are in flight before the first is stored, and the loads of the NEXT chunk are issued
+    // before this chunk's stores.  The last, partial dword of a stream is read as a whole dword and masked wherever the
+    // payload has the bytes (always, except at its very end).
+    uint32_t w[16];
+    auto request = [&](uint32_t c0) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const uint32_t j = b + 4 * t, n = gs.len[j], p = c0 * 256 + a * 4;
@@ -420,6 +427,9 @@ __global__ __launch_bounds__(256) void k_stage_streams(const Geometry g, const u
                 else w[t] = load_bytes_le(src, n - p);
             }
         }
+    };
+    request(0);
+    for (uint32_t c0 = 0; c0 * 256 < gs.max_len + 4; ++c0) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {  // (the mask is applied here, not above: nothing waits for a load before all are issued)
             const uint32_t j = b + 4 * t, n = gs.len[j], p = c0 * 256 + a * 4;
@@ -427,6 +437,7 @@ __global__ __launch_bounds__(256) void k_stage_streams(const Geometry g, const u
             tile[j][a] = w[t] & keep;
         }
         __syncthreads();
+        if ((c0 + 1) * 256 < gs.max_len + 4) request(c0 + 1);
         for (uint32_t uu = b; uu < 16; uu += 4) {
             const uint32_t u = c0 * 16 + uu;
             if (u < cap16 && a < (1u << g.lane_shift))
