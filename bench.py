@@ -339,23 +339,34 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     for _ in range(max(3, warmup - 1)):  # at least three more untimed passes: torch's allocator pools still grow in them
         step()
     torch.cuda.synchronize()
+    # N = 1 only (an `also` leg there; at N > 1 this IS the timed headline and carries no instrumentation)
+    codecs = [sc.band.codec for sc in scs if getattr(sc.band, "codec", None) is not None] if world == 1 else []
+    for cd in codecs:  # hipEvent spans of the local coding kernels, so that a slow step can be told from a slow exchange
+        cd.set_profiling(True)
+        cd.get_profile()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks = []
     for _ in range(steps):
         conts, outs = step()
-        if os.environ.get("LLCOMP_BENCH_DEBUG"):
-            torch.cuda.synchronize()
-            marks.append(time.perf_counter())
+        marks.append(time.perf_counter())
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
+    spans = {}
+    for cd in codecs:
+        pr, _, _ = cd.get_profile()
+        cd.set_profiling(False)
+        for k_, v_ in pr.items():
+            spans[k_] = spans.get(k_, 0.0) + v_ / steps
+    c4_run.last_detail = {"kernel_ms_per_step": {k_: round(v_, 3) for k_, v_ in spans.items()},
+                          "step_ms": [round(1e3 * (b - a), 1) for a, b in zip([t0] + marks[:-1], marks)], "parts": halves}
     if os.environ.get("LLCOMP_BENCH_ALLOC") and rank == 0:
         st_ = torch.cuda.memory_stats()
         print("c4 allocator:", {k: st_.get(k) for k in ("num_alloc_retries", "num_device_alloc", "num_device_free", "reserved_bytes.all.peak", "allocated_bytes.all.peak")},
               "ms/step", round(1e3 * dt / steps, 1), file=sys.stderr, flush=True)
-    if marks and rank == 0:
+    if os.environ.get("LLCOMP_BENCH_DEBUG") and rank == 0:
         print("c4 step times (ms):", [round(1e3 * (b - a), 1) for a, b in zip([t0] + marks[:-1], marks)], "reserved GB", round(torch.cuda.memory_reserved() / 1e9, 1),
               "free GB", round(torch.cuda.mem_get_info()[0] / 1e9, 1), file=sys.stderr, flush=True)
     for k in range(halves):
@@ -559,7 +570,8 @@ def main():
             also["c4_sharded_one_gpu"] = {"value": round(args.c4_images * 8192 * 8192 * n4 / dt4 / 1e6, 1), "unit": "MPix/s",
                                           "ms_per_step": round(dt4 / n4 * 1e3, 3), "steps": n4, "images_per_step": args.c4_images,
                                           "compression_ratio": round(args.c4_images * 8192 * 8192 * 3 / pay4, 4),
-                                          "workload": f"C4 {args.c4_images} x 8192x8192 RGB8 uniform noise, {args.c4_tile_w}x{args.c4_tile_h} planar, the sharded code path on 1 GPU"}
+                                          "workload": f"C4 {args.c4_images} x 8192x8192 RGB8 uniform noise, {args.c4_tile_w}x{args.c4_tile_h} planar, the sharded code path on 1 GPU",
+                                          **getattr(c4_run, "last_detail", {})}
 
         def leg_contents():  # other contents at the default slicing (4 distinct frames, the rest rotations)
             for content in ("g2", "mid"):
