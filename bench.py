@@ -335,9 +335,12 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     if first is not None:
         one = mi.compress_image(first, size, size, 3, format=mi.FORMAT_SLICED, tile_w=tile_w, tile_h=tile_h, planar=True, device=local_rank)
         assert bytes(conts[0][0].cpu().numpy()) == one, "sharded container differs from the one-piece container"
-    del conts, outs
-    for _ in range(max(3, warmup - 1)):  # at least three more untimed passes: torch's allocator pools still grow in them
-        step()
+    # At least three more untimed passes, bound exactly like the timed ones (the results of pass i stay alive while pass
+    # i + 1 runs): that is when torch's allocator takes its last segments from the driver.  With the results dropped at
+    # once, the first such hipMalloc fell into the SECOND timed step instead -- 260 ms on a freshly provisioned box, one
+    # step of four at 340 ms beside three at 80 ms.
+    for _ in range(max(3, warmup - 1)):
+        conts, outs = step()
     torch.cuda.synchronize()
     # N = 1 only (an `also` leg there; at N > 1 this IS the timed headline and carries no instrumentation)
     codecs = [sc.band.codec for sc in scs if getattr(sc.band, "codec", None) is not None] if world == 1 else []
@@ -598,11 +601,11 @@ def main():
             also["legacy_streams_batched"] = brief(ml, workload="512 frames 256x256 RGB8 mid, one whole-image stream each (payload == reference stream), one GPU lane per stream")
             legacy_box["frame"] = leg[0].copy()
 
-        # The two big legs go first (BASELINE config 4 on one GPU = the N = 1 point of the strong-scaling curve, >100 GB of
-        # workspace; BASELINE config 5 through the streaming pipeline, PCIe inclusive), before the allocate / free cycles of
-        # the others fragment HBM (the same kernels then ran up to 2x slower: TLB reach).  A secondary leg that fails is
+        # The two big legs go first (BASELINE config 5 through the streaming pipeline, PCIe inclusive -- 3.9 instead of
+        # 4.8-5.2 GPix/s when its pinned buffers are allocated behind config 4's 150 GB; then BASELINE config 4 on one GPU =
+        # the N = 1 point of the strong-scaling curve), before the allocate / free cycles of the others fragment HBM.  A secondary leg that fails is
         # reported as such; it never costs the headline line.
-        for name, fn in (("c4", leg_c4), ("c5", leg_c5), ("contents", leg_contents), ("tiles", leg_tiles), ("latency", leg_latency), ("legacy", leg_legacy)):
+        for name, fn in (("c5", leg_c5), ("c4", leg_c4), ("contents", leg_contents), ("tiles", leg_tiles), ("latency", leg_latency), ("legacy", leg_legacy)):
             if not want(name):
                 continue
             try:
