@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised HIP-vs-oracle parity over shapes, contents, slicings and kernel-family overrides.  Collected by pytest
-(-m gpu) with a bounded number of cases; a longer run by hand on a GPU box:
+(-m gpu) with a bounded number of cases (72 general + 100 on the fused one-row path); a longer run by hand on a GPU box:
 
     python tests/test_gpu_stress.py [cases] [first seed]
 
@@ -99,6 +99,44 @@ def test_stress_parity(chunk):
         run_case(mi, orc, 1000 + chunk * 12 + i, check_legacy=(i % 6 == 0))
 
 
+ROW_WIDTHS = (1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 63, 64, 65, 66, 127, 129, 200, 257, 480, 500, 1000)
+ROW_TILES = (1, 2, 3, 7, 8, 9, 63, 64, 65, 128, 130)
+
+
+def run_rows_case(mi, orc, seed):
+    """The fused one-row path (planar, tile_h = 1: k_model_rows_fwd / _inv and the ROWS slice kernels) at the widths and
+    tile widths where its 8-pixel thread groups, 64-sample chunks, packed pixel pairs and byte-skewed staging have their
+    edges; a few rows, 1..4 channels, both model sizes."""
+    rng = np.random.default_rng(seed)
+    c = int(rng.integers(1, 5))
+    w = int(rng.choice(ROW_WIDTHS + (int(rng.integers(1, 1500)),)))
+    h = int(rng.integers(1, 40))
+    tw = int(rng.choice(ROW_TILES + (w, max(1, w // 2), int(rng.integers(1, w + 1)))))
+    img = make(rng, w, h, c, int(rng.integers(0, 4)))
+    small = bool(rng.random() < 0.15)
+    orc.set_small_model(small)
+    try:
+        want = orc.compress_sliced(img, tw, 1, True)
+        got = mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=1, planar=True, small_model=small)
+        assert got == want, f"rows case {seed}: container differs ({w}x{h}x{c} tile {tw}x1 small={small})"
+        assert np.array_equal(mi.decompress_image(got).pixels, img), f"rows case {seed}: round trip"
+    finally:
+        orc.set_small_model(False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", range(4))
+def test_rows_path_edges(chunk):
+    """100 random cases per run on the fused one-row path, byte-exact against the oracle and lossless."""
+    import llcomp_amd as mi
+    import orc as orc_mod
+
+    assert mi.device_count() >= 1, "GPU tests need a HIP device"
+    orc = orc_mod.Orc()
+    for i in range(25):
+        run_rows_case(mi, orc, 5000 + chunk * 25 + i)
+
+
 def main():
     import llcomp_amd as mi
     import orc as orc_mod
@@ -108,9 +146,10 @@ def main():
     orc = orc_mod.Orc()
     for i in range(cases):
         run_case(mi, orc, seed0 + i, check_legacy=(i % 7 == 0))
+        run_rows_case(mi, orc, seed0 + i)
         if i % 25 == 24:
             print(f"{i + 1} cases ok", flush=True)
-    print(f"stress parity: {cases} cases ok")
+    print(f"stress parity: {cases} cases ok (+ as many on the one-row path)")
 
 
 if __name__ == "__main__":
