@@ -366,7 +366,7 @@ class Codec:
     def close(self):
         if self._h:
             self._L.llcomp_mi_codec_destroy(self._h)
-            self._h = C.c_void_p()
+            self._h = None
 
     __del__ = close
 
