@@ -155,7 +155,7 @@ class Stream:
     def close(self):
         if self._h:
             self._L.llcomp_mi_stream_destroy(self._h)
-            self._h = C.c_void_p()
+            self._h = None
 
     __del__ = close
 
