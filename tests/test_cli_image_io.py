@@ -113,3 +113,143 @@ def test_pnm_and_rejections(probe, tmp_path):
     z[len(z) // 2] ^= 0x55  # damaged deflate data: an error or some picture, never a crash
     (tmp_path / "noise.png").write_bytes(bytes(z))
     assert subprocess.run([probe, str(tmp_path / "noise.png")], capture_output=True).returncode in (0, 1)
+
+
+# ---- every bit depth, Adam7 interlacing, BMP -------------------------------------------------------------------------
+ADAM7 = ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))
+
+
+def pack_rows(smp, depth, filters):
+    """smp: (h, w, c) integer samples at file depth -> filtered PNG scanlines (samples packed MSB first / big-endian)."""
+    h, w, c = smp.shape
+    if h == 0 or w == 0:
+        return b""
+    if depth == 16:
+        rows = np.stack([smp >> 8, smp & 0xFF], axis=-1).reshape(h, w * c * 2).astype(np.uint8)
+        fd = 2 * c
+    elif depth == 8:
+        rows = smp.reshape(h, w * c).astype(np.uint8)
+        fd = c
+    else:
+        bits = np.zeros((h, ((w * c * depth + 7) // 8) * 8), np.uint8)
+        flat = smp.reshape(h, w * c)
+        for b in range(depth):
+            bits[:, b:w * c * depth:depth] = (flat >> (depth - 1 - b)) & 1
+        rows = np.packbits(bits, axis=1)
+        fd = 1
+    return filtered_bytes(rows, fd, filters)
+
+
+def filtered_bytes(rows, fd, filters):
+    h, n = rows.shape
+    out = bytearray()
+    r = rows.astype(np.int32)
+    for y in range(h):
+        ft = filters[y % len(filters)]
+        cur, up = r[y], r[y - 1] if y else np.zeros(n, np.int32)
+        line = bytearray([ft])
+        for i in range(n):
+            a = cur[i - fd] if i >= fd else 0
+            b = up[i]
+            cc = up[i - fd] if i >= fd else 0
+            pred = [0, a, b, (a + b) >> 1, paeth(int(a), int(b), int(cc))][ft]
+            line.append((int(cur[i]) - int(pred)) & 0xFF)
+        out += line
+    return bytes(out)
+
+
+def make_png_any(smp, ctype, depth, interlace=False, filters=(0, 1, 2, 3, 4), extra=b""):
+    h, w, _ = smp.shape
+    if interlace:
+        data = b"".join(pack_rows(smp[y0::dy, x0::dx], depth, filters) for x0, y0, dx, dy in ADAM7)
+    else:
+        data = pack_rows(smp, depth, filters)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlace else 0)) + extra +
+            chunk(b"IDAT", zlib.compress(data, 6)) + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("interlace", [False, True])
+@pytest.mark.parametrize("ctype,c,depth", [(0, 1, 1), (0, 1, 2), (0, 1, 4), (0, 1, 8), (0, 1, 16), (2, 3, 8), (2, 3, 16), (4, 2, 8), (4, 2, 16),
+                                           (6, 4, 8), (6, 4, 16)])
+def test_png_every_depth_and_interlace(probe, tmp_path, ctype, c, depth, interlace):
+    rng = np.random.default_rng(ctype * 100 + depth + (1000 if interlace else 0))
+    for h, w in ((1, 1), (2, 3), (5, 9), (8, 8), (19, 23)):
+        smp = rng.integers(0, 1 << depth, size=(h, w, c)).astype(np.int64)
+        p = tmp_path / "d.png"
+        p.write_bytes(make_png_any(smp, ctype, depth, interlace))
+        want = (smp >> 8 if depth == 16 else smp * {1: 255, 2: 85, 4: 17, 8: 1}[depth]).astype(np.uint8)  # what stbi_load's 8-bit interface returns
+        assert np.array_equal(load(probe, p), want), (h, w)
+
+
+@pytest.mark.parametrize("interlace", [False, True])
+@pytest.mark.parametrize("depth", [1, 2, 4, 8])
+def test_png_palette_depths(probe, tmp_path, depth, interlace):
+    rng = np.random.default_rng(depth + (50 if interlace else 0))
+    n = 1 << depth
+    pal = rng.integers(0, 256, size=(min(n, 200), 3), dtype=np.uint8)
+    idx = rng.integers(0, len(pal), size=(13, 21, 1)).astype(np.int64)
+    p = tmp_path / "p.png"
+    p.write_bytes(make_png_any(idx, 3, depth, interlace, extra=chunk(b"PLTE", pal.tobytes())))
+    assert np.array_equal(load(probe, p), pal[idx[..., 0]])
+
+
+def test_png_colour_key_at_16_bits_and_low_depth(probe, tmp_path):
+    rng = np.random.default_rng(9)
+    smp = rng.integers(0, 4, size=(7, 9, 3)).astype(np.int64) * 0x4001  # few distinct 16-bit values
+    key = smp[3, 4]
+    p = tmp_path / "k.png"
+    p.write_bytes(make_png_any(smp, 2, 16, extra=chunk(b"tRNS", struct.pack(">HHH", *map(int, key)))))
+    got = load(probe, p)
+    assert got.shape == (7, 9, 4) and np.array_equal(got[..., :3], (smp >> 8).astype(np.uint8))
+    assert np.array_equal(got[..., 3] == 0, (smp == key).all(axis=2))
+    g = rng.integers(0, 4, size=(6, 10, 1)).astype(np.int64)
+    p.write_bytes(make_png_any(g, 0, 2, interlace=True, extra=chunk(b"tRNS", struct.pack(">H", 2))))
+    got = load(probe, p)
+    assert got.shape == (6, 10, 2) and np.array_equal(got[..., 0], (g[..., 0] * 85).astype(np.uint8))
+    assert np.array_equal(got[..., 1] == 0, g[..., 0] == 2)
+
+
+def make_bmp(img, bits, top_down=False, v4_alpha=False, pal=None):
+    h, w, c = img.shape
+    stride = ((w * bits + 31) // 32) * 4
+    rows = bytearray()
+    for y in (range(h) if top_down else range(h - 1, -1, -1)):
+        if bits == 8:
+            line = bytes(img[y, :, 0])
+        elif bits == 24:
+            line = img[y, :, ::-1].tobytes()  # BGR
+        else:
+            a = img[y, :, 3:4] if c == 4 else np.zeros((w, 1), np.uint8)
+            line = np.concatenate([img[y, :, 2::-1][:, :3], a], axis=1).astype(np.uint8).tobytes()  # BGRA
+        rows += line + bytes(stride - len(line))
+    hsz = 108 if v4_alpha else 40
+    palette = b"" if pal is None else b"".join(bytes([int(q[2]), int(q[1]), int(q[0]), 0]) for q in pal)
+    head = struct.pack("<IiiHHIIiiII", hsz, w, -h if top_down else h, 1, bits, 3 if v4_alpha else 0, len(rows), 2835, 2835, len(pal) if pal is not None else 0, 0)
+    if v4_alpha:
+        head += struct.pack("<IIII", 0x00FF0000, 0x0000FF00, 0x000000FF, 0xFF000000) + bytes(108 - 40 - 16)
+    off = 14 + len(head) + len(palette)
+    return b"BM" + struct.pack("<IHHI", off + len(rows), 0, 0, off) + head + palette + bytes(rows)
+
+
+def test_bmp_variants(probe, tmp_path):
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, size=(7, 5, 3), dtype=np.uint8)  # 5 pixels x 3 bytes: padded rows
+    p = tmp_path / "a.bmp"
+    for top_down in (False, True):
+        p.write_bytes(make_bmp(img, 24, top_down))
+        assert np.array_equal(load(probe, p), img)
+    p.write_bytes(make_bmp(img, 32))  # 32 bits without an alpha mask: three channels, like stb
+    assert np.array_equal(load(probe, p), img)
+    rgba = rng.integers(0, 256, size=(4, 6, 4), dtype=np.uint8)
+    p.write_bytes(make_bmp(rgba, 32, v4_alpha=True))
+    assert np.array_equal(load(probe, p), rgba)
+    pal = rng.integers(0, 256, size=(17, 3), dtype=np.uint8)
+    idx = rng.integers(0, 17, size=(9, 7, 1), dtype=np.uint8)
+    p.write_bytes(make_bmp(idx, 8, pal=pal))
+    assert np.array_equal(load(probe, p), pal[idx[..., 0]])
+    bad = bytearray(make_bmp(img, 24))
+    bad[30] = 1  # RLE8: refused, never misread
+    p.write_bytes(bytes(bad))
+    assert subprocess.run([probe, str(p)], capture_output=True).returncode == 1
+    p.write_bytes(make_bmp(img, 24)[:60])
+    assert subprocess.run([probe, str(p)], capture_output=True).returncode == 1

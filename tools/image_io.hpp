@@ -1,7 +1,7 @@
 // image_io.hpp -- the image file I/O the reference delegates to stb (not vendored, not installed, no network):
-// readers for binary PNM/PAM (P5 grey, P6 RGB, P7 with 1..4 channels, maxval 255) and for PNG (8 bits per channel,
-// grey / RGB / palette / alpha, non-interlaced; own inflate), and a writer for PNG with stored (uncompressed) deflate
-// blocks.  Plays the role of stbi_load (llcompc.cpp:25) / stbi_write_png (llcompd.cpp:29); it is host glue of the
+// readers for binary PNM/PAM (P5 grey, P6 RGB, P7 with 1..4 channels, maxval 255), for PNG (every colour type and bit
+// depth, Adam7 interlacing; own inflate) and for uncompressed BMP (8-bit palette, 24-bit, 32-bit with masks), and a writer
+// for PNG with stored (uncompressed) deflate blocks.  Plays the role of stbi_load (llcompc.cpp:25) / stbi_write_png (llcompd.cpp:29); it is host glue of the
 // CLIs, not part of the coding path.  Channel counts follow stb: grey 1, grey+alpha 2, RGB / palette 3, RGBA 4, and
 // a tRNS chunk adds the alpha channel.
 #pragma once
@@ -196,7 +196,10 @@ inline bool inflate_zlib(const std::vector<uint8_t>& z, std::vector<uint8_t>& ou
     return true;
 }
 
-// PNG, 8 bits per channel, non-interlaced.  Returns an empty string on success, else the failure reason.
+// PNG: every colour type at every bit depth the format allows (1/2/4/8/16), Adam7-interlaced or not.  Samples come out
+// as 8 bits per channel the way stbi_load (8-bit interface) hands them over: low bit depths of grey are scaled to
+// 0..255 (x255, x85, x17), 16-bit samples keep their high byte, palette indices are looked up.  Returns an empty string on
+// success, else the failure reason.
 inline std::string load_png(const std::string& path, std::vector<uint8_t>& px, int& w, int& h, int& c) {
     std::ifstream in(path, std::ios::binary);
     if (!in) return "can't fopen";
@@ -222,8 +225,6 @@ inline std::string load_png(const std::string& path, std::vector<uint8_t>& px, i
         o += 12 + size_t(n);
     }
     if (w <= 0 || h <= 0 || ctype < 0) return "no IHDR";
-    if (depth != 8) return "unsupported PNG bit depth (8 bits per channel only)";
-    if (interlace) return "interlaced PNG is not supported";
     int fc;  // channels in the file
     switch (ctype) {
         case 0: fc = 1; break;
@@ -233,48 +234,95 @@ inline std::string load_png(const std::string& path, std::vector<uint8_t>& px, i
         case 6: fc = 4; break;
         default: return "bad PNG colour type";
     }
+    // PNG spec table 11.1: grey 1/2/4/8/16, palette 1/2/4/8, everything else 8/16
+    const bool depth_ok = ctype == 0 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
+                        : ctype == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8) : (depth == 8 || depth == 16);
+    if (!depth_ok) return "bad PNG bit depth";
+    if (interlace > 1) return "bad PNG interlace method";
     if (ctype == 3 && plte.size() < 3) return "missing PLTE";
-    const size_t row = size_t(w) * fc;
     if (uint64_t(w) * uint64_t(h) * 4 >= (1ull << 31)) return "too large";
-    std::vector<uint8_t> raw;
-    if (!inflate_zlib(idat, raw, (row + 1) * size_t(h)) || raw.size() < (row + 1) * size_t(h)) return "bad zlib stream";
-    std::vector<uint8_t> img(row * size_t(h));
-    for (int y = 0; y < h; ++y) {  // undo the row filters (PNG spec 9.2)
-        const uint8_t* src = &raw[(row + 1) * size_t(y)];
-        uint8_t* cur = &img[row * size_t(y)];
-        const uint8_t* up = y ? cur - row : nullptr;
-        const int ft = src[0];
-        if (ft > 4) return "bad PNG filter";
-        for (size_t i = 0; i < row; ++i) {
-            const int a = i >= size_t(fc) ? cur[i - fc] : 0, b = up ? up[i] : 0, cc = (up && i >= size_t(fc)) ? up[i - fc] : 0;
-            int pred = 0;
-            if (ft == 1) pred = a;
-            else if (ft == 2) pred = b;
-            else if (ft == 3) pred = (a + b) >> 1;
-            else if (ft == 4) {
-                const int pp = a + b - cc, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - cc);
-                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : cc);
-            }
-            cur[i] = uint8_t(src[1 + i] + pred);
+    const int bpp = depth * fc;                       // bits per pixel in the file
+    const size_t fdist = size_t(bpp >= 8 ? bpp / 8 : 1);  // filter distance in bytes (PNG spec 9.2)
+    auto row_bytes = [&](int pw) { return (size_t(pw) * size_t(bpp) + 7) / 8; };
+    // the (sub)images in the stream: one, or the seven Adam7 passes
+    struct Pass { int x0, y0, dx, dy, pw, ph; };
+    std::vector<Pass> passes;
+    if (!interlace) passes.push_back({0, 0, 1, 1, w, h});
+    else {
+        static const int A[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+        for (auto& a : A) {
+            const int pw = (w - a[0] + a[2] - 1) / a[2], ph = (h - a[1] + a[3] - 1) / a[3];
+            if (pw > 0 && ph > 0) passes.push_back({a[0], a[1], a[2], a[3], pw, ph});
         }
     }
-    // to the channel layout stb would hand over
+    size_t need = 0;
+    for (auto& ps : passes) need += (row_bytes(ps.pw) + 1) * size_t(ps.ph);
+    std::vector<uint8_t> raw;
+    if (!inflate_zlib(idat, raw, need) || raw.size() < need) return "bad zlib stream";
+    // samples at file depth, one uint16 per sample, [y][x][fc]
+    std::vector<uint16_t> smp(size_t(w) * h * fc);
+    size_t at = 0;
+    std::vector<uint8_t> cur_row, up_row;
+    for (auto& ps : passes) {
+        const size_t row = row_bytes(ps.pw);
+        cur_row.assign(row, 0);
+        up_row.assign(row, 0);
+        for (int y = 0; y < ps.ph; ++y) {  // undo the row filters (PNG spec 9.2), then unpack the samples
+            const uint8_t* src = &raw[at];
+            at += row + 1;
+            const int ft = src[0];
+            if (ft > 4) return "bad PNG filter";
+            for (size_t i = 0; i < row; ++i) {
+                const int a = i >= fdist ? cur_row[i - fdist] : 0, b = up_row[i], cc = i >= fdist ? up_row[i - fdist] : 0;
+                int pred = 0;
+                if (ft == 1) pred = a;
+                else if (ft == 2) pred = b;
+                else if (ft == 3) pred = (a + b) >> 1;
+                else if (ft == 4) {
+                    const int pp = a + b - cc, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - cc);
+                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : cc);
+                }
+                cur_row[i] = uint8_t(src[1 + i] + pred);
+            }
+            const int oy = ps.y0 + y * ps.dy;
+            for (int x = 0; x < ps.pw; ++x) {
+                uint16_t* o = &smp[(size_t(oy) * w + size_t(ps.x0 + x * ps.dx)) * fc];
+                for (int k = 0; k < fc; ++k) {
+                    const size_t si = size_t(x) * fc + k;  // sample index in the row
+                    if (depth == 16) o[k] = uint16_t((cur_row[2 * si] << 8) | cur_row[2 * si + 1]);
+                    else if (depth == 8) o[k] = cur_row[si];
+                    else {  // 1, 2, 4 bits: leftmost sample in the high-order bits
+                        const size_t bit = si * size_t(depth);
+                        o[k] = uint16_t((cur_row[bit >> 3] >> (8 - depth - int(bit & 7))) & ((1 << depth) - 1));
+                    }
+                }
+            }
+            cur_row.swap(up_row);  // (the row just finished becomes "up"; cur is overwritten next)
+        }
+    }
+    // to the channel layout and sample range stb would hand over
     const bool pal = ctype == 3;
-    const bool key = !pal && !trns.empty() && (ctype == 0 || ctype == 2);
+    const bool key = !pal && (ctype == 0 || ctype == 2) && trns.size() >= size_t(2 * fc);
     c = pal ? (trns.empty() ? 3 : 4) : fc + (key ? 1 : 0);
     px.resize(size_t(w) * h * c);
     const size_t npx = size_t(w) * h;
+    const int scale = depth == 1 ? 255 : depth == 2 ? 85 : depth == 4 ? 17 : 1;  // grey below 8 bits
+    auto to8 = [&](uint16_t v) { return uint8_t(depth == 16 ? v >> 8 : depth == 8 ? v : v * scale); };
     for (size_t i = 0; i < npx; ++i) {
         uint8_t* o = &px[i * c];
+        const uint16_t* sp = &smp[i * fc];
         if (pal) {
-            const size_t idx = img[i];
+            const size_t idx = sp[0];
             for (int k = 0; k < 3; ++k) o[k] = idx * 3 + k < plte.size() ? plte[idx * 3 + k] : 0;
             if (c == 4) o[3] = idx < trns.size() ? trns[idx] : 255;
         } else {
-            for (int k = 0; k < fc; ++k) o[k] = img[i * fc + k];
-            if (key) {  // colour key: 16-bit samples in tRNS, the low byte counts at depth 8
-                bool same = trns.size() >= size_t(2 * fc);
-                for (int k = 0; same && k < fc; ++k) same = trns[2 * k + 1] == o[k];
+            for (int k = 0; k < fc; ++k) o[k] = to8(sp[k]);
+            if (key) {  // colour key: 16-bit big-endian values at file depth
+                bool same = true;
+                for (int k = 0; same && k < fc; ++k) {
+                    const uint16_t t = uint16_t((trns[2 * k] << 8) | trns[2 * k + 1]);
+                    same = depth == 16 ? t == sp[k] : (t & 0xFF) == sp[k];
+                }
                 o[fc] = same ? 0 : 255;
             }
         }
@@ -282,13 +330,81 @@ inline std::string load_png(const std::string& path, std::vector<uint8_t>& px, i
     return "";
 }
 
-// stbi_load's role: PNG or binary PNM/PAM by signature.
+// BMP (what stb_image reads of it most often): BITMAPINFOHEADER and later, uncompressed, 8-bit palette / 24-bit / 32-bit,
+// bottom-up or top-down; 32-bit files with BI_BITFIELDS masks (any 8-bit-aligned byte positions) carry alpha when the
+// header names an alpha mask.  Channels: 3, or 4 with alpha -- like stb.
+inline std::string load_bmp(const std::string& path, std::vector<uint8_t>& px, int& w, int& h, int& c) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return "can't fopen";
+    std::vector<uint8_t> f((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    auto le16 = [&](size_t o) { return uint32_t(f[o]) | (uint32_t(f[o + 1]) << 8); };
+    auto le32 = [&](size_t o) { return le16(o) | (le16(o + 2) << 16); };
+    if (f.size() < 54 || f[0] != 'B' || f[1] != 'M') return "not BMP";
+    const uint32_t off = le32(10), hsz = le32(14);
+    if (hsz < 40 || 14 + size_t(hsz) > f.size()) return "unsupported BMP header";
+    const int32_t bw = int32_t(le32(18)), bh = int32_t(le32(22));
+    const uint32_t planes = le16(26), bits = le16(28), comp = le32(30);
+    if (planes != 1 || bw <= 0 || bh == 0) return "bad BMP";
+    if (!(bits == 8 || bits == 24 || bits == 32)) return "unsupported BMP bit count";
+    if (!(comp == 0 || (comp == 3 && bits == 32))) return "compressed BMP is not supported";
+    w = bw;
+    h = bh < 0 ? -bh : bh;
+    if (uint64_t(w) * uint64_t(h) * 4 >= (1ull << 31)) return "too large";
+    uint32_t mask[4] = {0x00FF0000u, 0x0000FF00u, 0x000000FFu, 0};  // r, g, b, a of an uncompressed 32-bit pixel
+    if (comp == 3) {
+        const size_t mo = 14 + 40;  // masks follow the 40-byte header (they are part of the V4/V5 headers)
+        if (mo + 12 > f.size()) return "bad BMP";
+        for (int k = 0; k < 3; ++k) mask[k] = le32(mo + 4 * size_t(k));
+        if (hsz >= 56 && mo + 16 <= f.size()) mask[3] = le32(mo + 12);
+    } else if (bits == 32 && hsz >= 56) {
+        mask[3] = le32(14 + 40 + 12);
+    }
+    int shift[4];
+    for (int k = 0; k < 4; ++k) {
+        shift[k] = -1;
+        for (int sft = 0; sft < 32; sft += 8)
+            if (mask[k] == (0xFFu << sft)) shift[k] = sft;
+        if (k < 3 && bits == 32 && shift[k] < 0) return "unsupported BMP channel masks";
+    }
+    const bool alpha = bits == 32 && mask[3] != 0 && shift[3] >= 0;
+    c = alpha ? 4 : 3;
+    const size_t stride = ((size_t(w) * bits + 31) / 32) * 4;
+    if (size_t(off) + stride * size_t(h) > f.size()) return "truncated BMP";
+    const size_t pal_at = 14 + size_t(hsz);
+    uint32_t ncol = le32(46);
+    if (bits == 8) {
+        if (ncol == 0 || ncol > 256) ncol = 256;
+        if (pal_at + 4 * size_t(ncol) > f.size()) return "bad BMP palette";
+    }
+    px.resize(size_t(w) * h * c);
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* src = &f[off + stride * size_t(bh < 0 ? y : h - 1 - y)];
+        uint8_t* o = &px[size_t(y) * w * c];
+        for (int x = 0; x < w; ++x, o += c) {
+            if (bits == 8) {
+                const uint32_t idx = src[x];
+                const uint8_t* q = &f[pal_at + 4 * size_t(idx < ncol ? idx : 0)];
+                o[0] = q[2]; o[1] = q[1]; o[2] = q[0];
+            } else if (bits == 24) {
+                o[0] = src[3 * x + 2]; o[1] = src[3 * x + 1]; o[2] = src[3 * x];
+            } else {
+                const uint32_t v = uint32_t(src[4 * x]) | (uint32_t(src[4 * x + 1]) << 8) | (uint32_t(src[4 * x + 2]) << 16) | (uint32_t(src[4 * x + 3]) << 24);
+                for (int k = 0; k < c; ++k) o[k] = uint8_t(v >> shift[k]);
+            }
+        }
+    }
+    return "";
+}
+
+// stbi_load's role: PNG, BMP or binary PNM/PAM by signature.
 inline std::string load_image(const std::string& path, std::vector<uint8_t>& px, int& w, int& h, int& c) {
     std::ifstream in(path, std::ios::binary);
     if (!in) return "can't fopen";
-    const int first = in.get();
+    const int first = in.get(), second = in.get();
     in.close();
-    return first == 0x89 ? load_png(path, px, w, h, c) : load_pnm(path, px, w, h, c);
+    if (first == 0x89) return load_png(path, px, w, h, c);
+    if (first == 'B' && second == 'M') return load_bmp(path, px, w, h, c);
+    return load_pnm(path, px, w, h, c);
 }
 
 inline uint32_t crc32(const uint8_t* p, size_t n, uint32_t crc = 0) {
