@@ -243,29 +243,56 @@ def profile_numbers(F, tile_w, tile_h, planar, content, S, dom):
     return None, None, None
 
 
-def c5_stream(frames_np, tile_w, tile_h, planar, depth=8, frames_per_job=4):
+def c5_stream(frames_np, tile_w, tile_h, planar, depth=8, frames_per_job=4, pipelines=2, encodes_in_flight=3, passes=4):
     """BASELINE config 5, PCIe inclusive: the frames stream host -> GPU -> host (container) -> GPU -> host through the
-    product's pipeline (llcomp_mi_stream_*, jobs of `frames_per_job` frames), twice over the batch; every frame verified
-    bit-exact."""
+    product's pipeline (llcomp_mi_stream_*, jobs of `frames_per_job` frames), `passes` times over the batch; every frame verified
+    bit-exact.  `pipelines` stream objects, each driven by its own thread over its own share of the frames: one pipeline
+    hands its results back in submission order and leaves the two DMA directions idle now and then (4.6 GPix/s; two
+    pipelines 6.0, two processes on one GPU 6.9 -- tools/c5_sweep.py)."""
+    import threading
+
     import llcomp_amd as mi
 
     F, h, w, c = frames_np.shape
-    F -= F % frames_per_job
+    per = (F // pipelines) // frames_per_job * frames_per_job  # frames per pipeline
+    assert per >= 4, "too few frames for this many pipelines"
+    F = per * pipelines
     pinned = mi.PinnedBuffer(F * h * w * c)
     pinned.array[:] = frames_np[:F].reshape(-1)
     views = [pinned.array[i * h * w * c:(i + 1) * h * w * c].reshape(h, w, c) for i in range(F)]
-    st = mi.Stream(w, h, c, tile_w, tile_h, planar, depth=depth, frames_per_job=frames_per_job)
-    jobs = views + views
-    lens, done_at, busy = mi.pipeline_roundtrip(st, jobs, max_encodes_in_flight=3, verify=True, verify_threads=6)
-    st.close()
-    n = len(jobs)
-    skip = max(4, frames_per_job)  # the first 4 frames = the first job
-    steady = (n - skip) * w * h / 1e6 / (done_at[-1] - done_at[skip - 1])
+    sts = [mi.Stream(w, h, c, tile_w, tile_h, planar, depth=depth, frames_per_job=frames_per_job) for _ in range(pipelines)]
+    res, errs = [None] * pipelines, []
+    origin = time.perf_counter()
+
+    def drive(t):
+        try:
+            mine = views[t * per:(t + 1) * per]  # (the frames of a job must be adjacent in memory)
+            res[t] = mi.pipeline_roundtrip(sts[t], mine * passes, max_encodes_in_flight=encodes_in_flight, verify=True,
+                                           verify_threads=max(2, 6 // pipelines), clock_origin=origin)
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    threads = [threading.Thread(target=drive, args=(t,)) for t in range(pipelines)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for st in sts:
+        st.close()
     pinned.close()
-    return {"value": round(steady, 1), "unit": "MPix/s", "frames": n, "frames_per_job": frames_per_job, "depth": depth,
-            "compression_ratio": round(n * h * w * c / sum(lens), 4),
-            "pcie_bytes_per_frame": int(2 * (h * w * c + sum(lens) / n)), "backpressure_hits": busy,
-            "note": "end to end over PCIe from/to pinned host memory, steady state (first 4 frames excluded), every frame bit-exact; never part of `value`"}
+    if errs:
+        raise errs[0]
+    n = passes * F
+    skip = max(4, frames_per_job)  # every pipeline's first 4 frames = its first job are left out
+    begin = max(r[1][skip - 1] for r in res)   # the moment the last pipeline has its first job back
+    end = max(r[1][-1] for r in res)
+    counted = sum(sum(1 for t in r[1] if t > begin) for r in res)
+    steady = counted * w * h / 1e6 / (end - begin)
+    total_len = sum(sum(r[0]) for r in res)
+    return {"value": round(steady, 1), "unit": "MPix/s", "frames": n, "frames_per_job": frames_per_job, "depth": depth, "pipelines": pipelines,
+            "compression_ratio": round(n * h * w * c / total_len, 4),
+            "pcie_bytes_per_frame": int(2 * (h * w * c + total_len / n)), "backpressure_hits": sum(r[2] for r in res),
+            "note": "end to end over PCIe from/to pinned host memory, steady state (every pipeline's first 4 frames excluded), every frame bit-exact; never part of `value`"}
 
 
 def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank, check_one_piece=True, parts=0):
@@ -457,6 +484,19 @@ def main():
                     local_rank, barrier=barrier)
         t = torch.tensor([m["dt"]], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # third key: BASELINE config 5 in replica mode: every rank streams its own share of the 64 frames
+        # host -> GPU -> host -> GPU -> host through llcomp_mi_stream_* over its own PCIe link, all ranks at the same time.
+        # A rank whose leg fails still takes part in the reductions (nobody is left waiting) and the key says so.
+        c5 = {"value": 0.0}
+        ok = 1.0
+        try:
+            dist.barrier()
+            c5 = c5_stream(make_frames(args.content, max(16, 64 // world), rank, distinct=8), args.tile_w, args.tile_h, planar)
+        except Exception as e:  # noqa: BLE001
+            ok = 0.0
+            print(f"bench: rank {rank}: config-5 replica leg failed: {e!r}", file=sys.stderr, flush=True)
+        v5 = torch.tensor([c5["value"], ok], dtype=torch.float64, device="cuda")
+        dist.all_reduce(v5, op=dist.ReduceOp.SUM)
         if rank == 0:
             value = B * size * size * args.steps / dt / 1e6
             raw = B * size * size * 3
@@ -481,6 +521,10 @@ def main():
                              "traffic": None, "note": "algorithmic bytes of encode + decode over the whole job / wall time; the per-kernel roofline is in the N=1 line"},
                 "replica": brief(dict(m, dt=float(t.item()), mpix=world * m["F"] * W4K * H4K * m["steps"] / float(t.item()) / 1e6), scaling="weak",
                                  workload=f"C3 {F} frames/step/GPU, frames sharded over {world} GPUs, no data-path collective"),
+                "c5_replica_pcie": {"value": round(float(v5[0].item()), 1), "unit": "MPix/s", "ranks_ok": int(round(float(v5[1].item()))), "scaling": "weak",
+                                    "frames_per_rank": 4 * max(16, 64 // world), "rank0": c5,
+                                    "workload": f"C5: every rank streams its own {max(16, 64 // world)} 4K frames (four passes) host -> GPU -> host -> GPU -> host "
+                                                f"through llcomp_mi_stream_*, all {world} ranks at once; sum of the ranks' steady-state rates, PCIe inclusive"},
             }
             print(json.dumps(res), flush=True)
         dist.destroy_process_group()

@@ -218,7 +218,7 @@ def _same_bytes(a, b):
     return bool(np.array_equal(a, b))
 
 
-def pipeline_roundtrip(stream, frames, max_encodes_in_flight=3, on_container=None, verify=True, verify_threads=4):
+def pipeline_roundtrip(stream, frames, max_encodes_in_flight=3, on_container=None, verify=True, verify_threads=4, clock_origin=None):
     """Drives BASELINE config 5 through a Stream: every frame host -> GPU -> host (container) -> GPU -> host.  An encode
     result (pinned containers) is handed to submit_decode as it is and released only when that decode has come back;
     submit_* returning False (back-pressure) makes the loop take a finished job first.  frames: list of C-contiguous
@@ -226,7 +226,8 @@ def pipeline_roundtrip(stream, frames, max_encodes_in_flight=3, on_container=Non
     of one buffer) and len(frames) a multiple of it.  Returns (container lengths, completion time of every frame in
     seconds, number of times back-pressure was hit).  on_container(i, bytes_view) sees every container; verify compares
     every decoded frame with its source bit for bit -- on a few worker threads (numpy releases the GIL), the slot is
-    released afterwards."""
+    released afterwards.  clock_origin: a time.perf_counter() value the completion times are measured from (several
+    pipelines driven from several threads share one; default: this call's start)."""
     import time
     from concurrent.futures import ThreadPoolExecutor
 
@@ -258,7 +259,7 @@ def pipeline_roundtrip(stream, frames, max_encodes_in_flight=3, on_container=Non
             finished += 1
             block = False
 
-    t0 = time.perf_counter()
+    t0 = time.perf_counter() if clock_origin is None else clock_origin
     try:
         while finished < n_jobs:
             progressed = False

@@ -1,14 +1,17 @@
-import sys, time, numpy as np
-sys.path.insert(0, '.')
-import bench, llcomp_amd as mi
-frames = bench.make_frames("g3", 32, 0)
-F,h,w,c = frames.shape
-pinned = mi.PinnedBuffer(frames.size); pinned.array[:] = frames.reshape(-1)
-views = [pinned.array[i*h*w*c:(i+1)*h*w*c].reshape(h,w,c) for i in range(F)]
-for depth, inflight, vt, verify in ((8,3,4,True),(8,3,4,False),(12,4,4,True),(12,5,6,True),(16,6,6,True),(16,6,6,False),(6,2,4,True)):
-    st = mi.Stream(w,h,c,480,1,True,depth=depth)
-    jobs = views+views
-    lens, done, busy = mi.pipeline_roundtrip(st, jobs, max_encodes_in_flight=inflight, verify=verify, verify_threads=vt)
-    st.close()
-    n=len(jobs)
-    print(f"depth {depth} inflight {inflight} threads {vt} verify {verify}: {(n-4)*w*h/1e6/(done[-1]-done[3]):.0f} MPix/s busy {busy}", flush=True)
+#!/usr/bin/env python3
+"""BASELINE config 5 (128 noise frames of 4K host -> GPU -> host -> GPU -> host through llcomp_mi_stream_*): sweep of the
+number of pipelines (stream objects, a driving thread each), slots, frames per job and encodes in flight.  bench.py's
+c5 leg is one line of this table.     python tools/c5_sweep.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+
+frames = bench.make_frames("g3", 32, 0, distinct=8)
+for pipelines, depth, fpj, enc in ((1, 8, 4, 3), (1, 12, 4, 4), (2, 6, 4, 2), (2, 8, 4, 3), (2, 12, 4, 4), (2, 8, 2, 3), (3, 6, 4, 2), (4, 4, 4, 2), (4, 6, 4, 2)):
+    try:
+        r = bench.c5_stream(frames, 480, 1, True, depth=depth, frames_per_job=fpj, pipelines=pipelines, encodes_in_flight=enc)
+        print(f"pipelines {pipelines} depth {depth} frames/job {fpj} encodes in flight {enc}: {r['value']:.0f} MPix/s steady, back-pressure {r['backpressure_hits']}", flush=True)
+    except AssertionError as e:
+        print(f"pipelines {pipelines} depth {depth} frames/job {fpj}: skipped ({e})", flush=True)
