@@ -51,6 +51,35 @@ def test_stream_small_frames_match_oracle(mi, orc):
         assert busy > 0, "11 frames through 3 slots must have hit back-pressure"
 
 
+def test_two_pipelines_on_two_threads_match_oracle(mi, orc):
+    """bench.py's config-5 leg drives two stream objects from two threads (the library is re-entrant: private HIP streams,
+    a mutex around the lane and device-memory caches); every container of both must equal the oracle's."""
+    import threading
+
+    rng = np.random.default_rng(21)
+    sets = [[rng.integers(0, 256, size=(60, 200, 3), dtype=np.uint8) for _ in range(12)],
+            [make_image("mid", 131, 77, 3) + np.uint8(i) for i in range(12)]]
+    slicing = [(64, 1, True), (32, 16, False)]
+    want = [[orc.compress_sliced(f, *slicing[t]) for f in sets[t]] for t in range(2)]
+    errs = []
+
+    def drive(t):
+        try:
+            def check(i, data):
+                assert data.tobytes() == want[t][i], f"pipeline {t}, frame {i}: container differs from the oracle's"
+
+            run_stream(mi, sets[t], *slicing[t], depth=3, max_encodes_in_flight=2, check=check)
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=drive, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+
+
 @pytest.mark.parametrize("fpj", [2, 3])
 def test_stream_jobs_of_several_frames_match_oracle(mi, orc, fpj):
     """frames_per_job > 1: one launch set and two copies per frame instead of a whole pipeline pass per frame; every
