@@ -224,7 +224,8 @@ def test_cpp_stream_driver(mi):
     exe = os.path.join(ROOT, "tools", "llcomp_stream")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")])
-    for args in (["12", "300", "200", "50", "1", "3", "2", "1"], ["12", "300", "200", "64", "16", "3", "2", "3"], ["8", "3840", "2160", "480", "1", "4", "2", "2"]):
+    for args in (["12", "300", "200", "50", "1", "3", "2", "1"], ["12", "300", "200", "64", "16", "3", "2", "3"], ["8", "3840", "2160", "480", "1", "4", "2", "2"],
+                 ["24", "300", "200", "64", "1", "3", "2", "2", "2"]):  # (the last: two pipelines on two threads)
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         out = json.loads(r.stdout.strip().splitlines()[-1])

@@ -1,11 +1,13 @@
-// llcomp_stream [frames] [width] [height] [tile_w] [tile_h] [depth] [encodes_in_flight] [frames_per_job]
+// llcomp_stream [frames] [width] [height] [tile_w] [tile_h] [depth] [encodes_in_flight] [frames_per_job] [pipelines]
 //
 // BASELINE config 5 driven from C++ through the C ABI alone (include/llcomp_mi.h, llcomp_mi_stream_*): `frames` distinct
 // RGB8 noise frames stream host -> GPU -> host (SLICED container) -> GPU -> host with `depth` pipeline slots; every decoded
 // frame is compared with its source (memcmp on worker threads); prints one JSON line with the steady-state rate (first 4
-// frames excluded) and the compression ratio.  The reference's counterpart is a loop of llcompc / llcompd runs, one image
-// per process (llcompc.cpp:25-41, llcompd.cpp:17-31).  This is also the example INTEGRATION.md points at for the pipeline:
-// pinned source buffers, back-pressure (LLCOMP_MI_BUSY), an encode result handed to submit_decode as it is.
+// frames of every pipeline excluded) and the compression ratio.  The reference's counterpart is a loop of llcompc / llcompd
+// runs, one image per process (llcompc.cpp:25-41, llcompd.cpp:17-31).  This is also the example INTEGRATION.md points at for
+// the pipeline: pinned source buffers, back-pressure (LLCOMP_MI_BUSY), an encode result handed to submit_decode as it is,
+// and `pipelines` stream objects driven by a thread each (one pipeline returns its results in submission order and leaves
+// a DMA direction idle now and then; two keep both busy).
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -34,38 +36,32 @@ void fill_noise(uint8_t* p, size_t n, uint64_t seed) {  // xorshift64*: incompre
     for (; i < n; ++i) p[i] = uint8_t(x >> (8 * (i & 7)));
 }
 
-struct Check {  // a decoded frame waiting for its comparison; the slot is released by the main thread afterwards
+struct Check {  // a decoded frame waiting for its comparison; the slot is released by the driving thread afterwards
     uint32_t slot;
     uint64_t tag;
     const uint8_t* got;
 };
 
-}  // namespace
+struct Config {
+    uint32_t w, h, c, tw, th, depth, max_enc, fpj;
+};
 
-int main(int argc, char** argv) {
-    uint32_t n = argc > 1 ? uint32_t(std::atoi(argv[1])) : 64;
-    const uint32_t w = argc > 2 ? uint32_t(std::atoi(argv[2])) : 3840, h = argc > 3 ? uint32_t(std::atoi(argv[3])) : 2160, c = 3;
-    const uint32_t tw = argc > 4 ? uint32_t(std::atoi(argv[4])) : 480, th = argc > 5 ? uint32_t(std::atoi(argv[5])) : 1;
-    const uint32_t depth = argc > 6 ? uint32_t(std::atoi(argv[6])) : 16, max_enc = argc > 7 ? uint32_t(std::atoi(argv[7])) : 6;
-    const uint32_t fpj = argc > 8 ? uint32_t(std::atoi(argv[8])) : 1;  // frames per job
-    const size_t raw1 = size_t(w) * h * c;
-    if (!n || !raw1 || !fpj || n % fpj) return 1;
-    const uint32_t frames_total = n;
-    n /= fpj;                       // from here on: jobs
-    const size_t raw = raw1 * fpj;  // bytes of one job's frames
+struct Outcome {
+    int fail = 0;
+    bool mismatch = false;
+    uint64_t container_bytes = 0;
+    uint32_t busy = 0;
+    std::vector<double> done_at;  // completion time of every job, seconds since `origin`
+};
 
+// one pipeline: `n` jobs of cfg.fpj frames each, sources at src + raw * job
+void drive(const Config& cfg, const uint8_t* src, uint32_t n, size_t raw, double origin, Outcome& out) {
     llcomp_mi_stream* st = nullptr;
-    if (int rc = llcomp_mi_stream_create_ex(&st, -1, w, h, c, tw, th, 1, depth, fpj)) {
+    if (int rc = llcomp_mi_stream_create_ex(&st, -1, cfg.w, cfg.h, cfg.c, cfg.tw, cfg.th, 1, cfg.depth, cfg.fpj)) {
         std::fprintf(stderr, "llcomp_mi_stream_create: %s\n", llcomp_mi_strerror(rc));
-        return 1;
+        out.fail = rc;
+        return;
     }
-    uint8_t* src = static_cast<uint8_t*>(llcomp_mi_host_alloc(raw * n));  // pinned: the H2D copies are plain DMA
-    if (!src) {
-        std::fprintf(stderr, "llcomp_mi_host_alloc failed\n");
-        return 1;
-    }
-    for (uint32_t i = 0; i < n; ++i) fill_noise(src + raw * i, raw, 1234 + i);
-
     // comparison workers
     std::mutex mu;
     std::condition_variable cv;
@@ -89,13 +85,12 @@ int main(int argc, char** argv) {
             }
         });
 
-    std::vector<double> done_at(n, 0.0);
+    out.done_at.assign(n, 0.0);
     std::vector<llcomp_mi_stream_result> enc_held(n);  // encode results whose containers a decode job still reads
     std::deque<llcomp_mi_stream_result> to_decode;
-    uint64_t container_bytes = 0;
-    uint32_t next = 0, finished = 0, enc_in_flight = 0, busy = 0;
+    uint32_t next = 0, finished = 0, enc_in_flight = 0;
     int fail = 0;
-    const double t0 = now();
+    const uint32_t fpj = cfg.fpj;
     while (finished < n && !fail) {
         bool progressed = false;
         {  // frames whose comparison is done: give their slots back
@@ -118,15 +113,15 @@ int main(int argc, char** argv) {
             }
             if (fail) break;
             const int rc = llcomp_mi_stream_submit_decode_batch(st, ptrs.data(), lens.data(), r.tag);
-            if (rc == LLCOMP_MI_BUSY) { ++busy; break; }
+            if (rc == LLCOMP_MI_BUSY) { ++out.busy; break; }
             if (rc) { fail = rc; break; }
             enc_held[r.tag] = r;
             to_decode.pop_front();
             progressed = true;
         }
-        while (!fail && next < n && enc_in_flight < max_enc && to_decode.empty()) {
+        while (!fail && next < n && enc_in_flight < cfg.max_enc && to_decode.empty()) {
             const int rc = llcomp_mi_stream_submit_encode(st, src + raw * next, next);
-            if (rc == LLCOMP_MI_BUSY) { ++busy; break; }
+            if (rc == LLCOMP_MI_BUSY) { ++out.busy; break; }
             if (rc) { fail = rc; break; }
             ++next;
             ++enc_in_flight;
@@ -139,10 +134,10 @@ int main(int argc, char** argv) {
             if (r.status) { fail = r.status; break; }
             if (r.kind == LLCOMP_MI_JOB_ENCODE) {
                 --enc_in_flight;
-                container_bytes += r.len;
+                out.container_bytes += r.len;
                 to_decode.push_back(r);
             } else {
-                done_at[r.tag] = now() - t0;
+                out.done_at[r.tag] = now() - origin;
                 llcomp_mi_stream_release(st, enc_held[r.tag].slot);
                 std::lock_guard<std::mutex> lock(mu);
                 todo.push_back({r.slot, r.tag, r.data});
@@ -156,15 +151,67 @@ int main(int argc, char** argv) {
     cv.notify_all();
     for (auto& t : workers) t.join();
     llcomp_mi_stream_destroy(st);
-    llcomp_mi_host_free(src);
-    if (fail || mismatch) {
-        std::fprintf(stderr, "llcomp_stream: %s\n", fail ? llcomp_mi_strerror(fail) : "a decoded frame differs from its source");
+    out.fail = fail;
+    out.mismatch = mismatch;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    const uint32_t frames_total = argc > 1 ? uint32_t(std::atoi(argv[1])) : 64;
+    Config cfg;
+    cfg.w = argc > 2 ? uint32_t(std::atoi(argv[2])) : 3840;
+    cfg.h = argc > 3 ? uint32_t(std::atoi(argv[3])) : 2160;
+    cfg.c = 3;
+    cfg.tw = argc > 4 ? uint32_t(std::atoi(argv[4])) : 480;
+    cfg.th = argc > 5 ? uint32_t(std::atoi(argv[5])) : 1;
+    cfg.depth = argc > 6 ? uint32_t(std::atoi(argv[6])) : 8;
+    cfg.max_enc = argc > 7 ? uint32_t(std::atoi(argv[7])) : 3;
+    cfg.fpj = argc > 8 ? uint32_t(std::atoi(argv[8])) : 1;
+    const uint32_t pipelines = argc > 9 ? uint32_t(std::atoi(argv[9])) : 1;
+    const size_t raw1 = size_t(cfg.w) * cfg.h * cfg.c;
+    if (!frames_total || !raw1 || !cfg.fpj || !pipelines || frames_total % (cfg.fpj * pipelines)) return 1;
+    const uint32_t jobs = frames_total / cfg.fpj, per = jobs / pipelines;  // jobs in all, jobs per pipeline
+    const size_t raw = raw1 * cfg.fpj;                                     // bytes of one job's frames
+
+    uint8_t* src = static_cast<uint8_t*>(llcomp_mi_host_alloc(raw * jobs));  // pinned: the H2D copies are plain DMA
+    if (!src) {
+        std::fprintf(stderr, "llcomp_mi_host_alloc failed\n");
         return 1;
     }
-    const uint32_t skip = n * fpj > 8 ? (4 + fpj - 1) / fpj : 0;  // jobs that hold the first 4 frames
-    const double steady = double(n - skip) * fpj * w * h / 1e6 / (done_at[n - 1] - (skip ? done_at[skip - 1] : 0.0));
-    std::printf("{\"frames\": %u, \"frames_per_job\": %u, \"width\": %u, \"height\": %u, \"tile\": \"%ux%u\", \"depth\": %u, \"steady_mpix_s\": %.1f, "
-                "\"compression_ratio\": %.4f, \"backpressure_hits\": %u, \"verified\": true}\n",
-                frames_total, fpj, w, h, tw, th, depth, steady, double(raw) * n / double(container_bytes), busy);
+    for (uint32_t i = 0; i < jobs; ++i) fill_noise(src + raw * i, raw, 1234 + i);
+
+    std::vector<Outcome> outs(pipelines);
+    std::vector<std::thread> drivers;
+    const double origin = now();
+    for (uint32_t p = 0; p < pipelines; ++p)
+        drivers.emplace_back([&, p] { drive(cfg, src + raw * per * p, per, raw, origin, outs[p]); });
+    for (auto& t : drivers) t.join();
+    llcomp_mi_host_free(src);
+
+    uint64_t container_bytes = 0;
+    uint32_t busy = 0;
+    for (auto& o : outs) {
+        if (o.fail || o.mismatch) {
+            std::fprintf(stderr, "llcomp_stream: %s\n", o.fail ? llcomp_mi_strerror(o.fail) : "a decoded frame differs from its source");
+            return 1;
+        }
+        container_bytes += o.container_bytes;
+        busy += o.busy;
+    }
+    // steady state: from the moment the last pipeline has the jobs that hold its first 4 frames back, to the end
+    const uint32_t skip = per * cfg.fpj > 8 ? (4 + cfg.fpj - 1) / cfg.fpj : 0;
+    double begin = 0.0, end = 0.0;
+    for (auto& o : outs) {
+        if (skip) begin = std::max(begin, o.done_at[skip - 1]);
+        end = std::max(end, o.done_at[per - 1]);
+    }
+    uint32_t counted = 0;
+    for (auto& o : outs)
+        for (double t : o.done_at) counted += t > begin;
+    const double steady = double(counted) * cfg.fpj * cfg.w * cfg.h / 1e6 / (end - begin);
+    std::printf("{\"frames\": %u, \"frames_per_job\": %u, \"pipelines\": %u, \"width\": %u, \"height\": %u, \"tile\": \"%ux%u\", \"depth\": %u, "
+                "\"steady_mpix_s\": %.1f, \"compression_ratio\": %.4f, \"backpressure_hits\": %u, \"verified\": true}\n",
+                frames_total, cfg.fpj, pipelines, cfg.w, cfg.h, cfg.tw, cfg.th, cfg.depth, steady, double(raw) * jobs / double(container_bytes), busy);
     return 0;
 }
