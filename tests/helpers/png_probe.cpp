@@ -1,4 +1,5 @@
-// Test helper: loads an image with the CLIs' reader (tools/image_io.hpp) and writes "w h c\n" + raw pixels to stdout.
+// Test helper: loads an image with the CLIs' reader (tools/image_io.hpp) and writes "w h c\n" + raw pixels to stdout;
+// with a second argument it writes the image back as PNG with the CLIs' writer instead.
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -14,6 +15,7 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "%s\n", why.c_str());
         return 1;
     }
+    if (argc > 2) return image_io::write_png(argv[2], w, h, c, px.data(), w * c) ? 0 : 3;  // re-encode with the CLIs' writer
     std::printf("%d %d %d\n", w, h, c);
     std::fwrite(px.data(), 1, px.size(), stdout);
     return 0;

@@ -253,3 +253,56 @@ def test_bmp_variants(probe, tmp_path):
     assert subprocess.run([probe, str(p)], capture_output=True).returncode == 1
     p.write_bytes(make_bmp(img, 24)[:60])
     assert subprocess.run([probe, str(p)], capture_output=True).returncode == 1
+
+
+# ---- the PNG writer (llcompd's output): adaptive filters + own deflate, read back by zlib ------------------------------
+def decode_png_py(data):
+    """minimal PNG decoder (8-bit, non-interlaced) on Python's zlib: what any other PNG reader would see"""
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    o, idat, hdr = 8, b"", None
+    while o < len(data):
+        n, t = struct.unpack(">I4s", data[o:o + 8])
+        body = data[o + 8:o + 8 + n]
+        assert struct.unpack(">I", data[o + 8 + n:o + 12 + n])[0] == zlib.crc32(t + body) & 0xFFFFFFFF, "chunk CRC"
+        if t == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif t == b"IDAT":
+            idat += body
+        o += 12 + n
+    w, h, depth, ctype, _, _, inter = hdr
+    assert depth == 8 and inter == 0
+    c = {0: 1, 2: 3, 4: 2, 6: 4}[ctype]
+    raw = zlib.decompress(idat)
+    row = w * c
+    assert len(raw) == (row + 1) * h
+    img = np.zeros((h, row), np.int32)
+    for y in range(h):
+        ft = raw[(row + 1) * y]
+        line = np.frombuffer(raw, np.uint8, row, (row + 1) * y + 1).astype(np.int32)
+        up = img[y - 1] if y else np.zeros(row, np.int32)
+        for i in range(row):
+            a = img[y, i - c] if i >= c else 0
+            b = up[i]
+            cc = up[i - c] if i >= c else 0
+            pred = [0, a, b, (a + b) >> 1, paeth(int(a), int(b), int(cc))][ft]
+            img[y, i] = (line[i] + pred) & 0xFF
+    return img.astype(np.uint8).reshape(h, w, c), len(raw), len(idat)
+
+
+@pytest.mark.parametrize("c,ctype", [(1, 0), (2, 4), (3, 2), (4, 6)])
+def test_png_writer_round_trip_and_compression(probe, tmp_path, c, ctype):
+    rng = np.random.default_rng(100 + c)
+    h, w = 41, 67
+    y, x, k = np.meshgrid(np.arange(h), np.arange(w), np.arange(c), indexing="ij")
+    smooth = ((x * 2 + y * 3 + k * 50) & 0xFF).astype(np.uint8)                # the filters and LZ77 have something to find
+    noisy = rng.integers(0, 256, size=(h, w, c), dtype=np.uint8)              # incompressible: must still be a valid stream
+    flat = np.full((h, w, c), 77, np.uint8)                                    # maximal matches (length 258)
+    for name, img in (("smooth", smooth), ("noisy", noisy), ("flat", flat), ("tiny", noisy[:1, :1])):
+        src, dst = tmp_path / "in.png", tmp_path / "out.png"
+        src.write_bytes(make_png(img, ctype))
+        assert subprocess.run([probe, str(src), str(dst)]).returncode == 0
+        got, raw_len, z_len = decode_png_py(dst.read_bytes())
+        assert np.array_equal(got, img), name
+        assert np.array_equal(load(probe, dst), img), name  # and our own reader agrees
+        if name in ("smooth", "flat"):
+            assert z_len < raw_len // 4, (name, z_len, raw_len)

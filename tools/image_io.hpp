@@ -1,7 +1,7 @@
 // image_io.hpp -- the image file I/O the reference delegates to stb (not vendored, not installed, no network):
 // readers for binary PNM/PAM (P5 grey, P6 RGB, P7 with 1..4 channels, maxval 255), for PNG (every colour type and bit
 // depth, Adam7 interlacing; own inflate) and for uncompressed BMP (8-bit palette, 24-bit, 32-bit with masks), and a writer
-// for PNG with stored (uncompressed) deflate blocks.  Plays the role of stbi_load (llcompc.cpp:25) / stbi_write_png (llcompd.cpp:29); it is host glue of the
+// for PNG (adaptive row filters, LZ77 + fixed-Huffman deflate).  Plays the role of stbi_load (llcompc.cpp:25) / stbi_write_png (llcompd.cpp:29); it is host glue of the
 // CLIs, not part of the coding path.  Channel counts follow stb: grey 1, grey+alpha 2, RGB / palette 3, RGBA 4, and
 // a tRNS chunk adds the alpha channel.
 #pragma once
@@ -434,28 +434,116 @@ inline void put_chunk(std::vector<uint8_t>& out, const char* type, const std::ve
     put_be32(out, crc32(t.data(), t.size()));
 }
 
-// 1 on success, 0 on failure (the convention of stbi_write_png).
+// ---- deflate for the PNG writer: LZ77 (hash chains, 32 KiB window) + the fixed Huffman code of RFC 1951 3.2.6 -------------
+struct BitWriter {
+    std::vector<uint8_t>& out;
+    uint32_t acc = 0;
+    int n = 0;
+    explicit BitWriter(std::vector<uint8_t>& o) : out(o) {}
+    void put(uint32_t v, int bits) {  // LSB first
+        acc |= v << n;
+        n += bits;
+        while (n >= 8) { out.push_back(uint8_t(acc)); acc >>= 8; n -= 8; }
+    }
+    void put_code(uint32_t code, int bits) {  // Huffman codes go in MSB first
+        uint32_t r = 0;
+        for (int i = 0; i < bits; ++i) r |= ((code >> i) & 1u) << (bits - 1 - i);
+        put(r, bits);
+    }
+    void flush() { if (n) { out.push_back(uint8_t(acc)); acc = 0; n = 0; } }
+};
+inline void put_fixed_symbol(BitWriter& bw, int sym) {  // literal / length alphabet
+    if (sym < 144) bw.put_code(0x30 + uint32_t(sym), 8);
+    else if (sym < 256) bw.put_code(0x190 + uint32_t(sym - 144), 9);
+    else if (sym < 280) bw.put_code(uint32_t(sym - 256), 7);
+    else bw.put_code(0xC0 + uint32_t(sym - 280), 8);
+}
+// zlib stream (RFC 1950) around one fixed-Huffman deflate block
+inline std::vector<uint8_t> deflate_zlib(const std::vector<uint8_t>& in) {
+    static const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    std::vector<uint8_t> z = {0x78, 0x5E};
+    BitWriter bw(z);
+    bw.put(1, 1);  // BFINAL
+    bw.put(1, 2);  // BTYPE = 01: fixed Huffman
+    const size_t n = in.size();
+    constexpr int kHashBits = 15, kWindow = 32768, kMaxChain = 24;
+    std::vector<int32_t> head(size_t(1) << kHashBits, -1), prev(n ? n : 1, -1);
+    auto hash3 = [&](size_t i) { return ((uint32_t(in[i]) << 16 | uint32_t(in[i + 1]) << 8 | in[i + 2]) * 0x9E3779B1u) >> (32 - kHashBits); };
+    size_t i = 0;
+    while (i < n) {
+        int best_len = 0, best_dist = 0;
+        if (i + 3 <= n) {
+            const uint32_t hh = hash3(i);
+            int chain = 0;
+            for (int32_t c = head[hh]; c >= 0 && int(i - size_t(c)) <= kWindow && chain < kMaxChain; c = prev[size_t(c)], ++chain) {
+                const size_t maxl = n - i < 258 ? n - i : 258;
+                size_t l = 0;
+                while (l < maxl && in[size_t(c) + l] == in[i + l]) ++l;
+                if (int(l) > best_len) { best_len = int(l); best_dist = int(i - size_t(c)); if (l == maxl) break; }
+            }
+        }
+        const size_t step = best_len >= 3 ? size_t(best_len) : 1;
+        if (best_len >= 3) {
+            int lc = 28;
+            while (len_base[lc] > best_len) --lc;
+            put_fixed_symbol(bw, 257 + lc);
+            if (len_extra[lc]) bw.put(uint32_t(best_len - len_base[lc]), len_extra[lc]);
+            int dc = 29;
+            while (dist_base[dc] > best_dist) --dc;
+            bw.put_code(uint32_t(dc), 5);
+            if (dist_extra[dc]) bw.put(uint32_t(best_dist - dist_base[dc]), dist_extra[dc]);
+        } else {
+            put_fixed_symbol(bw, in[i]);
+        }
+        for (size_t k = 0; k < step; ++k, ++i)  // every position enters the hash chains
+            if (i + 3 <= n) { const uint32_t hh = hash3(i); prev[i] = head[hh]; head[hh] = int32_t(i); }
+    }
+    put_fixed_symbol(bw, 256);  // end of block
+    bw.flush();
+    uint32_t a = 1, b = 0;
+    for (uint8_t v : in) { a = (a + v) % 65521; b = (b + a) % 65521; }
+    put_be32(z, (b << 16) | a);
+    return z;
+}
+
+// 1 on success, 0 on failure (the convention of stbi_write_png).  Per row the filter with the smallest sum of absolute
+// (signed) residuals is taken, like stb_image_write; the rows are deflated with the coder above.
 inline int write_png(const std::string& path, int w, int h, int c, const uint8_t* px, int stride) {
     if (w <= 0 || h <= 0 || c < 1 || c > 4) return 0;
     static const uint8_t colour_type[5] = {0, 0, 4, 2, 6};
+    const size_t row = size_t(w) * c;
     std::vector<uint8_t> raw;
-    raw.reserve((size_t(w) * c + 1) * h);
+    raw.reserve((row + 1) * h);
+    std::vector<uint8_t> cand(row), best(row);
     for (int y = 0; y < h; ++y) {
-        raw.push_back(0);  // filter: none
-        raw.insert(raw.end(), px + size_t(y) * stride, px + size_t(y) * stride + size_t(w) * c);
+        const uint8_t* cur = px + size_t(y) * stride;
+        const uint8_t* up = y ? px + size_t(y - 1) * stride : nullptr;
+        long best_sum = -1;
+        int best_ft = 0;
+        for (int ft = 0; ft < 5; ++ft) {
+            long sum = 0;
+            for (size_t i = 0; i < row; ++i) {
+                const int a = i >= size_t(c) ? cur[i - c] : 0, b = up ? up[i] : 0, cc = (up && i >= size_t(c)) ? up[i - c] : 0;
+                int pred = 0;
+                if (ft == 1) pred = a;
+                else if (ft == 2) pred = b;
+                else if (ft == 3) pred = (a + b) >> 1;
+                else if (ft == 4) {
+                    const int pp = a + b - cc, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - cc);
+                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : cc);
+                }
+                cand[i] = uint8_t(cur[i] - pred);
+                sum += std::abs(int(int8_t(cand[i])));
+            }
+            if (best_sum < 0 || sum < best_sum) { best_sum = sum; best_ft = ft; best.swap(cand); }
+        }
+        raw.push_back(uint8_t(best_ft));
+        raw.insert(raw.end(), best.begin(), best.end());
     }
-    std::vector<uint8_t> z = {0x78, 0x01};
-    uint32_t a = 1, b = 0;
-    for (uint8_t v : raw) { a = (a + v) % 65521; b = (b + a) % 65521; }
-    for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
-        const size_t n = raw.size() - off < 65535 ? raw.size() - off : 65535;
-        z.push_back(off + n >= raw.size() ? 1 : 0);
-        z.push_back(uint8_t(n)); z.push_back(uint8_t(n >> 8));
-        z.push_back(uint8_t(~n)); z.push_back(uint8_t((~n) >> 8));
-        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
-        if (raw.empty()) break;
-    }
-    put_be32(z, (b << 16) | a);
+    const std::vector<uint8_t> z = deflate_zlib(raw);
     std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
     std::vector<uint8_t> ihdr;
     put_be32(ihdr, uint32_t(w)); put_be32(ihdr, uint32_t(h));

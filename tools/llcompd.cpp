@@ -4,7 +4,7 @@
 // (/root/reference/llcompd.cpp:11-41): one positional argument, the picture is written as "<file>.png", exit status 1
 // when the input cannot be read or the stream is rejected with a std::exception (message printed), 2 for any other
 // exception, and -- faithfully -- still 0 when only writing the PNG failed (llcompd.cpp:29-31).  stb_image_write is not
-// available; tools/image_io.hpp writes the PNG (stored deflate blocks).  Reads both wire formats.  --small-model: the file is a
+// available; tools/image_io.hpp writes the PNG (adaptive row filters, own deflate).  Reads both wire formats.  --small-model: the file is a
 // reference-format stream written by a reference built with `LargeModel = false` (llcomp.hpp:21) -- that header does not
 // record the variant (a sliced container does).
 #include <cstdio>
