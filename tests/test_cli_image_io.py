@@ -306,3 +306,48 @@ def test_png_writer_round_trip_and_compression(probe, tmp_path, c, ctype):
         assert np.array_equal(load(probe, dst), img), name  # and our own reader agrees
         if name in ("smooth", "flat"):
             assert z_len < raw_len // 4, (name, z_len, raw_len)
+
+
+def make_tga(img, rle=False, top_down=False, right_left=False):
+    h, w, c = img.shape
+    src = img if top_down else img[::-1]
+    if right_left:
+        src = src[:, ::-1]
+    file_px = (src if c == 1 else np.concatenate([src[..., 2::-1][..., :3], src[..., 3:]], axis=2)).reshape(-1, c)  # B, G, R(, A)
+    head = bytes([0, 0, (11 if c == 1 else 10) if rle else (3 if c == 1 else 2), 0, 0, 0, 0, 0, 0, 0, 0, 0]) + struct.pack("<HHBB", w, h, 8 * c,
+                 (0x20 if top_down else 0) | (0x10 if right_left else 0) | (8 if c == 4 else 0))
+    if not rle:
+        return head + file_px.tobytes()
+    out, i, n = bytearray(), 0, len(file_px)
+    while i < n:  # runs where the next pixels repeat, raw packets otherwise (runs may cross scanlines: allowed by the readers)
+        run = 1
+        while i + run < n and run < 128 and (file_px[i + run] == file_px[i]).all():
+            run += 1
+        if run > 1:
+            out += bytes([0x80 | (run - 1)]) + file_px[i].tobytes()
+            i += run
+        else:
+            j = i + 1
+            while j < n and j - i < 128 and not (j + 1 < n and (file_px[j + 1] == file_px[j]).all()):
+                j += 1
+            out += bytes([j - i - 1]) + file_px[i:j].tobytes()
+            i = j
+    return head + bytes(out)
+
+
+@pytest.mark.parametrize("c", [1, 3, 4])
+def test_tga_variants(probe, tmp_path, c):
+    rng = np.random.default_rng(40 + c)
+    img = rng.integers(0, 4, size=(13, 17, c), dtype=np.uint8) * 60  # few values: real runs for the RLE packets
+    img[5] = 200
+    p = tmp_path / "a.tga"
+    for rle in (False, True):
+        for top_down, right_left in ((False, False), (True, False), (False, True)):
+            p.write_bytes(make_tga(img, rle, top_down, right_left))
+            assert np.array_equal(load(probe, p), img), (rle, top_down, right_left)
+    p.write_bytes(make_tga(img)[:40])
+    assert subprocess.run([probe, str(p)], capture_output=True).returncode == 1
+    bad = bytearray(make_tga(img))
+    bad[2] = 1  # colour-mapped: refused
+    p.write_bytes(bytes(bad))
+    assert subprocess.run([probe, str(p)], capture_output=True).returncode == 1

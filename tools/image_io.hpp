@@ -1,6 +1,7 @@
 // image_io.hpp -- the image file I/O the reference delegates to stb (not vendored, not installed, no network):
 // readers for binary PNM/PAM (P5 grey, P6 RGB, P7 with 1..4 channels, maxval 255), for PNG (every colour type and bit
-// depth, Adam7 interlacing; own inflate) and for uncompressed BMP (8-bit palette, 24-bit, 32-bit with masks), and a writer
+// depth, Adam7 interlacing; own inflate), for uncompressed BMP (8-bit palette, 24-bit, 32-bit with masks) and for TGA (true
+// colour / grey, raw or run-length), and a writer
 // for PNG (adaptive row filters, LZ77 + fixed-Huffman deflate).  Plays the role of stbi_load (llcompc.cpp:25) / stbi_write_png (llcompd.cpp:29); it is host glue of the
 // CLIs, not part of the coding path.  Channel counts follow stb: grey 1, grey+alpha 2, RGB / palette 3, RGBA 4, and
 // a tRNS chunk adds the alpha channel.
@@ -8,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cctype>
 #include <cstring>
 #include <fstream>
 #include <iterator>
@@ -396,7 +398,61 @@ inline std::string load_bmp(const std::string& path, std::vector<uint8_t>& px, i
     return "";
 }
 
-// stbi_load's role: PNG, BMP or binary PNM/PAM by signature.
+// TGA (no signature: recognised by extension and header sanity, like stb does last): true-colour and grey, 8 / 24 / 32
+// bits, raw or run-length packets, either vertical origin.  Channels: 1, 3 or 4 -- like stb.
+inline std::string load_tga(const std::string& path, std::vector<uint8_t>& px, int& w, int& h, int& c) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return "can't fopen";
+    std::vector<uint8_t> f((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    if (f.size() < 18) return "not TGA";
+    const int id_len = f[0], cmap = f[1], type = f[2], bits = f[16], desc = f[17];
+    w = f[12] | (f[13] << 8);
+    h = f[14] | (f[15] << 8);
+    const bool rle = type == 10 || type == 11, grey = type == 3 || type == 11;
+    if (cmap != 0 || !(type == 2 || type == 3 || type == 10 || type == 11)) return "unsupported TGA type";
+    if (w <= 0 || h <= 0) return "bad TGA";
+    if (!(grey ? bits == 8 : (bits == 24 || bits == 32))) return "unsupported TGA bit count";
+    c = bits / 8;
+    const size_t npx = size_t(w) * h;
+    px.resize(npx * c);
+    size_t at = 18 + size_t(id_len);
+    auto put = [&](size_t i, const uint8_t* q) {  // file order is B, G, R(, A)
+        uint8_t* o = &px[i * c];
+        if (c == 1) o[0] = q[0];
+        else { o[0] = q[2]; o[1] = q[1]; o[2] = q[0]; if (c == 4) o[3] = q[3]; }
+    };
+    std::vector<uint8_t> lin(npx * c);  // pixels in file order first
+    if (!rle) {
+        if (at + npx * c > f.size()) return "truncated TGA";
+        lin.assign(f.begin() + long(at), f.begin() + long(at + npx * c));
+    } else {
+        size_t i = 0;
+        while (i < npx) {
+            if (at >= f.size()) return "truncated TGA";
+            const int head = f[at++], n = (head & 127) + 1;
+            if (i + size_t(n) > npx) return "bad TGA packet";
+            if (head & 128) {
+                if (at + size_t(c) > f.size()) return "truncated TGA";
+                for (int k = 0; k < n; ++k) std::memcpy(&lin[(i + size_t(k)) * c], &f[at], size_t(c));
+                at += size_t(c);
+            } else {
+                if (at + size_t(n) * c > f.size()) return "truncated TGA";
+                std::memcpy(&lin[i * c], &f[at], size_t(n) * c);
+                at += size_t(n) * c;
+            }
+            i += size_t(n);
+        }
+    }
+    const bool top_down = (desc & 0x20) != 0, right_left = (desc & 0x10) != 0;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const size_t src = size_t(top_down ? y : h - 1 - y) * w + size_t(right_left ? w - 1 - x : x);
+            put(size_t(y) * w + x, &lin[src * c]);
+        }
+    return "";
+}
+
+// stbi_load's role: PNG, BMP or binary PNM/PAM by signature; TGA (which has none) by its extension.
 inline std::string load_image(const std::string& path, std::vector<uint8_t>& px, int& w, int& h, int& c) {
     std::ifstream in(path, std::ios::binary);
     if (!in) return "can't fopen";
@@ -404,6 +460,11 @@ inline std::string load_image(const std::string& path, std::vector<uint8_t>& px,
     in.close();
     if (first == 0x89) return load_png(path, px, w, h, c);
     if (first == 'B' && second == 'M') return load_bmp(path, px, w, h, c);
+    if (path.size() >= 4) {
+        std::string ext = path.substr(path.size() - 4);
+        for (auto& ch : ext) ch = char(std::tolower(static_cast<unsigned char>(ch)));
+        if (ext == ".tga") return load_tga(path, px, w, h, c);
+    }
     return load_pnm(path, px, w, h, c);
 }
 
