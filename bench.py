@@ -12,13 +12,19 @@ w*h / (t_enc + t_dec) per frame.  `also` = the other workloads of DESIGN.md sect
 same run: other contents, 2-D tiles, one-frame latency, batched legacy streams, the PCIe-inclusive C5 stream, and the C4
 workload on one GPU (the N = 1 point of the strong-scaling curve).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL over xGMI): BASELINE config 4, STRONG scaling -- a fixed
-batch of 8192x8192 RGB8 images, every image sharded over all ranks by interleaved chunks of tile rows
-(llcomp_amd/sharding.py): local encode, slice-table all_gather, one variable-size all-to-all of the payloads (image b is
-gathered on rank b % N), device concatenator -> complete containers spread over the ranks; decode mirrors it.  The exchange is
-inside the timed region,
-container 0 is compared with the one-piece container.  `replica` = the config-3 workload with frames sharded over the ranks
-(no data-path collective, weak scaling), a few steps, as a second key.
+N > 1: one rank per GPU over RCCL.  Started bare (`python bench.py --gpus N`, no WORLD_SIZE in the environment) this
+process touches no GPU: it starts `python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a
+child, relays rank 0's JSON line and exits with the child's code; started by torch.distributed.run it is one of the ranks.
+`value` is the SAME metric and workload as at N = 1 -- config 3, F frames per GPU per step, frames dealt to the ranks
+(independent objects: no data-path collective, weak scaling), barrier + synchronize on both sides, max over ranks -- so
+value(N) / value(1) is a scaling point.  `c4_sharded` = BASELINE config 4, the path that has a real exchange step, STRONG
+scaling: a fixed batch of 8192x8192 RGB8 images, every image sharded over all ranks by interleaved chunks of tile rows
+(llcomp_amd/sharding.py): local encode, slice-table all_gather, one variable-size all-to-all of the payloads (RCCL, image b
+is gathered on rank b % N), device concatenator -> complete containers spread over the ranks; decode mirrors it; the
+exchange is inside the timed region and container 0 is compared with the one-piece container.  Its one-GPU point is
+measured in the same run (rank 0 codes the same batch through a one-rank subgroup first): `one_gpu_value`,
+`scaling_vs_one_gpu`, `ranks_seen`.  `c5_replica_pcie` = config 5 in replica mode.  The secondary legs sit behind a
+watchdog: if one of them fails or hangs, the line still goes out with the headline and says which leg was lost.
 """
 import argparse
 import json
@@ -295,7 +301,7 @@ def c5_stream(frames_np, tile_w, tile_h, planar, depth=8, frames_per_job=4, pipe
             "note": "end to end over PCIe from/to pinned host memory, steady state (every pipeline's first 4 frames excluded), every frame bit-exact; never part of `value`"}
 
 
-def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank, check_one_piece=True, parts=0):
+def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank, check_one_piece=True, parts=0, group=None):
     """BASELINE config 4: `images` noise images of size x size RGB8, each sharded over all ranks; encode (+ exchange of the
     bitstream) and decode (+ exchange back) per step.  The batch is coded as up to three part batches on as many HIP streams
     (a ShardedCodec each) so that the exchange of one part overlaps the coding of the others.  Returns the max-over-ranks wall time."""
@@ -309,7 +315,7 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     # 3, 2 or 1 part batches (measured on one GPU: 2, 3 and 6 parts all take 82 ms per step), each spreading its containers evenly over the ranks
     halves = next(p for p in ((parts,) if parts else ()) + (3, 2, 1) if images % p == 0 and (images // p) % world == 0 or p == 1)
     per = images // halves
-    scs = [sharding.ShardedCodec(size, size, 3, tile_w, tile_h, True, images=per, device=dev) for _ in range(halves)]
+    scs = [sharding.ShardedCodec(size, size, 3, tile_w, tile_h, True, images=per, device=dev, group=group) for _ in range(halves)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(halves)]
     # uniform byte noise (torch Philox, seed 1234 + image): every rank draws the full image on its GPU and keeps its rows
     bands, first = [], None
@@ -357,7 +363,7 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     for k in range(halves):
         assert torch.equal(outs[k], bands[k]), "sharded round trip is not lossless"
     pb = torch.tensor([sum(int(c_.numel()) for cs in conts for c_ in cs.values())], dtype=torch.int64, device=dev)
-    dist.all_reduce(pb, op=dist.ReduceOp.SUM)
+    dist.all_reduce(pb, op=dist.ReduceOp.SUM, group=group)
     payload_bytes = int(pb.item())
     if first is not None:
         one = mi.compress_image(first, size, size, 3, format=mi.FORMAT_SLICED, tile_w=tile_w, tile_h=tile_h, planar=True, device=local_rank)
@@ -374,7 +380,7 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     for cd in codecs:  # hipEvent spans of the local coding kernels, so that a slow step can be told from a slow exchange
         cd.set_profiling(True)
         cd.get_profile()
-    dist.barrier()
+    dist.barrier(group=group)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks = []
@@ -382,7 +388,7 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
         conts, outs = step()
         marks.append(time.perf_counter())
     torch.cuda.synchronize()
-    dist.barrier()
+    dist.barrier(group=group)
     dt = time.perf_counter() - t0
     spans = {}
     for cd in codecs:
@@ -391,7 +397,8 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
         for k_, v_ in pr.items():
             spans[k_] = spans.get(k_, 0.0) + v_ / steps
     c4_run.last_detail = {"kernel_ms_per_step": {k_: round(v_, 3) for k_, v_ in spans.items()},
-                          "step_ms": [round(1e3 * (b - a), 1) for a, b in zip([t0] + marks[:-1], marks)], "parts": halves}
+                          "step_ms": [round(1e3 * (b - a), 1) for a, b in zip([t0] + marks[:-1], marks)], "parts": halves,
+                          "payload_collectives_per_step": sum(sc.exchanges for sc in scs) // max(1, steps + max(3, warmup - 1) + 1)}
     if os.environ.get("LLCOMP_BENCH_ALLOC") and rank == 0:
         st_ = torch.cuda.memory_stats()
         print("c4 allocator:", {k: st_.get(k) for k in ("num_alloc_retries", "num_device_alloc", "num_device_free", "reserved_bytes.all.peak", "allocated_bytes.all.peak")},
@@ -402,10 +409,173 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     for k in range(halves):
         assert torch.equal(outs[k], bands[k])
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     del scs, bands, outs, conts
     torch.cuda.empty_cache()
     return float(t.item()), payload_bytes
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started bare: this process must not touch the GPU (a process that has initialised HIP may
+    neither fork ranks nor be replaced by another program on this pool), so it only starts the launcher as a child, relays
+    rank 0's JSON line and hands the child's exit code on."""
+    import socket
+    import subprocess
+
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in child.stdout:  # the ranks' stdout: exactly one JSON line is expected (anything else goes to stderr)
+        t = out.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            print(t, file=sys.stderr, flush=True)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        print("bench: the ranks exited without a result line", file=sys.stderr)
+        rc = 1
+    raise SystemExit(rc)
+
+
+def headline(args, m, world, planar):
+    """the JSON line's common part: BASELINE's metric on config 3 from measure()'s numbers (at N > 1: rank 0's kernels, the
+    whole job's pixels over the max-over-ranks time)"""
+    F = args.frames
+    S, prof = m["S"], m["prof"]
+    # roofline of the dominant kernel (SURVEY 8d: algorithmic bytes of one coding direction = raw + stream), per launch
+    # (a launch covers F/S frames), duration measured live with hipEvents on the launching stream
+    k_enc = prof["k_encode_slices"] / max(1, m["n_enc"])
+    k_dec = prof["k_decode_slices"] / max(1, m["n_dec"])
+    dom, dom_ms = ("k_decode_slices", k_dec) if k_dec >= k_enc else ("k_encode_slices", k_enc)
+    algo = (m["raw_bytes"] + m["container_bytes"]) // S
+    achieved = algo / (dom_ms * 1e-3) / 1e9
+    traffic, valu, source = profile_numbers(F, args.tile_w, args.tile_h, planar, args.content, S, dom)
+    clock = clock_numbers()
+    isolated = None
+    if m["iso"]:
+        iso_ms = m["iso"][dom] / max(1, m["iso_enc"] if dom == "k_encode_slices" else m["iso_dec"])
+        isolated = {"avg_launch_ms": round(iso_ms, 4), "achieved": round(algo / (iso_ms * 1e-3) / 1e9, 3),
+                    "frac": round(algo / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                    "note": "the same launches with one pipeline at a time on the GPU, outside the timed region"}
+        if valu:
+            isolated["valu_issue_frac"] = round(valu / (iso_ms * 1e-3) / VALU_PEAK, 4)
+    valu_issue = None
+    if valu:
+        valu_issue = {"valu_wave_insts_per_launch": valu, "source": source, "achieved": round(valu / (dom_ms * 1e-3) / 1e9, 2), "peak": VALU_PEAK / 1e9,
+                      "unit": "G wave-instructions/s", "frac": round(valu / (dom_ms * 1e-3) / VALU_PEAK, 4),
+                      "note": "VALU wave-instructions of one launch (committed rocprofv3 SQ_INSTS_VALU pass of this configuration) / live launch duration, "
+                              "against 1024 SIMDs x 2.4 GHz / 2; live launches share the SIMDs with the other pipelines' kernels, isolated.valu_issue_frac is the kernel alone"}
+        if clock:  # the same against the clock the kernel was MEASURED to run at (s_memtime / s_memrealtime in a diagnostic build)
+            ghz = clock.get(dom, {}).get("clock_ghz")
+            if ghz:
+                true_peak = 1024 * ghz * 1e9 / 2
+                valu_issue.update({"clock_ghz": ghz, "clock_source": clock.get("source"), "peak_at_clock": round(true_peak / 1e9, 1),
+                                   "frac_at_clock": round(valu / (dom_ms * 1e-3) / true_peak, 4)})
+                if isolated and "valu_issue_frac" in isolated:
+                    isolated["valu_issue_frac_at_clock"] = round(isolated["valu_issue_frac"] * 2.4 / ghz, 4)
+    return {
+        "metric": "encode+decode MPix/s on 4K RGB8, bit-exact",
+        "value": round(m["mpix"], 2),
+        "unit": "MPix/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(m["dt"] / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"C3 3840x2160 RGB8 {args.content} ({'std::mt19937 noise' if args.content == 'g3' else args.content}), "
+                        f"{F} frames/step/GPU resident in HBM, sliced container: {args.tile_w}x{args.tile_h} tiles, "
+                        f"{'per-channel planes' if planar else 'channels interleaved'}, {m['n_slices'] // F} slices/frame, {S} stream(s)"
+                        + ("" if world == 1 else f"; {world} GPUs, {F} frames each per step (frames are independent objects: dealt to the ranks, no data-path collective)"),
+            "frames_per_step_per_gpu": F, "tile_w": args.tile_w, "tile_h": args.tile_h, "planar": planar, "content": args.content,
+            "slices_per_frame": m["n_slices"] // F, "streams": S,
+            "compression_ratio": round(m["ratio"], 4),
+            "parallelism": "one GPU" if world == 1 else f"dp{world}: one process per GPU, frames sharded over the ranks; config 4 (tiles of one image sharded, RCCL exchange) is the c4_sharded key",
+        },
+        "roofline": {
+            "bound": "valu_issue", "hbm_bound_as_contract_asks": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": source,
+            "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(dom_ms, 4), "isolated": isolated,
+            "limiter": "valu_issue",
+            "valu_issue": valu_issue,
+            "note": "achieved/peak/frac are the contract's HBM figures (algorithmic bytes of one coding direction per launch / live launch duration vs 8 TB/s); "
+                    "`bound` names what limits the kernel: VALU issue along its serial dependency chain (one lane per slice), DESIGN.md 4 -- its own roofline is "
+                    "valu_issue (frac_at_clock = against the measured in-kernel clock); launch durations are measured while the other stream(s)' pipelines run beside them",
+        },
+        "kernel_ms_per_step": {k: round(v / max(1, args.steps), 4) for k, v in prof.items()},
+    }
+
+
+def clock_numbers():
+    """in-kernel shader clock of the slice kernels, measured with a diagnostic build (tools/clock_probe.py: delta s_memtime /
+    delta s_memrealtime x 100 MHz, median over wavefronts) and committed under profiles/; None when there is no such file"""
+    for name in ("r03_inkernel_clock.json",):
+        try:
+            cj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            cj["source"] = "profiles/" + name
+            return cj
+        except (OSError, ValueError):
+            pass
+    return None
+
+
+class Watchdog:
+    """The secondary legs of the N > 1 line run behind this: if they have not finished `seconds` after arm(), rank 0 prints
+    the line with what it has (the headline is complete by then) and every rank leaves with exit code 0 -- a leg that hangs
+    in a collective, or a rank that died in one, costs that leg, not the run."""
+
+    def __init__(self, rank, res):
+        import threading
+
+        self.rank, self.res, self.lock, self.done = rank, res, threading.Lock(), False
+        self.timer = None
+
+    def bail(self, what, why):
+        """give up on the remaining legs NOW: rank 0 prints the line as it stands, the process leaves with exit code 0"""
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            print(f"bench: rank {self.rank}: giving up on '{what}': {why}", file=sys.stderr, flush=True)
+            if self.rank == 0 and self.res is not None:
+                self.res.setdefault("lost_legs", []).append({"leg": what, "why": why[:300]})
+                print(json.dumps(self.res), flush=True)
+        sys.stdout.flush()
+        time.sleep(0 if self.rank == 0 else 3.0)
+        os._exit(0)
+
+    def arm(self, seconds, what):
+        import threading
+
+        self.timer = threading.Timer(seconds, self.bail, args=(what, f"not finished after {seconds:.0f} s (a rank is stuck or gone)"))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def finish(self):
+        """True when the caller may print (the watchdog has not already done so)"""
+        with self.lock:
+            if self.done:
+                return False
+            self.done = True
+        if self.timer:
+            self.timer.cancel()
+        return True
 
 
 def main():
@@ -422,14 +592,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra one-pipeline-at-a-time launches behind the timed region (profiler runs)")
     ap.add_argument("--no-also", action="store_true", help="only the headline workload (profiler runs, sweeps)")
-    ap.add_argument("--also-only", default="", help="comma-separated subset of the `also` legs: contents,tiles,latency,legacy,c5,c4 (profiling)")
+    ap.add_argument("--also-only", default="", help="comma-separated subset of the `also` legs: contents,tiles,latency,legacy,c5,c4,c2 (profiling)")
     ap.add_argument("--c4-parts", type=int, default=0, help="part batches (ShardedCodec objects on their own HIP streams) of the config-4 step; 0 = three where the image count allows")
     ap.add_argument("--c4-images", type=int, default=24, help="8192x8192 images per step of the sharded (config 4) workload (fixed total: strong scaling)")
     ap.add_argument("--c4-tile-w", type=int, default=512)
     ap.add_argument("--c4-tile-h", type=int, default=1)
+    ap.add_argument("--legs-timeout", type=float, default=300.0, help="N > 1: seconds the secondary legs (config 4, config 5) may take before the line goes out without them")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="rehearsal of the N > 1 code path on a one-GPU box: all ranks use cuda:0 and exchange over gloo (RCCL refuses two ranks on one device); the numbers mean nothing")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)  # (does not return)
 
     import numpy as np
     import torch
@@ -441,9 +615,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.rehearse_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available() or mi.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: llcomp_amd has no CPU path")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     if world == 1:  # the sharded workload runs under torch.distributed at every N, so the N = 1 point is the same code
         import socket
@@ -465,6 +641,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         warm = torch.zeros(1, device="cuda")
         dist.all_reduce(warm)
+        solo = dist.new_group(ranks=[0]) if world > 1 else None  # rank 0 alone: the one-GPU point of the config-4 curve
+        if solo is not None and rank == 0:
+            dist.all_reduce(warm, group=solo)
         torch.cuda.synchronize()
     finally:
         sys.stdout.flush()
@@ -476,15 +655,52 @@ def main():
     F = args.frames
 
     if world > 1:
-        # ---- BASELINE config 4: strong scaling of sharded 8192^2 images, gather + scatter inside the timed region ----
-        size, B = 8192, args.c4_images
-        dt, payload = c4_run(B, size, args.c4_tile_w, args.c4_tile_h, args.steps, args.warmup, local_rank, world, rank, parts=args.c4_parts)
-        # second key: the config-3 workload, frames sharded over the ranks (independent objects, no collective)
-        m = measure(make_frames(args.content, F, rank, distinct=min(F, 8)), args.tile_w, args.tile_h, planar, args.streams, max(2, args.steps // 3), 1,
+        # ---- headline: BASELINE's metric on config 3, frames dealt to the ranks (same workload per GPU as at N = 1) ----
+        m = measure(make_frames(args.content, F, rank, distinct=min(F, 8)), args.tile_w, args.tile_h, planar, args.streams, args.steps, args.warmup,
                     local_rank, barrier=barrier)
         t = torch.tensor([m["dt"]], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        # third key: BASELINE config 5 in replica mode: every rank streams its own share of the 64 frames
+        dt_all = float(t.item())
+        res = None
+        if rank == 0:
+            res = headline(args, dict(m, dt=dt_all, mpix=world * m["F"] * W4K * H4K * m["steps"] / dt_all / 1e6), world, planar)
+            res["ranks_seen"] = dist.get_world_size()
+            res["per_gpu_value"] = round(res["value"] / world, 2)
+        dog = Watchdog(rank, res)
+        dog.arm(args.legs_timeout, "c4_sharded + c5_replica_pcie")
+        # ---- BASELINE config 4: strong scaling of sharded 8192^2 images, gather + scatter inside the timed region -------
+        size, B = 8192, args.c4_images
+        n4 = max(3, args.steps // 2)
+        c4 = {}
+        try:
+            one = None
+            if rank == 0:  # the one-GPU point of the same batch, same code path, on a one-rank subgroup
+                dt1, pay1 = c4_run(B, size, args.c4_tile_w, args.c4_tile_h, n4, 3, local_rank, 1, 0, parts=args.c4_parts, group=solo)
+                mi.trim()
+                torch.cuda.empty_cache()
+                one = B * size * size * n4 / dt1 / 1e6
+            dist.barrier()
+            dtn, payload = c4_run(B, size, args.c4_tile_w, args.c4_tile_h, n4, 3, local_rank, world, rank, parts=args.c4_parts)
+            mi.trim()
+            torch.cuda.empty_cache()
+            if rank == 0:
+                raw = B * size * size * 3
+                vn = B * size * size * n4 / dtn / 1e6
+                c4 = {"value": round(vn, 1), "unit": "MPix/s", "scaling": "strong", "ms_per_step": round(dtn / n4 * 1e3, 3), "steps": n4,
+                      "one_gpu_value": round(one, 1), "one_gpu_ms_per_step": round(dt1 / n4 * 1e3, 3), "scaling_vs_one_gpu": round(vn / one, 3),
+                      "ranks_seen": dist.get_world_size(), "images_per_step": B, "compression_ratio": round(raw / payload, 4),
+                      "hbm_roofline_frac": round(2 * (raw + payload) * n4 / dtn / 1e9 / (HBM_PEAK_GBS * world), 6),
+                      **getattr(c4_run, "last_detail", {}),
+                      "workload": f"C4 {B} x 8192x8192 RGB8 uniform noise per step (fixed total), every image sharded over {world} GPUs by interleaved chunks of "
+                                  f"tile rows; sliced container {args.c4_tile_w}x{args.c4_tile_h} tiles, per-channel planes; per step: local encode, slice-table "
+                                  f"all_gather, variable-size all-to-all of the packed payloads over RCCL (image b is gathered on rank b % {world}), device "
+                                  f"concatenator -> {B} complete containers spread over the ranks; then table all_gather, all-to-all back, local decode (decoded "
+                                  f"rows stay on their ranks); one_gpu_value = the same batch through the same code on rank 0 alone, same run"}
+        except Exception as e:  # noqa: BLE001  (the other ranks are very likely stuck in a collective now: their watchdogs end them)
+            dog.bail("c4_sharded", f"rank {rank}: {type(e).__name__}: {e}")
+        if rank == 0:
+            res["c4_sharded"] = c4
+        # ---- BASELINE config 5 in replica mode: every rank streams its own share of the 64 frames
         # host -> GPU -> host -> GPU -> host through llcomp_mi_stream_* over its own PCIe link, all ranks at the same time.
         # A rank whose leg fails still takes part in the reductions (nobody is left waiting) and the key says so.
         c5 = {"value": 0.0}
@@ -498,34 +714,11 @@ def main():
         v5 = torch.tensor([c5["value"], ok], dtype=torch.float64, device="cuda")
         dist.all_reduce(v5, op=dist.ReduceOp.SUM)
         if rank == 0:
-            value = B * size * size * args.steps / dt / 1e6
-            raw = B * size * size * 3
-            res = {
-                "metric": "encode+decode MPix/s on 8192x8192 RGB8 sharded over the GPUs, RCCL exchange of the bitstream included, bit-exact",
-                "value": round(value, 2), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-                "dtype": "int32", "data": "synthetic",
-                "config": {
-                    "workload": f"C4 {B} x 8192x8192 RGB8 uniform noise per step (fixed total), every image sharded over {world} GPUs by interleaved "
-                                f"chunks of tile rows; sliced container {args.c4_tile_w}x{args.c4_tile_h} tiles, per-channel planes; per step: local encode, "
-                                f"slice-table all_gather, variable-size all-to-all of the packed payloads over RCCL (image b is gathered on rank b % {world}), "
-                                f"device concatenator -> {B} complete containers spread over the ranks; then table all_gather, all-to-all back, local decode "
-                                f"(decoded rows stay on their ranks)",
-                    "images_per_step": B, "tile_w": args.c4_tile_w, "tile_h": args.c4_tile_h, "planar": True, "content": "uniform noise (torch Philox, seed 1234+i)",
-                    "compression_ratio": round(raw / payload, 4),
-                    "parallelism": f"tile-row chunks of every image round-robin over {world} GPUs; exchange = all_gather(lengths) + alltoallv(payload) per direction",
-                    "one_gpu_point": "the N=1 run reports the same workload under also.c4_sharded_one_gpu",
-                },
-                "roofline": {"bound": "hbm", "kernel": "whole step (sharded)", "achieved": round(2 * (raw + payload) * args.steps / dt / 1e9, 3),
-                             "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(2 * (raw + payload) * args.steps / dt / 1e9 / (HBM_PEAK_GBS * world), 6),
-                             "traffic": None, "note": "algorithmic bytes of encode + decode over the whole job / wall time; the per-kernel roofline is in the N=1 line"},
-                "replica": brief(dict(m, dt=float(t.item()), mpix=world * m["F"] * W4K * H4K * m["steps"] / float(t.item()) / 1e6), scaling="weak",
-                                 workload=f"C3 {F} frames/step/GPU, frames sharded over {world} GPUs, no data-path collective"),
-                "c5_replica_pcie": {"value": round(float(v5[0].item()), 1), "unit": "MPix/s", "ranks_ok": int(round(float(v5[1].item()))), "scaling": "weak",
-                                    "frames_per_rank": 4 * max(16, 64 // world), "rank0": c5,
-                                    "workload": f"C5: every rank streams its own {max(16, 64 // world)} 4K frames (four passes) host -> GPU -> host -> GPU -> host "
-                                                f"through llcomp_mi_stream_*, all {world} ranks at once; sum of the ranks' steady-state rates, PCIe inclusive"},
-            }
+            res["c5_replica_pcie"] = {"value": round(float(v5[0].item()), 1), "unit": "MPix/s", "ranks_ok": int(round(float(v5[1].item()))), "scaling": "weak",
+                                      "frames_per_rank": 4 * max(16, 64 // world), "rank0": c5,
+                                      "workload": f"C5: every rank streams its own {max(16, 64 // world)} 4K frames (four passes) host -> GPU -> host -> GPU -> host "
+                                                  f"through llcomp_mi_stream_*, all {world} ranks at once; sum of the ranks' steady-state rates, PCIe inclusive"}
+        if dog.finish() and rank == 0:
             print(json.dumps(res), flush=True)
         dist.destroy_process_group()
         return
@@ -533,60 +726,7 @@ def main():
     # ---- N = 1: BASELINE config 3 (headline) ------------------------------------------------------------------------
     frames_np = make_frames(args.content, F, rank)
     m = measure(frames_np, args.tile_w, args.tile_h, planar, args.streams, args.steps, args.warmup, local_rank, isolated=not args.no_isolated)
-    S, prof = m["S"], m["prof"]
-    # roofline of the dominant kernel (algorithmic bytes of one coding direction = raw + stream), per launch
-    # (a launch covers F/S frames), duration measured live with hipEvents on the launching stream
-    k_enc = prof["k_encode_slices"] / max(1, m["n_enc"])
-    k_dec = prof["k_decode_slices"] / max(1, m["n_dec"])
-    dom, dom_ms = ("k_decode_slices", k_dec) if k_dec >= k_enc else ("k_encode_slices", k_enc)
-    algo = (m["raw_bytes"] + m["container_bytes"]) // S
-    achieved = algo / (dom_ms * 1e-3) / 1e9
-    traffic, valu, source = profile_numbers(F, args.tile_w, args.tile_h, planar, args.content, S, dom)
-    isolated = None
-    if m["iso"]:
-        iso_ms = m["iso"][dom] / max(1, m["iso_enc"] if dom == "k_encode_slices" else m["iso_dec"])
-        isolated = {"avg_launch_ms": round(iso_ms, 4), "achieved": round(algo / (iso_ms * 1e-3) / 1e9, 3),
-                    "frac": round(algo / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                    "note": "the same launches with one pipeline at a time on the GPU, outside the timed region"}
-        if valu:
-            isolated["valu_issue_frac"] = round(valu / (iso_ms * 1e-3) / VALU_PEAK, 4)
-    res = {
-        "metric": "encode+decode MPix/s on 4K RGB8, bit-exact",
-        "value": round(m["mpix"], 2),
-        "unit": "MPix/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(m["dt"] / args.steps * 1e3, 3),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "int32",
-        "data": "synthetic",
-        "config": {
-            "workload": f"C3 3840x2160 RGB8 {args.content} ({'std::mt19937 noise' if args.content == 'g3' else args.content}), "
-                        f"{F} frames/step/GPU resident in HBM, sliced container: {args.tile_w}x{args.tile_h} tiles, "
-                        f"{'per-channel planes' if planar else 'channels interleaved'}, {m['n_slices'] // F} slices/frame, {S} stream(s)",
-            "frames_per_step_per_gpu": F, "tile_w": args.tile_w, "tile_h": args.tile_h, "planar": planar, "content": args.content,
-            "slices_per_frame": m["n_slices"] // F, "streams": S,
-            "compression_ratio": round(m["ratio"], 4),
-            "parallelism": "one GPU (N > 1 runs the sharded config-4 workload)",
-        },
-        "roofline": {
-            "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": source,
-            "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(dom_ms, 4), "isolated": isolated,
-            "limiter": "valu_issue",
-            "valu_issue": None if not valu else {
-                "valu_wave_insts_per_launch": valu, "source": source, "achieved": round(valu / (dom_ms * 1e-3) / 1e9, 2), "peak": VALU_PEAK / 1e9,
-                "unit": "G wave-instructions/s", "frac": round(valu / (dom_ms * 1e-3) / VALU_PEAK, 4),
-                "note": "VALU wave-instructions of one launch (committed rocprofv3 SQ_INSTS_VALU pass of this configuration) / live launch duration, "
-                        "against 1024 SIMDs x 2.4 GHz / 2; live launches share the SIMDs with the other pipelines' kernels, isolated.valu_issue_frac is the kernel alone"},
-            "note": "the contract's HBM roofline is reported as asked, but this kernel is bound by VALU issue / its serial dependency chain (one lane per slice), "
-                    "not by HBM: DESIGN.md 4; launch durations are measured while the pipelines of the other stream(s) run beside them",
-        },
-        "kernel_ms_per_step": {k: round(v / max(1, args.steps), 4) for k, v in prof.items()},
-    }
+    res = headline(args, m, world, planar)
     # byte-level pin of the measured workload: frame 0 of the default batch is the golden vector's image (std::mt19937(1234)),
     # its container length must be the one the real reference's per-slice streams add up to (tests/golden, also hashed in
     # tests/test_gpu_stream.py::test_c3_4k_bench_slicing_golden)

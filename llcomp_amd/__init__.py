@@ -29,9 +29,10 @@ RawImage = namedtuple("RawImage", "pixels width height channels")
 
 
 class LlcompError(RuntimeError):
-    def __init__(self, status):
+    def __init__(self, status, detail=None):
         self.status = int(status)
-        super().__init__(_lib.load().llcomp_mi_strerror(int(status)).decode())
+        msg = _lib.load().llcomp_mi_strerror(int(status)).decode()
+        super().__init__(msg if not detail else f"{msg} ({detail})")
 
 
 def _check(rc):

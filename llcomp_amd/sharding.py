@@ -21,6 +21,7 @@ decoded bands stay on their ranks (gather_pixels() collects them when a single i
 The only host round trip per direction is the world x world matrix of message sizes.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -75,8 +76,11 @@ class _HipBand:
         self.codec.decode(payload.data_ptr(), payload_bytes, lens.data_ptr(), out.data_ptr(), self.status.data_ptr(), st)
         return self.status
 
+    def status_code(self, bits):
+        return self.codec.status(int(bits))
+
     def check(self, status):
-        rc = self.codec.status(int(status.item()))
+        rc = self.status_code(int(status.item()))
         if rc != OK:
             raise LlcompError(rc)
 
@@ -115,8 +119,12 @@ class ShardedCodec:
     object, tests inject a CPU stand-in to exercise the distributed logic where no GPU exists."""
 
     def __init__(self, w, h, c, tile_w=0, tile_h=0, planar=True, images=1, group=None, root=None, chunks_per_rank=4, device=None,
-                 band_factory=None):
+                 band_factory=None, force_exchange=None):
         self.group = group
+        # test hook: run the payload collective even where it is the identity (world 1), so that the RCCL alltoallv on
+        # device tensors executes on a one-GPU box (LLCOMP_MI_FORCE_EXCHANGE=1 does the same for bench.py)
+        self.force_exchange = bool(int(os.environ.get("LLCOMP_MI_FORCE_EXCHANGE", "0"))) if force_exchange is None else bool(force_exchange)
+        self.exchanges = 0  # payload collectives actually executed (tests assert on it)
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.w, self.h, self.c, self.images, self.planar = w, h, c, images, bool(planar)
@@ -137,6 +145,9 @@ class ShardedCodec:
         self.chunks = plan_chunks(h, self.tile_h, world, chunks_per_rank)
         self.ntx = (w + self.tile_w - 1) // self.tile_w
         self.per_row = self.ntx * (c if self.planar else 1)  # slices per tile row
+        # no slice stream is longer than this (geometry.hpp: 13 bytes per sample + slack); lengths read from a container
+        # are clamped to it before anything is sized or copied by them
+        self.slice_cap = (13 * self.tile_w * self.tile_h * (1 if self.planar else c) + 32 + 15) // 16 * 16
         self.nty = (h + self.tile_h - 1) // self.tile_h
         self.spf = self.per_row * self.nty                  # slices of one full image
         self.rows = [(t0 * self.tile_h, min(h, t1 * self.tile_h)) for t0, t1, o in self.chunks if o == self.rank]
@@ -186,14 +197,24 @@ class ShardedCodec:
     def _to_comm(self, t):
         return t if t.device == self.comm_device else t.to(self.comm_device)
 
-    def _all_lens(self, lens):
-        """[world * images * max_local] int64 on self.device: every rank's slice lengths, zero padded"""
-        mine = torch.zeros(self.images * self.max_local, dtype=torch.int32, device=self.device)
+    def _all_lens(self, lens, status=None):
+        """([world * images * max_local] int64 on self.device: every rank's slice lengths, zero padded; [world] int64: every
+        rank's coder status word).  The status rides along in the same all_gather, so every rank learns of a failed local
+        encode before the payload collective and all of them raise together (nobody is left waiting in all_to_all)."""
+        n = self.images * self.max_local
+        mine = torch.zeros(n + 1, dtype=torch.int32, device=self.device)
         if lens is not None:
             mine[: lens.numel()] = lens
-        out = torch.empty(self.world * mine.numel(), dtype=torch.int32, device=self.comm_device)
+        if status is not None:
+            mine[n] = status.reshape(-1)[0].to(self.device)
+        out = torch.empty(self.world * (n + 1), dtype=torch.int32, device=self.comm_device)
         dist.all_gather_into_tensor(out, self._to_comm(mine), group=self.group)
-        return out.to(self.device).to(torch.int64)
+        out = out.to(self.device).view(self.world, n + 1).to(torch.int64)
+        return self._as_lengths(out[:, :n].reshape(-1)), out[:, n].contiguous()
+
+    def _as_lengths(self, t):
+        """int32 words read as the u32 they are on the wire, clamped to what a slice can hold"""
+        return torch.clamp(t.to(torch.int64) & 0xFFFFFFFF, max=self.slice_cap)
 
     def _segment_tables(self, lens_c):
         """From the container-order slice lengths [images * spf]: per (image, chunk) segment its byte count, its offset in
@@ -218,8 +239,9 @@ class ShardedCodec:
     def _exchange(self, send, send_split, recv_split):
         """variable-size all-to-all of bytes (RCCL alltoallv on device tensors); returns the receive buffer on self.device"""
         n_send = int(sum(send_split))
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             return send  # one rank: what it would send to itself is already in place
+        self.exchanges += 1
         recv = torch.empty(int(sum(recv_split)) + 16, dtype=torch.uint8, device=self.comm_device)
         src = self._to_comm(send[:n_send]) if n_send else torch.empty(0, dtype=torch.uint8, device=self.comm_device)
         dist.all_to_all_single(recv[: int(sum(recv_split))], src.contiguous(), output_split_sizes=[int(x) for x in recv_split],
@@ -245,14 +267,17 @@ class ShardedCodec:
         if self._pending is not None:
             payload, lens, total, status = self._pending
         self._pending = None
-        all_lens = self._all_lens(lens)                      # collective 1: slice-length tables
+        all_lens, all_status = self._all_lens(lens, status)  # collective 1: slice-length tables (+ every rank's status word)
         lens_c = all_lens[self.perm]                         # container order
         seg_len, in_exchange, in_image, img_bytes, M = self._segment_tables(lens_c)
-        host = torch.cat([M.reshape(-1), img_bytes]).cpu()   # the one host round trip: message and container sizes
-        if self.band is not None:
-            self.band.check(status)
-        M_h = host[: self.world * self.world].view(self.world, self.world).tolist()
-        img_b = host[self.world * self.world:].tolist()
+        host = torch.cat([M.reshape(-1), img_bytes, all_status]).cpu()   # the one host round trip: message and container sizes
+        ww = self.world * self.world
+        for r, bits in enumerate(host[ww + self.images:].tolist()):  # the same verdict on every rank, before collective 2
+            if bits:
+                code = self.band.status_code(bits) if hasattr(self.band, "status_code") else 7
+                raise LlcompError(code, f"rank {r}'s local encode failed, status bits {bits}")
+        M_h = host[:ww].view(self.world, self.world).tolist()
+        img_b = host[ww:ww + self.images].tolist()
         if payload is None:
             payload = torch.empty(0, dtype=torch.uint8, device=self.device)
         # collective 2: every coding rank's packed payload to the gathering ranks, GPU to GPU
@@ -300,21 +325,30 @@ class ShardedCodec:
         decode, enqueued on the current stream; nothing waits for the decoded pixels"""
         head = HEADER + 4 * self.spf
         per_root = max(1, max(sum(1 for b in range(self.images) if self.root_of[b] == r) for r in range(self.world)))
-        mine_tab = torch.zeros(per_root * self.spf, dtype=torch.int32, device=self.comm_device)
+        # [per_root * spf slice lengths | 1 flag]: a rank that holds a container it cannot use says so in the flag word of the
+        # same all_gather, and every rank raises together (a lone raise would leave the others waiting in the collective)
+        mine_tab = torch.zeros(per_root * self.spf + 1, dtype=torch.int32, device=self.comm_device)
         for j, b in enumerate(self.my_images):
-            cont = containers[b]
-            if cont.numel() < head or (validate and bytes(cont[:HEADER].cpu().numpy()) != bytes(self.header.cpu().numpy())):
-                raise ValueError("container does not match this ShardedCodec's geometry")
+            cont = containers.get(b) if hasattr(containers, "get") else containers[b]
+            if cont is None or cont.numel() < head or (validate and bytes(cont[:HEADER].cpu().numpy()) != bytes(self.header.cpu().numpy())):
+                mine_tab[-1] = 1
+                continue
             mine_tab[j * self.spf:(j + 1) * self.spf] = self._to_comm(cont[HEADER:head].clone().view(torch.int32))  # (clone: dword alignment)
         tabs = torch.empty(self.world * mine_tab.numel(), dtype=torch.int32, device=self.comm_device)
         dist.all_gather_into_tensor(tabs, mine_tab, group=self.group)    # collective 1: the slice tables of every image
-        tabs = tabs.view(self.world, per_root, self.spf)
+        tabs = tabs.view(self.world, per_root * self.spf + 1)
+        bad = tabs[:, -1].cpu().tolist()
+        if any(bad):
+            raise ValueError("container does not match this ShardedCodec's geometry (rank(s) %s)" % [r for r, f in enumerate(bad) if f])
+        tabs = tabs[:, :-1].reshape(self.world, per_root, self.spf)
         slot = [0] * self.world
         pick = []
         for b in range(self.images):
             pick.append((self.root_of[b], slot[self.root_of[b]]))
             slot[self.root_of[b]] += 1
-        lens_c = torch.stack([tabs[r, j] for r, j in pick]).reshape(-1).to(self.device).to(torch.int64)
+        # the tables come out of containers: read as the u32 they are and clamped to a slice's capacity, so that a damaged
+        # table can neither go negative nor size a copy beyond what the geometry allows (the decoder reports the damage)
+        lens_c = self._as_lengths(torch.stack([tabs[r, j] for r, j in pick]).reshape(-1).to(self.device))
         seg_len, in_exchange, in_image, img_bytes, M = self._segment_tables(lens_c)
         M_h = M.cpu().tolist()                               # host round trip: message sizes
         # my containers -> send buffer ordered (coding rank, frame, chunk); the table may promise more than a damaged

@@ -1,6 +1,8 @@
 """The multi-GPU path (llcomp_amd/sharding.py) with the PRODUCT's local coder -- the device-resident HIP codec object --
 under torch.distributed:
-  * world size 1 on the nccl (= RCCL) backend: every collective of the path runs on device tensors;
+  * world size 1 on the nccl (= RCCL) backend: every collective of the path runs on device tensors -- including, with the
+    force_exchange hook, the variable-size all_to_all of the payloads that a single rank would otherwise skip;
+  * world size 2 on the nccl backend, one rank per GPU (skipped on a one-GPU box): the path as bench.py --gpus 2 runs it;
   * world size 2 on the gloo backend, both ranks on the one GPU of the test box: the full exchange logic (slice-table
     all_gather / broadcast, one payload message per rank, device concatenator) around real HIP encodes / decodes.
 Containers must equal the one-piece container of the host call byte for byte (BASELINE config 4 sizes included)."""
@@ -25,7 +27,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, backend, port, cases, q):
+def _worker(rank, world, backend, port, cases, q, own_gpu=False, force=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     import torch
@@ -34,8 +36,9 @@ def _worker(rank, world, backend, port, cases, q):
     import llcomp_amd as mi
     from llcomp_amd import sharding, synth
 
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
+    ordinal = rank if own_gpu else 0
+    torch.cuda.set_device(ordinal)
+    dev = torch.device("cuda", ordinal)
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     else:
@@ -44,19 +47,21 @@ def _worker(rank, world, backend, port, cases, q):
         for (gen, w, h, c), (tw, th), planar, images, cpr, *rest in cases:
             root = rest[0] if rest else None
             full = np.stack([np.roll(synth.GENERATORS[gen](w, h, c), 5 * b, axis=1) for b in range(images)])
-            sc = sharding.ShardedCodec(w, h, c, tw, th, planar, images=images, chunks_per_rank=cpr, root=root, device=dev)
+            sc = sharding.ShardedCodec(w, h, c, tw, th, planar, images=images, chunks_per_rank=cpr, root=root, device=dev, force_exchange=force)
             assert sc.band is None or type(sc.band).__name__ == "_HipBand"
             band = sc.take_local(full)
             conts = sc.encode(band)
             assert sorted(conts) == [b for b in range(images) if (b % world if root is None else root) == rank]   # spread round-robin, or funnelled
             for b in conts:
-                want = mi.compress_image(full[b], w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar, device=0)
+                want = mi.compress_image(full[b], w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar, device=ordinal)
                 assert conts[b].is_cuda and bytes(conts[b].cpu().numpy()) == want, f"{gen} {w}x{h}: image {b} differs from the one-piece container"
             out = sc.decode(conts)
             assert out.is_cuda and torch.equal(out, band), "decoded rows differ from the source rows"
             px = sc.gather_pixels(out)
             if rank == 0:
                 assert np.array_equal(px.cpu().numpy(), full)
+            if force or world > 1:  # the payload collective ran on device tensors, once per direction
+                assert sc.exchanges == 2 and (backend != "nccl" or sc.comm_device.type == "cuda")
             del sc
         q.put((rank, "ok"))
     except Exception:  # pragma: no cover
@@ -68,11 +73,11 @@ def _worker(rank, world, backend, port, cases, q):
         dist.destroy_process_group()
 
 
-def _run(world, backend, cases):
+def _run(world, backend, cases, own_gpu=False, force=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, backend, port, cases, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, backend, port, cases, q, own_gpu, force)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -94,3 +99,26 @@ def test_sharded_path_world2_hip_coder_gloo_exchange():
                      (("nat", 777, 130, 3), (64, 16), False, 1, 1),
                      (("mid", 640, 360, 3), (64, 64), True, 3, 2, 1),                 # every container funnelled to rank 1
                      (("g3", 8192, 2048, 3), (480, 1), True, 1, 4)])      # a quarter of config 4, noise
+
+
+def test_sharded_path_world1_rccl_forced_alltoallv():
+    """the RCCL all_to_all_single with uneven uint8 splits on device tensors, executed (not short-circuited) on one GPU"""
+    _run(1, "nccl", [(("mid", 2048, 1024, 3), (128, 128), True, 2, 4),
+                     (("g3", 1000, 333, 4), (480, 1), True, 3, 4),
+                     (("nat", 777, 130, 3), (64, 16), False, 1, 1),
+                     (("g3", 8192, 2048, 3), (512, 1), True, 2, 4)], force=True)
+
+
+def _gpus():
+    import torch
+
+    return torch.cuda.device_count()  # (counting devices does not initialise the GPU in this process)
+
+
+@pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs: one RCCL rank per device")
+def test_sharded_path_world2_rccl():
+    _run(2, "nccl", [(("mid", 2048, 1024, 3), (128, 128), True, 2, 4),
+                     (("g3", 1000, 333, 4), (480, 1), True, 2, 3),
+                     (("nat", 777, 130, 3), (64, 16), False, 1, 1),
+                     (("mid", 640, 360, 3), (64, 64), True, 3, 2, 1),
+                     (("g3", 8192, 2048, 3), (512, 1), True, 2, 4)], own_gpu=True)

@@ -162,3 +162,138 @@ def test_chunk_plan_covers_image():
         assert max(sizes) - min(sizes) <= 1
         flat = sorted(y for r in range(world) for y0, y1 in sharding.local_rows(h, th, world, r, cpr) for y in range(y0, y1))
         assert flat == list(range(h))
+
+
+# ---- failure agreement and untrusted tables (a lone raise before a collective hangs the others) -------------
+def _worker_faults(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+
+    import orc as orc_mod
+    from llcomp_amd import LlcompError, sharding
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        orc = orc_mod.Orc()
+        w, h, c, tw, th = 48, 24, 3, 16, 4
+        Band = oracle_band_factory(orc)
+
+        class FailingBand(Band):  # rank 1's coder reports an overflow
+            def encode(self, px):
+                payload, lens, total, status = super().encode(px)
+                if rank == 1:
+                    status = torch.tensor([1], dtype=torch.int32)
+                return payload, lens, total, status
+
+        full = np.stack([orc_mod.gen_mid(w, h, c), orc_mod.gen_g3(w, h, c, seed=9)])
+        mk = lambda factory, **kw: sharding.ShardedCodec(w, h, c, tw, th, True, images=2, device=torch.device("cpu"), band_factory=factory, **kw)  # noqa: E731
+        # 1. one rank's local encode fails: EVERY rank raises, before the payload collective
+        sc = mk(FailingBand)
+        try:
+            sc.encode(sc.take_local(full))
+            raise AssertionError("no error raised")
+        except LlcompError as e:
+            assert "rank 1" in str(e) and sc.exchanges == 0
+        dist.barrier()  # nobody is stuck in a collective
+        # 2. a container that does not belong to this geometry on ONE rank: every rank raises ValueError together
+        sc = mk(Band)
+        conts = sc.encode(sc.take_local(full))
+        bad = dict(conts)
+        if rank == 1:
+            for b in bad:
+                bad[b] = bad[b].clone()
+                bad[b][8] ^= 1  # width
+        try:
+            sc.decode(bad)
+            raise AssertionError("no error raised")
+        except ValueError as e:
+            assert "[1]" in str(e)
+        dist.barrier()
+        # 3. a damaged slice table (a length of 0xFFFFFFF0 = negative as int32, and one far beyond the container): sizes stay
+        #    bounded by the slice capacity, nothing is copied from outside the container, the decoder gets zero-filled bytes
+        dmg = dict(conts)
+        for b in dmg:
+            t = dmg[b].clone()
+            t[24:28] = torch.tensor([0xF0, 0xFF, 0xFF, 0xFF], dtype=torch.uint8)
+            t[32:36] = torch.tensor([0x00, 0x00, 0x00, 0x7F], dtype=torch.uint8)
+            dmg[b] = t
+        lens_seen = []
+        orig = sc.band.decode
+
+        def spy(payload, payload_bytes, lens, out):
+            lens_seen.append(lens.clone())
+            assert int(lens.min()) >= 0 and int(lens.max()) <= sc.slice_cap and payload_bytes <= sc.slice_cap * lens.numel()
+            out.zero_()
+            return torch.zeros(1, dtype=torch.int32)
+
+        sc.band.decode = spy
+        sc.decode(dmg)
+        sc.band.decode = orig
+        assert lens_seen and int(torch.stack([x.max() for x in lens_seen]).max()) <= sc.slice_cap
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_failures_are_agreed_before_collectives_and_tables_are_clamped():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_faults, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert res == [(0, "ok"), (1, "ok")], res
+
+
+def _worker_forced(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+
+    import orc as orc_mod
+    from llcomp_amd import sharding
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = orc_mod.Orc()
+        w, h, c, tw, th = 50, 21, 3, 16, 4
+        full = np.stack([orc_mod.gen_mid(w, h, c), orc_mod.gen_g3(w, h, c, seed=3)])
+        sc = sharding.ShardedCodec(w, h, c, tw, th, True, images=2, device=torch.device("cpu"), band_factory=oracle_band_factory(orc), force_exchange=True)
+        conts = sc.encode(sc.take_local(full))
+        assert sc.exchanges == 1  # the all_to_all ran although it is the identity at world 1
+        for b in range(2):
+            assert bytes(conts[b].numpy()) == orc.compress_sliced(full[b], tw, th, True)
+        out = sc.decode(conts)
+        assert sc.exchanges == 2 and np.array_equal(out.numpy(), full[sc.frame_images])
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world1_forced_exchange_runs_the_payload_collective():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_forced, args=(0, 1, _free_port(), q))
+    p.start()
+    p.join(120)
+    assert q.get(timeout=5) == (0, "ok")
