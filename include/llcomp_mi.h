@@ -89,9 +89,15 @@ int llcomp_mi_decode_into(const uint8_t* data, size_t len, int32_t device, uint8
                           uint32_t* h, uint32_t* c);
 /* The host-buffer calls keep a few idle coding lanes (GBs of HBM workspace for a 4K frame) for the next call of the same
  * shape, and the library parks the device memory of destroyed codecs / streams / lanes for reuse instead of returning it
- * to the driver (up to 64 GiB; released by itself when an allocation fails).  This releases both.  Codec and stream
- * objects in use are not touched. */
+ * to the driver (up to the pool limit per device; released by itself when an allocation OF THE LIBRARY fails).  This
+ * releases both.  Codec and stream objects in use are not touched.  A process that shares the GPU with another allocator
+ * (PyTorch's caching allocator, say) calls this when that allocator reports out-of-memory. */
 void llcomp_mi_trim(void);
+/* Parked device memory allowed PER DEVICE (default 16 GiB, or the environment's LLCOMP_MI_POOL_MAX_BYTES read once);
+ * blocks beyond it go back to the driver, largest first.  0 = park nothing: every release is a hipFree. */
+void llcomp_mi_set_pool_limit(uint64_t bytes_per_device);
+uint64_t llcomp_mi_pool_limit(void);
+uint64_t llcomp_mi_pool_idle_bytes(void); /* bytes parked right now, all devices */
 void* llcomp_mi_host_alloc(size_t bytes); /* pinned host memory, NULL on failure */
 void llcomp_mi_host_free(void* p);
 const char* llcomp_mi_strerror(int status);

@@ -83,6 +83,15 @@ def trim():
     _lib.load().llcomp_mi_trim()
 
 
+def set_pool_limit(bytes_per_device):
+    """Device memory the library may keep parked per device (csrc/devmem.hip); 0 = return every block to the driver."""
+    _lib.load().llcomp_mi_set_pool_limit(int(bytes_per_device))
+
+
+def pool_idle_bytes():
+    return int(_lib.load().llcomp_mi_pool_idle_bytes())
+
+
 def reload_tuning():
     """Have the library read its test / tuning hooks (LLCOMP_MI_*) from the environment again."""
     _lib.load().llcomp_mi_reload_tuning()

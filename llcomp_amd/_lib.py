@@ -6,7 +6,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libllcomp_mi.so")
+# LLCOMP_MI_LIB: load another build of the same sources instead (tools/clock_probe.py loads the diagnostic library with
+# in-kernel clock stamps, csrc/Makefile `probe`); the tests, bench.py and smoke() never set it
+LIB_PATH = os.environ.get("LLCOMP_MI_LIB") or os.path.join(_HERE, "libllcomp_mi.so")
 
 # every symbol include/llcomp_mi.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = [
@@ -22,6 +24,7 @@ SYMBOLS = [
     "llcomp_mi_stream_result_part", "llcomp_mi_stream_destroy", "llcomp_mi_stream_container_capacity",
     "llcomp_mi_stream_submit_encode", "llcomp_mi_stream_submit_decode", "llcomp_mi_stream_pending",
     "llcomp_mi_stream_poll", "llcomp_mi_stream_wait", "llcomp_mi_stream_release",
+    "llcomp_mi_set_pool_limit", "llcomp_mi_pool_limit", "llcomp_mi_pool_idle_bytes",
 ]
 
 u8p = C.POINTER(C.c_uint8)
@@ -134,6 +137,13 @@ def load():
     L.llcomp_mi_codec_create_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int32] + [C.c_uint32] * 8
     L.llcomp_mi_trim.restype = None
     L.llcomp_mi_trim.argtypes = []
+    if "LLCOMP_MI_LIB" not in os.environ or hasattr(L, "llcomp_mi_set_pool_limit"):  # (an A/B build of older sources may lack them)
+        L.llcomp_mi_set_pool_limit.restype = None
+        L.llcomp_mi_set_pool_limit.argtypes = [C.c_uint64]
+        L.llcomp_mi_pool_limit.restype = C.c_uint64
+        L.llcomp_mi_pool_limit.argtypes = []
+        L.llcomp_mi_pool_idle_bytes.restype = C.c_uint64
+        L.llcomp_mi_pool_idle_bytes.argtypes = []
     L.llcomp_mi_reload_tuning.restype = None
     L.llcomp_mi_reload_tuning.argtypes = []
     L.llcomp_mi_stream_create.restype = C.c_int

@@ -86,19 +86,26 @@ struct Timed {
     }
 };
 
+// the codec's completion event: recorded behind the last launch of a call, on the caller's stream
+void mark_done(llcomp_mi_codec* k, hipStream_t s) {
+    if (!k->done) k->done = llcomp_mi::make_done_event();
+    if (k->done && k->done->ev && hipEventRecord(k->done->ev, s) != hipSuccess) (void)hipGetLastError();
+}
+
 }  // namespace
 
 namespace llcomp_mi {
-// frees a codec whose work is known to be complete (the lanes synchronise their own stream instead of the whole device)
+// parks the codec's blocks behind the event of its last call (nothing waits here: whoever takes a block out of the cache
+// waits for that event; the lanes have drained their private stream before they get here anyway)
 void codec_release(llcomp_mi_codec* k) {
     if (!k) return;
     DeviceGuard guard(k->device);
-    dev_free(k->d_sym_or_rec);
-    dev_free(k->d_lane_order);
-    dev_free(k->d_states);
-    dev_free(k->d_scratch);
-    dev_free(k->d_group_off);
-    dev_free(k->d_total_tmp);
+    dev_free(k->d_sym_or_rec, k->done);
+    dev_free(k->d_lane_order, k->done);
+    dev_free(k->d_states, k->done);
+    dev_free(k->d_scratch, k->done);
+    dev_free(k->d_group_off, k->done);
+    dev_free(k->d_total_tmp, k->done);
     for (auto& sp : k->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     delete k;
 }
@@ -185,13 +192,9 @@ int llcomp_mi_codec_create_ex(llcomp_mi_codec** out, int32_t device, uint32_t fr
 }
 
 void llcomp_mi_codec_destroy(llcomp_mi_codec* k) {
-    if (!k) return;
-    {
-        // the buffers go back to the library's cache (devmem.hip), which does not wait for the device the way hipFree
-        // does: whatever the caller still has in flight on its streams must be done first
-        DeviceGuard guard(k->device);
-        (void)hipDeviceSynchronize();
-    }
+    // No device-wide wait: the blocks go back to the library's cache (devmem.hip) together with the event recorded behind
+    // the codec's last encode / decode, and are handed out again only after it.  Profiling events that were never read
+    // are destroyed by codec_release (hipEventDestroy of a pending event is legal: it is released when it completes).
     llcomp_mi::codec_release(k);
 }
 
@@ -245,6 +248,7 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
                                     static_cast<uint8_t*>(d_payload), payload_cap, static_cast<uint32_t*>(d_status), s));
     }
     ++k->n_encode;
+    mark_done(k, s);
     return LLCOMP_MI_OK;
 }
 
@@ -287,6 +291,7 @@ int llcomp_mi_codec_decode(llcomp_mi_codec* k, const void* d_payload, uint64_t p
         }
     }
     ++k->n_decode;
+    mark_done(k, s);
     return LLCOMP_MI_OK;
 }
 

@@ -4,11 +4,20 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "../../include/llcomp_mi.h"
 #include "geometry.hpp"
 #include "kernels.hpp"
+
+namespace llcomp_mi {
+struct DoneEvent {  // devmem.hip: completion event that travels with parked device blocks
+    hipEvent_t ev = nullptr;
+    ~DoneEvent();
+};
+std::shared_ptr<DoneEvent> make_done_event();
+}  // namespace llcomp_mi
 
 struct llcomp_mi_codec {
     llcomp_mi::Geometry g{};
@@ -27,6 +36,9 @@ struct llcomp_mi_codec {
     struct Span { hipEvent_t a, b; int slot; };
     std::vector<Span> spans;
     uint32_t n_encode = 0, n_decode = 0;
+    // recorded on the caller's stream behind the last launch of every encode / decode: the codec's device blocks are
+    // parked with it when the codec is destroyed (no device-wide wait on destroy)
+    std::shared_ptr<llcomp_mi::DoneEvent> done;
 };
 
 namespace llcomp_mi {
@@ -94,11 +106,14 @@ int lane_enqueue_decode(HostLane* l, uint64_t payload_bytes);
 void codec_release(llcomp_mi_codec* k);  // codec.hip: destroy without the device-wide wait (its work is known to be done)
 
 // devmem.hip: every device buffer of the library comes from here.  dev_alloc is hipMalloc on the current device through a
-// cache of parked blocks; dev_free parks a block (no device synchronisation: the caller makes sure nothing in flight
-// still uses it); dev_release_idle hands the parked blocks back to the driver.
+// cache of parked blocks; dev_free parks a block -- either the caller has made sure nothing in flight still uses it (the
+// lanes drain their private stream), or it passes the event behind the last use and the block is handed out again only
+// after that event; dev_release_idle hands the parked blocks back to the driver.
 hipError_t dev_alloc(void** p, uint64_t bytes);
-void dev_free(void* p);
+void dev_free(void* p, const std::shared_ptr<DoneEvent>& done = nullptr);  // done: reuse only after this event
 void dev_release_idle();
 uint64_t dev_idle_bytes();
+void dev_set_limit(uint64_t bytes_per_device);  // parked bytes allowed per device (0: every free goes to the driver)
+uint64_t dev_limit();
 
 }  // namespace llcomp_mi

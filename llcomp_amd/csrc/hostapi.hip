@@ -335,6 +335,10 @@ void llcomp_mi_trim(void) {
     dev_release_idle();
 }
 
+void llcomp_mi_set_pool_limit(uint64_t bytes_per_device) { dev_set_limit(bytes_per_device); }
+uint64_t llcomp_mi_pool_limit(void) { return dev_limit(); }
+uint64_t llcomp_mi_pool_idle_bytes(void) { return dev_idle_bytes(); }
+
 void* llcomp_mi_host_alloc(size_t bytes) {
     void* p = nullptr;
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;

@@ -25,6 +25,35 @@ namespace llcomp_mi {
 
 namespace {
 
+// ---- diagnostic build only (make probe: -DLLMI_CLOCK_PROBE, a separate library that is never shipped or benchmarked) -----
+// In-kernel shader clock of the two slice kernels, the way /opt/skills/guides/MI355X_MICROARCH.md prescribes: every
+// wavefront stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) when it starts coding and when it is done; the
+// quotient of the differences x 100 MHz is the clock it ran at.  The stamps go to a buffer of their own that no kernel
+// reads; no output depends on them.  The product build contains none of this.
+#ifdef LLMI_CLOCK_PROBE
+constexpr uint32_t kProbeSlots = 1u << 15;
+__device__ unsigned long long g_probe[2][kProbeSlots][2];  // [kernel: 0 encode / 1 decode][block & mask][shader ticks, 100 MHz ticks]
+struct ProbeStamp {
+    unsigned long long t, r;
+    __device__ __forceinline__ void start() {
+        t = __builtin_amdgcn_s_memtime();
+        r = __builtin_amdgcn_s_memrealtime();
+    }
+    __device__ __forceinline__ void stop(int kernel) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) {
+            g_probe[kernel][blockIdx.x & (kProbeSlots - 1)][0] = t1 - t;
+            g_probe[kernel][blockIdx.x & (kProbeSlots - 1)][1] = r1 - r;
+        }
+    }
+};
+#define LLMI_PROBE_START() ProbeStamp probe_stamp; probe_stamp.start()
+#define LLMI_PROBE_STOP(kernel) probe_stamp.stop(kernel)
+#else
+#define LLMI_PROBE_START() do {} while (0)
+#define LLMI_PROBE_STOP(kernel) do {} while (0)
+#endif
+
 // ---- model table ------------------------------------------------------------------------------------------------
 // entry = entry_lo | entry_hi << 32 (tables.hpp), always moved as ONE 64-bit LDS access
 using entry_t = unsigned long long;
@@ -350,8 +379,6 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     __shared__ entry_t tab[128];
     __shared__ __attribute__((aligned(32))) uint8_t ring[kRingBytes * 64];
     __shared__ unsigned long long rowbank[ROWS ? 3 * 64 : 1];
-    __shared__ unsigned long long wave_bytes;  // sum of this wavefront's stream lengths (see k_scan_groups)
-    if (threadIdx.x == 0) wave_bytes = 0;
     clear_lds_states<LDSTAB>();
     load_table(tab);
     const uint32_t id = blockIdx.x * lpw + threadIdx.x;
@@ -372,6 +399,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     const size_t GW = size_t(1) << g.lane_shift;  // distance between consecutive samples of this slice
     const uint32_t total = n_row * r.sh;
     bool hot = false;  // wave-uniform: most lanes had a non-zero residual last time
+    LLMI_PROBE_START();
 
     if constexpr (ROWS) {
         // contexts 0 / 605 / 1210 only: their state bytes sit in LDS, [context][lane] (a read + a write per sample
@@ -441,17 +469,24 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
         }
     }
     enc_finish(e);
+    LLMI_PROBE_STOP(0);
     if (e.pos > e.cap) {
         atomicOr(status, kStOverflow);
         e.pos = e.cap;
     }
     slice_len[id] = uint32_t(e.pos);
     // When a wavefront holds exactly one lane group (the normal case) it leaves the group's byte count behind: the
-    // global scan then runs over one value per group instead of one per slice.  The lanes have reconverged here; LDS
-    // operations of one wavefront execute in order, so lane 0 reads the finished sum.
+    // global scan then runs over one value per group instead of one per slice.  The sum is formed with v_readlane over
+    // the lanes that are active HERE (a convergent operation with a defined result per lane: no shared-memory hand-off
+    // between lanes whose order would rest on how the compiler lays out the reconverged paths above).
     if (group_sum) {
-        atomicAdd(&wave_bytes, (unsigned long long)uint32_t(e.pos));
-        if (threadIdx.x == 0) group_sum[blockIdx.x] = wave_bytes;
+        unsigned long long live = __ballot(1), sum = 0;
+        while (live) {
+            const int lane = __builtin_ctzll(live);
+            sum += uint32_t(__builtin_amdgcn_readlane(e.pos, lane));
+            live &= live - 1;
+        }
+        if (threadIdx.x == 0) group_sum[blockIdx.x] = sum;
     }
 }
 
@@ -718,6 +753,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
     // the same through a wave-uniform base + 32-bit element offset (one store instruction, no 64-bit address math)
     int16_t* const gbase = rec + ((size_t(grp) * g.slice_samples) << g.lane_shift);
     bool hot = false;
+    LLMI_PROBE_START();
 
     if constexpr (ROWS) {
         // one-row slice (llcomp.hpp:494-509 with h == 0): l = left (128 at the start), everything above = l, so
@@ -862,9 +898,23 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
         }
         }
     }
+    LLMI_PROBE_STOP(1);
 }
 
 }  // namespace
+
+#ifdef LLMI_CLOCK_PROBE
+// diagnostic library only: copies the stamps out (u64[2][slots][2]) and clears them; returns the slot count
+extern "C" uint32_t llcomp_mi_probe_read(unsigned long long* out) {
+    if (out) {
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), sizeof(g_probe));
+        static unsigned long long zeros[2][kProbeSlots][2];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe), zeros, sizeof(g_probe));
+    }
+    return kProbeSlots;
+}
+#endif
 
 // (channels per slice, 1-row slices, state table in LDS) -> template instance
 #define LLMI_DISPATCH_SLICE(nch, rows, lds, ...)                                                             \
