@@ -64,6 +64,20 @@ def make_frames(content, frames, rank, w=W4K, h=H4K, c=C4K, distinct=None):
     return out
 
 
+def host_cpu():
+    """model name and logical CPU count of the host the CPU legs run on"""
+    name = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                name = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return f"{name} ({os.cpu_count()} logical CPUs, {usable} usable by this process)"
+
+
 def cpu_baseline(img, label, tile_w, tile_h, planar, same_slicing=False):
     """Time the CPU path on ONE frame, single thread.  kind 'reference' = the real llcomp.hpp compiled in place
     (oracle/_ref, whole-image stream: O2 encode + unmodified decompressImage); kind 'port' = the plain-C restatement
@@ -92,7 +106,7 @@ def cpu_baseline(img, label, tile_w, tile_h, planar, same_slicing=False):
         t2 = time.perf_counter()
         assert rc == 0 and np.array_equal(px, img)
         kind, sample = "port", f"1 frame {label}, same slicing, plain-C oracle (enc {t1 - t0:.2f}s + dec {t2 - t1:.2f}s)"
-    res = {"value": round(w * h / 1e6 / (t2 - t0), 4), "unit": "MPix/s", "cores": 1, "kind": kind, "sample": sample}
+    res = {"value": round(w * h / 1e6 / (t2 - t0), 4), "unit": "MPix/s", "cores": 1, "kind": kind, "sample": sample, "cpu": host_cpu()}
     if kind == "reference" and same_slicing:
         # like for like: the plain-C port on the SAME slicing the GPU codes (same container bytes, same ratio), one thread
         orc = orc_mod.Orc()
@@ -175,7 +189,11 @@ def measure(frames_np, tile_w, tile_h, planar, streams, steps, warmup, local_ran
         p["total"] = int(p["tot"].item())
     total = sum(p["total"] for p in parts)
     spf0 = parts[0]["codec"].n_slices // parts[0]["n"]
-    frame0_container = 24 + 4 * spf0 + int(parts[0]["len"][:spf0].to(torch.int64).sum().item())  # bytes of frame 0's container
+    frame0_payload = int(parts[0]["len"][:spf0].to(torch.int64).sum().item())
+    frame0_container = 24 + 4 * spf0 + frame0_payload  # bytes of frame 0's container
+    # ... and its FNV-1a-64, as the golden vectors record it: [24-byte header][u32 slice table][payload]
+    head0 = bytes([0x9C, 1, c, 1 if planar else 0]) + b"".join(int(v).to_bytes(4, "little") for v in (w, h, min(tile_w or w, w), min(tile_h or h, h), spf0))
+    frame0_fnv = mi.fnv1a64(head0, parts[0]["len"][:spf0].cpu().numpy().astype("<u4").view("uint8"), parts[0]["pay"][:frame0_payload].cpu().numpy())
     for _ in range(max(0, warmup - 1)):
         step()
     torch.cuda.synchronize()
@@ -224,7 +242,7 @@ def measure(frames_np, tile_w, tile_h, planar, streams, steps, warmup, local_ran
     torch.cuda.empty_cache()
     container_bytes = total + 24 * F + 4 * n_slices  # per-frame container headers + slice tables
     return dict(dt=dt, steps=steps, F=F, S=S, w=w, h=h, c=c, n_slices=n_slices, payload=total, container_bytes=container_bytes,
-                raw_bytes=int(frames_np.size), prof=prof, frame0_container=frame0_container, n_enc=n_enc, n_dec=n_dec, iso=iso, iso_enc=iso_enc, iso_dec=iso_dec,
+                raw_bytes=int(frames_np.size), prof=prof, frame0_container=frame0_container, frame0_fnv=frame0_fnv, n_enc=n_enc, n_dec=n_dec, iso=iso, iso_enc=iso_enc, iso_dec=iso_dec,
                 mpix=F * w * h * steps / dt / 1e6, ratio=frames_np.size / container_bytes)
 
 
@@ -736,9 +754,11 @@ def main():
         gold = [v for v in json.load(open(os.path.join(ROOT, "tests", "golden", "slice_payloads.json")))["vectors"]
                 if (v["gen"], v["w"], v["tile_w"], v["tile_h"], v["planar"]) == (args.content, W4K, args.tile_w, args.tile_h, planar)]
         if gold and args.content in ("g3", "g2"):  # frame 0 of these two IS the golden vector's image (mid / nat use other seeds here)
-            res["golden_pin"] = {"frame0_container_bytes": m["frame0_container"], "reference": gold[0]["container_len"],
-                                 "match": m["frame0_container"] == gold[0]["container_len"]}
-            assert res["golden_pin"]["match"], "frame 0's container length differs from the reference's"
+            res["golden_pin"] = {"frame0_container_bytes": m["frame0_container"], "reference_bytes": gold[0]["container_len"],
+                                 "frame0_container_fnv1a64": m["frame0_fnv"], "reference_fnv1a64": gold[0]["container_fnv1a64"],
+                                 "match": m["frame0_container"] == gold[0]["container_len"] and m["frame0_fnv"] == gold[0]["container_fnv1a64"],
+                                 "source": "tests/golden/slice_payloads.json (container assembled from the real reference's per-slice streams)"}
+            assert res["golden_pin"]["match"], "frame 0's container differs from the reference's (length or FNV-1a-64)"
     except OSError:
         pass
     if not args.no_also:
@@ -777,9 +797,25 @@ def main():
                                                                state_bank_rmw_per_s=round(samples / m2["dt"] / 1e9, 2), rmw_ceiling=RMW_CEILING / 1e9,
                                                                frac_of_random_access_ceiling=round(samples / m2["dt"] / RMW_CEILING, 3))
 
-        def leg_latency():  # latency of ONE frame
+        def leg_latency():  # latency of ONE frame: at the throughput slicing, and at the width the library suggests for one frame per call
             m1 = measure(frames_np[:1], args.tile_w, args.tile_h, planar, 1, 20, 2, local_rank)
             also["one_frame_latency"] = brief(m1, workload=f"1 frame 4K {args.content}, {args.tile_w}x{args.tile_h} planar", ms_enc_plus_dec=round(m1["dt"] / m1["steps"] * 1e3, 3))
+            tw1 = mi.suggest_tile_w(1, W4K, H4K, C4K, planar)
+            m1s = measure(frames_np[:1], tw1, 1, planar, 1, 20, 2, local_rank)
+            also["one_frame_latency_suggested_tile_w"] = brief(m1s, workload=f"1 frame 4K {args.content}, {tw1}x1 planar (llcomp_mi_suggest_tile_w for one frame per call)",
+                                                               tile_w=tw1, ms_enc_plus_dec=round(m1s["dt"] / m1s["steps"] * 1e3, 3))
+
+        def leg_c2():  # BASELINE config 2: 1920x1080 RGB8 noise, ONE SLICE PER ROW, one frame and a batch of 32
+            c2 = make_frames("g3", 32, 0, w=1920, h=1080, c=3, distinct=8)
+            out = {}
+            for label, pl in (("interleaved", False), ("planar", True)):
+                one = measure(c2[:1], 1920, 1, pl, 1, 20, 2, local_rank)
+                many = measure(c2, 1920, 1, pl, 2, sub, 1, local_rank)
+                out[label] = {"one_frame": brief(one, ms_enc_plus_dec=round(one["dt"] / one["steps"] * 1e3, 3), slices=one["n_slices"]),
+                              "batch_32_frames": brief(many, slices=many["n_slices"])}
+            out["workload"] = ("C2 1920x1080 RGB8 std::mt19937 noise, one slice per row (1920x1): 1080 slices per frame with the channels interleaved "
+                               "(payload of a slice == reference stream of that row), 3240 as per-channel planes; one frame = 17 / 51 wavefronts on 1024 SIMDs")
+            also["c2_rows_1080p"] = out
 
         def leg_legacy():  # the reference's own format in bulk: 512 whole-image streams (one lane each) of 256x256 RGB8
             leg = make_frames("mid", 512, 0, w=256, h=256, c=3, distinct=16)
@@ -791,7 +827,7 @@ def main():
         # 4.8-5.2 GPix/s when its pinned buffers are allocated behind config 4's 150 GB; then BASELINE config 4 on one GPU =
         # the N = 1 point of the strong-scaling curve), before the allocate / free cycles of the others fragment HBM.  A secondary leg that fails is
         # reported as such; it never costs the headline line.
-        for name, fn in (("c5", leg_c5), ("c4", leg_c4), ("contents", leg_contents), ("tiles", leg_tiles), ("latency", leg_latency), ("legacy", leg_legacy)):
+        for name, fn in (("c5", leg_c5), ("c4", leg_c4), ("contents", leg_contents), ("tiles", leg_tiles), ("latency", leg_latency), ("c2", leg_c2), ("legacy", leg_legacy)):
             if not want(name):
                 continue
             try:

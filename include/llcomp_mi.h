@@ -118,6 +118,13 @@ typedef struct llcomp_mi_info {
 } llcomp_mi_info;
 int llcomp_mi_probe(const uint8_t* data, size_t len, llcomp_mi_info* info);
 uint32_t llcomp_mi_slice_count(uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar);
+/* Slice width for one-row slices (tile_h = 1) when `frames` frames are coded per call: the widest slice (64..480 pixels) that
+ * still keeps about four wavefronts per SIMD busy.  A call that codes few frames is latency-bound with wide slices; this
+ * trades a little compression (fresh models per slice) for it.  Returns 0 for nonsense arguments. */
+uint32_t llcomp_mi_suggest_tile_w(uint32_t frames, uint32_t w, uint32_t h, uint32_t c, uint32_t planar);
+/* FNV-1a-64 of a byte range (the checksum tests/golden records containers in); seed 0 starts a hash, a previous result
+ * continues it over the next piece (header, slice table and payload of a container that lies in three buffers). */
+uint64_t llcomp_mi_fnv1a64(const uint8_t* data, size_t len, uint64_t seed);
 /* Concatenator for multi-GPU sharding: `bands` are SLICED containers of consecutive horizontal bands of one
  * image (same width/channels/tile/planar; every band but the last a multiple of tile_h rows, because slices
  * have slice-local borders a band's slices ARE the full image's slices).  Produces the container of the whole

@@ -329,6 +329,23 @@ def probe(data):
     return info
 
 
+def fnv1a64(*pieces):
+    """FNV-1a-64 over the concatenation of `pieces` (bytes or contiguous numpy uint8 arrays), as a 16-digit hex string --
+    the form tests/golden records container hashes in."""
+    L = _lib.load()
+    h = 0
+    for p in pieces:
+        a = np.frombuffer(p, dtype=np.uint8) if isinstance(p, (bytes, bytearray, memoryview)) else np.ascontiguousarray(p, dtype=np.uint8).reshape(-1)
+        if a.size:
+            h = L.llcomp_mi_fnv1a64(a.ctypes.data, a.size, h)
+    return "%016x" % (h or 1469598103934665603)
+
+
+def suggest_tile_w(frames, w, h, c, planar=True):
+    """slice width for one-row slices that keeps the GPU busy when `frames` frames are coded per call (llcomp_mi_suggest_tile_w)"""
+    return int(_lib.load().llcomp_mi_suggest_tile_w(frames, w, h, c, int(bool(planar))))
+
+
 def slice_count(w, h, c, tile_w=0, tile_h=0, planar=False):
     return _lib.load().llcomp_mi_slice_count(w, h, c, tile_w, tile_h, int(bool(planar)))
 

@@ -24,7 +24,7 @@ SYMBOLS = [
     "llcomp_mi_stream_result_part", "llcomp_mi_stream_destroy", "llcomp_mi_stream_container_capacity",
     "llcomp_mi_stream_submit_encode", "llcomp_mi_stream_submit_decode", "llcomp_mi_stream_pending",
     "llcomp_mi_stream_poll", "llcomp_mi_stream_wait", "llcomp_mi_stream_release",
-    "llcomp_mi_set_pool_limit", "llcomp_mi_pool_limit", "llcomp_mi_pool_idle_bytes",
+    "llcomp_mi_set_pool_limit", "llcomp_mi_pool_limit", "llcomp_mi_pool_idle_bytes", "llcomp_mi_fnv1a64", "llcomp_mi_suggest_tile_w",
 ]
 
 u8p = C.POINTER(C.c_uint8)
@@ -144,6 +144,12 @@ def load():
         L.llcomp_mi_pool_limit.argtypes = []
         L.llcomp_mi_pool_idle_bytes.restype = C.c_uint64
         L.llcomp_mi_pool_idle_bytes.argtypes = []
+    if "LLCOMP_MI_LIB" not in os.environ or hasattr(L, "llcomp_mi_fnv1a64"):
+        L.llcomp_mi_fnv1a64.restype = C.c_uint64
+        L.llcomp_mi_fnv1a64.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+    if "LLCOMP_MI_LIB" not in os.environ or hasattr(L, "llcomp_mi_suggest_tile_w"):
+        L.llcomp_mi_suggest_tile_w.restype = C.c_uint32
+        L.llcomp_mi_suggest_tile_w.argtypes = [C.c_uint32] * 5
     L.llcomp_mi_reload_tuning.restype = None
     L.llcomp_mi_reload_tuning.argtypes = []
     L.llcomp_mi_stream_create.restype = C.c_int

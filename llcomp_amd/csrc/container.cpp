@@ -31,6 +31,35 @@ using namespace llcomp_mi;
 
 extern "C" {
 
+// FNV-1a-64 (offset 1469598103934665603, prime 1099511628211): the checksum the golden vectors of this project are
+// recorded in; `seed` = 0 starts a new hash, the previous result continues one over several pieces.
+uint64_t llcomp_mi_fnv1a64(const uint8_t* data, size_t len, uint64_t seed) {
+    uint64_t h = seed ? seed : 1469598103934665603ull;
+    for (size_t i = 0; i < len; ++i) h = (h ^ data[i]) * 1099511628211ull;
+    return h;
+}
+
+// Width of one-row slices (tile_h == 1) for a call that codes `frames` frames at once: the widest slice that still gives
+// the GPU about four wavefronts per SIMD (1024 SIMDs x 64 lanes x 4 = 262 144 slices), never narrower than 64 pixels
+// (narrow slices cost compression: every slice starts with fresh models) and never wider than 480 (the throughput
+// default of bench.py).  Few-frame calls are latency-bound with wide slices: one 4K frame in 480x1 planes is 51 840
+// slices = 0.8 wavefronts per SIMD (2.1 ms); the width this returns, 96, gives 4 per SIMD.
+uint32_t llcomp_mi_suggest_tile_w(uint32_t frames, uint32_t w, uint32_t h, uint32_t c, uint32_t planar) {
+    if (!frames || !w || !h || !c) return 0;
+    const uint64_t target = 262144;
+    const uint64_t rows = uint64_t(frames) * h * (planar ? c : 1);  // slices per tile column
+    uint64_t cols = (target + rows - 1) / rows;                     // tile columns wanted
+    if (cols < 1) cols = 1;
+    uint64_t tw = (w + cols - 1) / cols;
+    if (tw > 480) tw = 480;
+    if (tw < 64) tw = 64;
+    if (tw > w) tw = w;
+    // prefer a width that divides the image width when one is near (no ragged last column)
+    for (uint64_t d = tw; 4 * d >= 3 * tw && d >= 64; --d)
+        if (w % d == 0) return uint32_t(d);
+    return uint32_t(tw);
+}
+
 uint32_t llcomp_mi_slice_count(uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar) {
     Geometry g;
     if (!make_geometry(g, 1, w, h, c, tile_w, tile_h, planar)) return 0;

@@ -127,6 +127,26 @@ def slice_payloads(ref):
     return out
 
 
+def c4_bench_slicing(ref):
+    """BASELINE config 4 at the slicing bench.py and the sharded path use (8192 x 8192 RGB8 noise, per-channel planes,
+    512x1): the container assembled from the real reference's per-slice streams, as length + hash (393 216 slices)."""
+    name, w, h, c, tw, th = "g3", 8192, 8192, 3, 512, 1
+    img = special(name, w, h, c)
+    planes = ref.o2_forward_rct(img)
+    pays = []
+    for y0 in range(h):
+        row = planes[y0]
+        for x0 in range(0, w, tw):
+            for k in range(c):
+                pays.append(ref.o2_encode_samples(np.ascontiguousarray(row[None, x0:x0 + tw, k:k + 1])))
+        if y0 % 512 == 511:
+            print("c4 rows", y0 + 1, flush=True)
+    cont = container(w, h, c, tw, th, True, pays)
+    lens = np.array([len(p) for p in pays], dtype=np.uint32)
+    return [{"gen": name, "w": w, "h": h, "c": c, "tile_w": tw, "tile_h": th, "planar": True, "n_slices": len(pays), "container_len": len(cont),
+             "container_fnv1a64": fnv(cont), "payload_bytes": int(lens.sum()), "slice_table_fnv1a64": fnv(lens.astype("<u4").tobytes())}]
+
+
 def small_model(ref_small):
     """The bitstream of a reference built with LargeModel = false (oracle/_ref/libllcomp_ref_small.so): legacy streams
     (O1 where defined, else O2) and sliced containers assembled from that reference's per-slice payloads."""
@@ -250,6 +270,10 @@ def main():
         with open(os.path.join(OUT, fn), "w") as f:
             json.dump({"meta": meta, "vectors": make(ref)}, f, indent=1)
         print("wrote", fn)
+    if "c4" in only:  # (minutes of single-thread reference coding: only on request)
+        with open(os.path.join(OUT, "c4_bench_slicing.json"), "w") as f:
+            json.dump({"meta": meta, "vectors": c4_bench_slicing(ref)}, f, indent=1)
+        print("wrote c4_bench_slicing.json")
     if not only or "small" in only:
         from orc import REF_SMALL_PATH
 

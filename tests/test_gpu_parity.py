@@ -121,7 +121,7 @@ def test_small_model_equals_reference_built_with_largemodel_false(mi, orc, v):
     img = make_image(v["gen"], v["w"], v["h"], v["c"])
     if v["kind"] == "legacy":
         if v["w"] * v["h"] > 700 * 400:
-            pytest.skip("a lone serial stream of this size takes seconds on one GPU lane; the smaller vectors cover the path")
+            pytest.skip("a lone serial stream of this size takes seconds on one GPU lane: test_small_model_large_legacy_streams (slow) runs it")
         s = mi.compress_image(img, v["w"], v["h"], v["c"], small_model=True)
         assert len(s) == v["len"] and fnv_hex(orc, s) == v["fnv1a64"]
         if "hex" in v:
@@ -137,6 +137,16 @@ def test_small_model_equals_reference_built_with_largemodel_false(mi, orc, v):
         assert len(s) == v["container_len"] and fnv_hex(orc, s) == v["container_fnv1a64"]
         assert mi.probe(s).small_model == 1
         assert np.array_equal(mi.decompress_image(s).pixels, img)  # the container says which model wrote it
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("v", [v for v in SMALL if v["kind"] == "legacy" and v["w"] * v["h"] > 700 * 400], ids=lambda v: _id(v))
+def test_small_model_large_legacy_streams(mi, orc, v):
+    """the 1080p whole-image streams of the LargeModel = false reference: one GPU lane each, seconds per stream"""
+    img = make_image(v["gen"], v["w"], v["h"], v["c"])
+    s = mi.compress_image(img, v["w"], v["h"], v["c"], small_model=True)
+    assert len(s) == v["len"] and fnv_hex(orc, s) == v["fnv1a64"]
+    assert np.array_equal(mi.decompress_image(s, small_model=True).pixels, img)
 
 
 # ---- decoder behaviour on damaged streams == the real reference's ------------------------------------------------

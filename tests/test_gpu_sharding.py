@@ -27,6 +27,24 @@ def _free_port():
     return p
 
 
+def _golden_container(gen, w, h, c, tw, th, planar):
+    import json
+
+    for v in json.load(open(os.path.join(ROOT, "tests", "golden", "c4_bench_slicing.json")))["vectors"]:
+        if (v["gen"], v["w"], v["h"], v["c"], v["tile_w"], v["tile_h"], v["planar"]) == (gen, w, h, c, tw, th, planar):
+            return v
+    return None
+
+
+def _oracle_container(img, tw, th, planar):
+    """the checker's container of a small image (the big cases fall back to the one-piece HIP container, which the parity
+    tests pin elsewhere)"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc as orc_mod
+
+    return orc_mod.Orc().compress_sliced(img, tw, th, planar)
+
+
 def _worker(rank, world, backend, port, cases, q, own_gpu=False, force=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
@@ -53,8 +71,18 @@ def _worker(rank, world, backend, port, cases, q, own_gpu=False, force=False):
             conts = sc.encode(band)
             assert sorted(conts) == [b for b in range(images) if (b % world if root is None else root) == rank]   # spread round-robin, or funnelled
             for b in conts:
-                want = mi.compress_image(full[b], w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar, device=ordinal)
-                assert conts[b].is_cuda and bytes(conts[b].cpu().numpy()) == want, f"{gen} {w}x{h}: image {b} differs from the one-piece container"
+                assert conts[b].is_cuda
+                gold = _golden_container(gen, w, h, c, tw, th, planar) if b == 0 else None
+                if gold is not None:
+                    # BASELINE config 4 at the benchmarked slicing: against the container assembled from the REAL reference's
+                    # per-slice streams (tests/golden/c4_bench_slicing.json, oracle/gen_golden.py c4) -- not against another HIP result
+                    host = conts[b].cpu().numpy()
+                    assert host.size == gold["container_len"], f"{gen} {w}x{h}: {host.size} bytes, the reference's container has {gold['container_len']}"
+                    assert mi.fnv1a64(host) == gold["container_fnv1a64"], f"{gen} {w}x{h}: sharded container differs from the reference's"
+                    continue
+                want = _oracle_container(full[b], tw, th, planar) if w * h * c <= 4_000_000 else \
+                    mi.compress_image(full[b], w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar, device=ordinal)
+                assert bytes(conts[b].cpu().numpy()) == want, f"{gen} {w}x{h}: image {b} differs from the one-piece container"
             out = sc.decode(conts)
             assert out.is_cuda and torch.equal(out, band), "decoded rows differ from the source rows"
             px = sc.gather_pixels(out)
@@ -98,7 +126,8 @@ def test_sharded_path_world2_hip_coder_gloo_exchange():
                      (("g3", 1000, 333, 4), (480, 1), True, 2, 3),
                      (("nat", 777, 130, 3), (64, 16), False, 1, 1),
                      (("mid", 640, 360, 3), (64, 64), True, 3, 2, 1),                 # every container funnelled to rank 1
-                     (("g3", 8192, 2048, 3), (480, 1), True, 1, 4)])      # a quarter of config 4, noise
+                     (("g3", 8192, 2048, 3), (480, 1), True, 1, 4),       # a quarter of config 4, noise
+                     (("g3", 8192, 8192, 3), (512, 1), True, 1, 4)])      # config 4 itself at the benchmarked slicing: golden from the real reference
 
 
 def test_sharded_path_world1_rccl_forced_alltoallv():
@@ -106,7 +135,8 @@ def test_sharded_path_world1_rccl_forced_alltoallv():
     _run(1, "nccl", [(("mid", 2048, 1024, 3), (128, 128), True, 2, 4),
                      (("g3", 1000, 333, 4), (480, 1), True, 3, 4),
                      (("nat", 777, 130, 3), (64, 16), False, 1, 1),
-                     (("g3", 8192, 2048, 3), (512, 1), True, 2, 4)], force=True)
+                     (("g3", 8192, 2048, 3), (512, 1), True, 2, 4),
+                     (("g3", 8192, 8192, 3), (512, 1), True, 1, 4)], force=True)   # BASELINE config 4, benchmarked slicing: golden from the real reference
 
 
 def _gpus():
@@ -121,4 +151,5 @@ def test_sharded_path_world2_rccl():
                      (("g3", 1000, 333, 4), (480, 1), True, 2, 3),
                      (("nat", 777, 130, 3), (64, 16), False, 1, 1),
                      (("mid", 640, 360, 3), (64, 64), True, 3, 2, 1),
-                     (("g3", 8192, 2048, 3), (512, 1), True, 2, 4)], own_gpu=True)
+                     (("g3", 8192, 2048, 3), (512, 1), True, 2, 4),
+                     (("g3", 8192, 8192, 3), (512, 1), True, 1, 4)], own_gpu=True)

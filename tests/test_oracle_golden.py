@@ -47,6 +47,17 @@ def test_legacy_stream_c4_gradient(orc):
     assert len(s) == v["len"] and fnv_hex(orc, s) == v["fnv1a64"]
 
 
+@pytest.mark.slow
+def test_c4_benchmarked_slicing_equals_reference_payloads(orc):
+    """BASELINE config 4 at the slicing bench.py and the sharded path use (8192^2 noise, planar 512x1, 393 216 slices): the
+    oracle's container == the container assembled from the real reference's per-slice streams."""
+    v = load_golden("c4_bench_slicing.json")["vectors"][0]
+    s = orc.compress_sliced(make_image(v["gen"], v["w"], v["h"], v["c"]), v["tile_w"], v["tile_h"], v["planar"])
+    assert len(s) == v["container_len"] and fnv_hex(orc, s) == v["container_fnv1a64"]
+    n = v["n_slices"]
+    assert fnv_hex(orc, bytes(s[24:24 + 4 * n])) == v["slice_table_fnv1a64"]
+
+
 @pytest.mark.parametrize("v", SLC, ids=_id)
 def test_sliced_container_equals_reference_payloads(orc, v):
     img = make_image(v["gen"], v["w"], v["h"], v["c"])
