@@ -38,7 +38,11 @@ sys.path.insert(0, ROOT)
 W4K, H4K, C4K = 3840, 2160, 3
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK = 1024 * 2.4e9 / 2  # wave-instructions/s: 256 CUs x 4 SIMDs, one VALU instruction per 2 cycles at 2.4 GHz
-RMW_CEILING = 22.0e9       # random 8-byte read-modify-writes/s into multi-GB tables: tools/ubench/rand_table.hip, profiles/r02_rand_table.txt
+RMW_UBENCH = 24.06e9       # uniformly random dependent 8-byte read-modify-writes/s into 12.4 GB of per-lane tables at the wavefront count
+                           # of the 2-D tile legs (3060): tools/ubench/rand_table.hip, profiles/r03_rand_table.txt.  NOT a ceiling for
+                           # the kernels: their contexts are not uniformly random (lanes share lines, the decoder skips unchanged banks)
+TILE_HBM_BYTES_PER_SAMPLE = {"g3": 141.0, "nat": 156.0}  # (2 x FETCH_SIZE + WRITE_SIZE) of k_encode_slices + k_decode_slices / (2 x samples), the guide's gfx950
+                                                         # correction applied: profiles/r03_tiles64_f16_{g3,nat}_pmc_summary.txt (g3: 131 encode, 151 decode; nat: 147, 165)
 
 
 def make_frames(content, frames, rank, w=W4K, h=H4K, c=C4K, distinct=None):
@@ -792,10 +796,16 @@ def main():
             for content in ("nat", "mid", "g3"):
                 fr = frames_np[:16] if content == args.content else make_frames(content, 16, 0, distinct=4)
                 m2 = measure(fr, 64, 64, True, 2, sub, 1, local_rank)
-                samples = 2 * 16 * W4K * H4K * C4K * m2["steps"]  # one state-bank read-modify-write per sample and direction
-                also[f"{content}_tiles64x64_16frames"] = brief(m2, workload=f"16 frames 4K {content}, 64x64 planar tiles, state tables in HBM",
-                                                               state_bank_rmw_per_s=round(samples / m2["dt"] / 1e9, 2), rmw_ceiling=RMW_CEILING / 1e9,
-                                                               frac_of_random_access_ceiling=round(samples / m2["dt"] / RMW_CEILING, 3))
+                samples = 2 * 16 * W4K * H4K * C4K * m2["steps"]  # at most one state-bank read-modify-write per sample and direction
+                extra = {}
+                if content in TILE_HBM_BYTES_PER_SAMPLE:  # HBM-side traffic of the slice kernels from the committed PMC passes of this leg's configuration
+                    gbs = TILE_HBM_BYTES_PER_SAMPLE[content] * samples / m2["dt"] / 1e9
+                    extra = {"hbm_bytes_per_sample": TILE_HBM_BYTES_PER_SAMPLE[content], "hbm_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 3)}
+                also[f"{content}_tiles64x64_16frames"] = brief(m2, workload=f"16 frames 4K {content}, 64x64 planar tiles, state tables in HBM (tagged with the call's generation, not cleared per call)",
+                                                               samples_per_s=round(samples / m2["dt"] / 1e9, 2), uniform_random_rmw_ubench=RMW_UBENCH / 1e9,
+                                                               ratio_to_uniform_random_rmw=round(samples / m2["dt"] / RMW_UBENCH, 3), **extra,
+                                                               note="bound by random state-bank transactions (one 128-byte line fill + partial write-back per sample), not by bytes: "
+                                                                    "ratio_to_uniform_random_rmw compares with a microbenchmark that does nothing else, at the same wavefront count and table size")
 
         def leg_latency():  # latency of ONE frame: at the throughput slicing, and at the width the library suggests for one frame per call
             m1 = measure(frames_np[:1], args.tile_w, args.tile_h, planar, 1, 20, 2, local_rank)

@@ -86,6 +86,19 @@ struct Timed {
     }
 };
 
+// State tables in HBM are tagged with the generation of the call that wrote them instead of being cleared per call
+// (kernels.hpp): a real clear happens before the first call and whenever the 8-bit generation would repeat.
+int next_state_generation(llcomp_mi_codec* k, hipStream_t s) {
+    if (!k->need_states) return LLCOMP_MI_OK;
+    if (k->state_generation == 0 || k->state_generation >= 255) {
+        const Geometry& g = k->g;
+        HIP_TRY(hipMemsetAsync(k->d_states, 0, (uint64_t(lane_groups(g)) * kContexts << g.lane_shift) * 8, s));
+        k->state_generation = 0;
+    }
+    ++k->state_generation;
+    return LLCOMP_MI_OK;
+}
+
 // the codec's completion event: recorded behind the last launch of a call, on the caller's stream
 void mark_done(llcomp_mi_codec* k, hipStream_t s) {
     if (!k->done) k->done = llcomp_mi::make_done_event();
@@ -223,7 +236,7 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
     HIP_TRY(hipMemsetAsync(d_status, 0, 4, s));
     {
         Timed t(k, s, 0);
-        if (k->need_states) HIP_TRY(hipMemsetAsync(k->d_states, 0, (uint64_t(lane_groups(g)) * kContexts << g.lane_shift) * 8, s));
+        if (int rc = next_state_generation(k, s)) return rc;
     }
     {
         Timed t(k, s, 1);
@@ -237,7 +250,7 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
     }
     {
         Timed t(k, s, 2);
-        HIP_TRY(launch_encode_slices(g, k->d_lane_order, k->d_states, k->d_scratch, static_cast<uint32_t*>(d_slice_len),
+        HIP_TRY(launch_encode_slices(g, k->d_lane_order, k->d_states, k->state_generation, k->d_scratch, static_cast<uint32_t*>(d_slice_len),
                                      k->d_group_off, static_cast<uint32_t*>(d_status), s));
     }
     {
@@ -262,7 +275,7 @@ int llcomp_mi_codec_decode(llcomp_mi_codec* k, const void* d_payload, uint64_t p
     HIP_TRY(hipMemsetAsync(d_status, 0, 4, s));
     {
         Timed t(k, s, 7);
-        if (k->need_states) HIP_TRY(hipMemsetAsync(k->d_states, 0, (uint64_t(lane_groups(g)) * kContexts << g.lane_shift) * 8, s));
+        if (int rc = next_state_generation(k, s)) return rc;
     }
     {
         Timed t(k, s, 4);
@@ -277,7 +290,7 @@ int llcomp_mi_codec_decode(llcomp_mi_codec* k, const void* d_payload, uint64_t p
     }
     {
         Timed t(k, s, 5);
-        HIP_TRY(launch_decode_slices(g, k->d_scratch, static_cast<const uint32_t*>(d_slice_len), k->d_states,
+        HIP_TRY(launch_decode_slices(g, k->d_scratch, static_cast<const uint32_t*>(d_slice_len), k->d_states, k->state_generation,
                                      static_cast<int16_t*>(k->d_lane_order), static_cast<uint32_t*>(d_status), s));
     }
     {

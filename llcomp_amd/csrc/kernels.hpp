@@ -37,11 +37,12 @@ bool slices_need_state_tables(const Geometry& g);
 // One lane per slice: binarisation + adaptive states + range encoder.  llcomp.hpp:33-89, 166-206, 283-293, 439-449.
 //   d_sym     : symbols in LANE ORDER: u32 (ctx | residual << 16), or the 16-bit form of the fused path when
 //               model_is_fused(g)
-//   d_states  : u64[lane group][kContexts][lanes of the group], zeroed by the caller (8 state bytes per context and
-//               slice); unused unless
-//               slices_need_state_tables(g)
+//   d_states  : u64[lane group][kContexts][lanes of the group] (8 state bytes per context and slice), unused unless
+//               slices_need_state_tables(g).  NOT cleared per call: every bank carries the `generation` (1..255) of the call
+//               that wrote it in the spare top bits of its state bytes, and a bank of another generation reads as zeros.
+//               The caller clears the table once (generation 0 = cleared memory) and again before it reuses a generation.
 //   d_scratch : the slices' streams in stream lane order ; d_slice_len : u32[n_slices]
-hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* d_states, uint8_t* d_scratch,
+hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* d_states, uint32_t generation, uint8_t* d_scratch,
                                 uint32_t* d_slice_len, uint64_t* d_group_off, uint32_t* d_status, hipStream_t stream);
 // Offsets of the slices in the packed payload: one exclusive prefix value per LANE GROUP, u64[lane_groups + 1] (the last
 // element and *d_total = sum of all lengths); pack / stage add the wave prefix of the group's own lengths.
@@ -69,6 +70,6 @@ hipError_t launch_copy_segments(const uint8_t* d_src, uint8_t* d_dst, const uint
 // llcomp.hpp:91-127, 219-247, 486-530.  d_rec int16 in LANE ORDER.
 // d_units: the slices' streams in stream lane order (launch_stage_streams).
 hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_units, const uint32_t* d_slice_len,
-                                uint64_t* d_states, int16_t* d_rec, uint32_t* d_status, hipStream_t stream);
+                                uint64_t* d_states, uint32_t generation, int16_t* d_rec, uint32_t* d_status, hipStream_t stream);
 
 }  // namespace llcomp_mi

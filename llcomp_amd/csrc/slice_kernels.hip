@@ -134,6 +134,20 @@ __device__ __forceinline__ uint32_t prob_of(entry_t e) { return byte_of(uint32_t
 // half of the entry that belongs to the coded bit: byte0 = successor state, byte1 = its probability
 __device__ __forceinline__ uint32_t successor(entry_t e, bool bit) { return bit ? uint32_t(e >> 32) : uint32_t(e); }
 
+// State tables in HBM (2-D tiles with several slices per wavefront) are NOT cleared per call: that was 6 GB of memset per
+// direction for 16 frames at 64x64 tiles, beside kernels that are bound by their own HBM traffic.  A state byte uses
+// 7 bits (128 states), so the eight spare top bits of a bank carry the GENERATION of the call that wrote it: a bank whose
+// tag is not this call's generation is stale and reads as eight zero states -- exactly what a cleared table holds.  The
+// host clears the table for real once per 255 calls (generation 0 = cleared memory, never a call's tag).
+constexpr uint64_t kTagBits = 0x8080808080808080ull;
+template <bool INLDS_TABLE>
+__device__ __forceinline__ uint64_t bank_fresh(uint64_t raw, uint64_t gpat) {  // what the table holds for THIS call
+    if constexpr (INLDS_TABLE) return raw;  // (a table in LDS is cleared by the kernel itself and carries no tags)
+    return (raw & kTagBits) == gpat ? (raw & ~kTagBits) : 0ull;
+}
+template <bool INLDS_TABLE>
+__device__ __forceinline__ uint64_t bank_tagged(uint64_t states, uint64_t gpat) { return INLDS_TABLE ? states : (states | gpat); }
+
 // The 8 entries of one context.  `all` = request slots 1..7 together with slot 0 (worth it when most residuals
 // are non-zero); otherwise they are requested after the zero flag turned out 0.
 struct Entries {
@@ -449,7 +463,7 @@ template <int NCH, bool ROWS, typename SYM, bool LDSTAB = false>
 __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const uint32_t lpw,
                                                       const SYM* __restrict__ sym, uint64_t* __restrict__ states,
                                                       uint8_t* __restrict__ scratch, uint32_t* __restrict__ slice_len,
-                                                      uint64_t* __restrict__ group_sum, uint32_t* status) {
+                                                      uint64_t* __restrict__ group_sum, uint32_t* status, const uint64_t gpat) {
     __shared__ entry_t tab[128];
     __shared__ __attribute__((aligned(32))) uint8_t stage[kStagePad + kStageBytes * 64];
     __shared__ unsigned long long rowbank[ROWS ? 3 * 64 : 1];
@@ -524,17 +538,18 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
         auto fetch = [&]() -> uint32_t { return p0[size_t(fk++) * GW]; };
         uint32_t s0 = fetch();
         uint32_t s1 = total > 1 ? fetch() : 0;
-        uint64_t b0 = banks[size_t(s0 & 0xFFFF) << bsh];
+        // (LDSTAB: the table was cleared in LDS by this kernel, gpat == 0 and every tag is 0: both helpers are identities)
+        uint64_t b0 = bank_fresh<LDSTAB>(banks[size_t(s0 & 0xFFFF) << bsh], gpat);
         for (uint32_t i = 0; i < total; ++i) {
             const uint32_t s2 = i + 2 < total ? fetch() : 0;
             const uint32_t ctx0 = s0 & 0xFFFF, ctx1 = s1 & 0xFFFF;
             const int res = int(s0) >> 16;
-            uint64_t b1 = (i + 1 < total) ? banks[size_t(ctx1) << bsh] : 0;
+            uint64_t b1 = (i + 1 < total) ? bank_fresh<LDSTAB>(banks[size_t(ctx1) << bsh], gpat) : 0;
             Bank bank{{uint32_t(b0), uint32_t(b0 >> 32)}, nullptr};
             if (hot) enc_residual<true, false>(e, bank, tab, res); else enc_residual<false, false>(e, bank, tab, res);
             hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(res != 0)) >= __popcll(__ballot(true)));
             b0 = uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32);
-            banks[size_t(ctx0) << bsh] = b0;
+            banks[size_t(ctx0) << bsh] = bank_tagged<LDSTAB>(b0, gpat);
             if (ctx1 == ctx0) b1 = b0;  // the prefetched copy is stale: forward
             b0 = b1;
             if (e.wp >= e.base + 16) enc_flush16(e);
@@ -808,7 +823,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                                                       const uint8_t* __restrict__ units,
                                                       const uint32_t* __restrict__ slice_len,
                                                       uint64_t* __restrict__ states, int16_t* __restrict__ rec,
-                                                      uint32_t* status) {
+                                                      uint32_t* status, const uint64_t gpat) {
     __shared__ entry_t tab[128];
     __shared__ unsigned long long rowbank[ROWS ? 3 * 64 : 1];
     clear_lds_states<LDSTAB>();
@@ -906,7 +921,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                         int ctx = context_hash(n, small_model);
                         const bool neg = ctx < 0;
                         if (neg) ctx = -ctx;
-                        const uint64_t b64 = banks[size_t(ctx) << bsh];
+                        const uint64_t b64 = bank_fresh<LDSTAB>(banks[size_t(ctx) << bsh], gpat);
                         Bank bank{{uint32_t(b64), uint32_t(b64 >> 32)}, nullptr};
                         uint32_t v;
                         if (!dec_sample<false>(d, bank, tab, hot, replay_always, v)) {
@@ -914,7 +929,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                             return;
                         }
                         hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true)));
-                        banks[size_t(ctx) << bsh] = uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32);
+                        banks[size_t(ctx) << bsh] = bank_tagged<LDSTAB>(uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32), gpat);
                         if (neg) v = 0u - v;
                         *q = int16_t(uint32_t(predict(n)) + v);
                     }
@@ -953,7 +968,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                     // most samples stay in the context of their predecessor, and when EVERY lane of the wavefront does, the
                     // table read -- the one memory round trip that hangs on the sample just decoded -- is skipped.  The test
                     // is wave-uniform: lanes never diverge here, and rough content pays one compare.
-                    if (__builtin_amdgcn_ballot_w64(uint32_t(ctx) != held_ctx) != 0) held_bank = banks[size_t(ctx) << bsh];
+                    if (__builtin_amdgcn_ballot_w64(uint32_t(ctx) != held_ctx) != 0) held_bank = bank_fresh<LDSTAB>(banks[size_t(ctx) << bsh], gpat);
                     held_ctx = uint32_t(ctx);
                     Bank bank{{uint32_t(held_bank), uint32_t(held_bank >> 32)}, nullptr};
                     uint32_t v;
@@ -964,7 +979,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                     }
                     hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true)));
                     held_bank = uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32);
-                    banks[size_t(ctx) << bsh] = held_bank;
+                    banks[size_t(ctx) << bsh] = bank_tagged<LDSTAB>(held_bank, gpat);
                     if (neg) v = 0u - v;
                     const int val = int(int16_t(uint32_t(predict(n)) + v));
                     q[k * GW] = int16_t(val);
@@ -1032,14 +1047,22 @@ hipError_t allow_big_lds(K kernel) {  // more than the default 64 KB of LDS per 
 
 bool encoder_writes_group_sums(const Geometry& g) { return g.lpw == (1u << g.lane_shift); }
 
-hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* d_states, uint8_t* d_scratch,
+// generation (1..255) -> the tag bits of a bank: bit i of the generation in the top bit of state byte i; 0 for tables in LDS
+uint64_t state_generation_tag(uint32_t generation) {
+    uint64_t t = 0;
+    for (int i = 0; i < 8; ++i) t |= uint64_t((generation >> i) & 1u) << (8 * i + 7);
+    return t;
+}
+
+hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* d_states, uint32_t generation, uint8_t* d_scratch,
                                 uint32_t* d_slice_len, uint64_t* d_group_off, uint32_t* d_status, hipStream_t stream) {
+    const uint64_t gpat = slices_need_state_tables(g) ? state_generation_tag(generation) : 0;
     const uint32_t lpw = g.lpw;
     const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
     uint64_t* const d_group_sum = encoder_writes_group_sums(g) ? d_group_off : nullptr;
     if (model_is_fused(g)) {  // planar 1-row slices: 16-bit symbols, always the ROWS kernel
         k_encode_slices<1, true, uint16_t><<<dim3(blocks), dim3(64), 0, stream>>>(
-            g, lpw, static_cast<const uint16_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status);
+            g, lpw, static_cast<const uint16_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status, gpat);
         return hipGetLastError();
     }
     const bool lds = states_in_lds(g);
@@ -1050,13 +1073,14 @@ hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* 
             if (e != hipSuccess) return e;
         }
         kernel<<<dim3(blocks), dim3(64), T ? kLdsTableBytes : 0, stream>>>(
-            g, lpw, static_cast<const uint32_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status);
+            g, lpw, static_cast<const uint32_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status, gpat);
     });
     return hipGetLastError();
 }
 
 hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_units, const uint32_t* d_slice_len,
-                                uint64_t* d_states, int16_t* d_rec, uint32_t* d_status, hipStream_t stream) {
+                                uint64_t* d_states, uint32_t generation, int16_t* d_rec, uint32_t* d_status, hipStream_t stream) {
+    const uint64_t gpat = slices_need_state_tables(g) ? state_generation_tag(generation) : 0;
     const uint32_t lpw = g.lpw;
     const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
     const uint32_t arg = lpw | ((g.flags & kGeoForceReplay) ? 0x100u : 0u);  // tests: rollback + checked replay everywhere
@@ -1068,7 +1092,7 @@ hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_units, const
             if (e != hipSuccess) return e;
         }
         kernel<<<dim3(blocks), dim3(64), T ? kLdsTableBytes : 0, stream>>>(g, arg, d_units, d_slice_len, d_states,
-                                                                          d_rec, d_status);
+                                                                          d_rec, d_status, gpat);
     });
     return hipGetLastError();
 }

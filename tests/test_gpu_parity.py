@@ -310,6 +310,48 @@ def test_batch_codec_small(mi, orc):
     _batch_roundtrip(mi, orc, 2, 61, 50, 1, 61, 1, False, ["g3", "g2"])
 
 
+def test_state_tables_survive_generation_wrap(mi, orc):
+    """State tables in HBM are not cleared per call: every bank carries the 8-bit generation of the call that wrote it
+    (slice_kernels.hip, bank_fresh) and the table is cleared for real once per 255 calls.  600 calls on one codec object,
+    three different batches in turn, across two wraps of the generation: every payload equals the oracle's, every decode
+    is lossless -- stale states of an earlier call must never leak into a later one."""
+    import torch
+
+    frames, w, h, c, tw, th = 2, 96, 80, 3, 16, 16   # 180 slices per call: several slices per wavefront -> tables in HBM
+    codec = mi.Codec(frames, w, h, c, tw, th, True)
+    st = torch.cuda.current_stream().cuda_stream
+    batches, wants = [], []
+    for k, gens in enumerate((["g3", "mid"], ["checker", "g1"], ["mid", "g3"])):
+        imgs = np.stack([np.roll(make_image(g, w, h, c), 3 * k + i, axis=1) for i, g in enumerate(gens)])
+        batches.append(torch.from_numpy(imgs).cuda())
+        ref = [orc.compress_sliced(imgs[f], tw, th, True) for f in range(frames)]
+        spf = codec.n_slices // frames
+        wants.append(b"".join(r[24 + 4 * spf:] for r in ref))
+    cap = max(len(x) for x in wants) + 4096
+    d_pay = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    d_len = torch.empty(codec.n_slices, dtype=torch.int32, device="cuda")
+    d_tot = torch.zeros(1, dtype=torch.int64, device="cuda")
+    d_st = torch.zeros(2, dtype=torch.int32, device="cuda")
+    d_out = torch.empty_like(batches[0])
+    for i in range(300):  # 600 calls: encode + decode each use a generation
+        b = i % 3
+        codec.encode(batches[b].data_ptr(), d_pay.data_ptr(), cap, d_len.data_ptr(), d_tot.data_ptr(), d_st.data_ptr(), st)
+        codec.decode(d_pay.data_ptr(), cap, d_len.data_ptr(), d_out.data_ptr(), d_st[1:].data_ptr(), st)
+        if i < 6 or i % 17 == 0 or 120 <= i <= 135 or i >= 290:  # dense around the wraps (call 255 = i 127, call 510 = i 254/255)
+            torch.cuda.synchronize()
+            assert d_st.tolist() == [0, 0]
+            total = int(d_tot.item())
+            assert d_pay[:total].cpu().numpy().tobytes() == wants[b], f"call {2 * i}: payload differs from the oracle's"
+            assert torch.equal(d_out, batches[b]), f"call {2 * i + 1}: round trip"
+    for i in range(250, 262):
+        b = i % 3
+        codec.encode(batches[b].data_ptr(), d_pay.data_ptr(), cap, d_len.data_ptr(), d_tot.data_ptr(), d_st.data_ptr(), st)
+        codec.decode(d_pay.data_ptr(), cap, d_len.data_ptr(), d_out.data_ptr(), d_st[1:].data_ptr(), st)
+        torch.cuda.synchronize()
+        assert d_st.tolist() == [0, 0] and d_pay[:int(d_tot.item())].cpu().numpy().tobytes() == wants[b] and torch.equal(d_out, batches[b])
+    codec.close()
+
+
 def test_payload_capacity_overflow_is_reported(mi):
     import torch
 
