@@ -273,7 +273,64 @@ def profile_numbers(F, tile_w, tile_h, planar, content, S, dom):
     return None, None, None
 
 
-def c5_stream(frames_np, tile_w, tile_h, planar, depth=8, frames_per_job=4, pipelines=2, encodes_in_flight=3, passes=4):
+def gpu_local_cpus(device=0):
+    """CPUs of the NUMA node the GPU hangs off (sysfs local_cpulist of its PCI function) that this process may run on; None
+    when the topology is not visible (containers often hide it)"""
+    try:
+        import torch
+
+        p = torch.cuda.get_device_properties(device)
+        path = f"/sys/bus/pci/devices/{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0/local_cpulist"
+        cpus = set()
+        for part in open(path).read().strip().split(","):
+            if part:
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        return cpus or None
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def link_rate(n=256 << 20, reps=6):
+    """what the host link gives on this box right now: copies between hipHostMalloc'ed (pinned, GPU-local) memory and HBM, H2D
+    alone, D2H alone and both directions at once on two HIP streams, 256 MiB each, in GB/s -- what the PCIe-inclusive config-5
+    leg is to be read against.  (Plain hipMemcpyAsync through ctypes: the same calls and the same kind of buffers as the
+    streaming pipeline uses.)"""
+    import ctypes as C
+
+    import torch
+
+    import llcomp_amd as mi
+
+    mi.device_count()  # (loads the library and with it the process's one HIP runtime, globally)
+    hip = C.CDLL(None)
+    hip.hipMemcpyAsync.restype = C.c_int
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    h_a, h_b = mi.PinnedBuffer(n), mi.PinnedBuffer(n)
+    d_a, d_b = torch.empty(n, dtype=torch.uint8, device="cuda"), torch.empty(n, dtype=torch.uint8, device="cuda")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def run(h2d, d2h, k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            if h2d:
+                assert hip.hipMemcpyAsync(d_a.data_ptr(), h_a.ptr, n, 1, s1.cuda_stream) == 0
+            if d2h:
+                assert hip.hipMemcpyAsync(h_b.ptr, d_b.data_ptr(), n, 2, s2.cuda_stream) == 0
+        torch.cuda.synchronize()
+        return (h2d + d2h) * k * n / (time.perf_counter() - t0) / 1e9
+
+    run(True, True, 2)
+    out = {"h2d_alone_GBps": round(run(True, False, reps), 1), "d2h_alone_GBps": round(run(False, True, reps), 1), "both_directions_GBps": round(run(True, True, reps), 1)}
+    h_a.close()
+    h_b.close()
+    del d_a, d_b
+    return out
+
+
+def c5_stream(frames_np, tile_w, tile_h, planar, depth=8, frames_per_job=4, pipelines=2, encodes_in_flight=3, passes=4, pin=True, verify=True, link=None):
     """BASELINE config 5, PCIe inclusive: the frames stream host -> GPU -> host (container) -> GPU -> host through the
     product's pipeline (llcomp_mi_stream_*, jobs of `frames_per_job` frames), `passes` times over the batch; every frame verified
     bit-exact.  `pipelines` stream objects, each driven by its own thread over its own share of the frames: one pipeline
@@ -294,10 +351,14 @@ def c5_stream(frames_np, tile_w, tile_h, planar, depth=8, frames_per_job=4, pipe
     res, errs = [None] * pipelines, []
     origin = time.perf_counter()
 
+    local = gpu_local_cpus() if pin else None
+
     def drive(t):
         try:
+            if local:  # the driving thread (and the verification workers it starts) stay on the GPU's NUMA node, next to the pinned buffers
+                os.sched_setaffinity(0, local)
             mine = views[t * per:(t + 1) * per]  # (the frames of a job must be adjacent in memory)
-            res[t] = mi.pipeline_roundtrip(sts[t], mine * passes, max_encodes_in_flight=encodes_in_flight, verify=True,
+            res[t] = mi.pipeline_roundtrip(sts[t], mine * passes, max_encodes_in_flight=encodes_in_flight, verify=verify,
                                            verify_threads=max(2, 6 // pipelines), clock_origin=origin)
         except BaseException as e:  # noqa: BLE001
             errs.append(e)
@@ -319,9 +380,14 @@ def c5_stream(frames_np, tile_w, tile_h, planar, depth=8, frames_per_job=4, pipe
     counted = sum(sum(1 for t in r[1] if t > begin) for r in res)
     steady = counted * w * h / 1e6 / (end - begin)
     total_len = sum(sum(r[0]) for r in res)
+    per_frame = int(2 * (h * w * c + total_len / n))
+    extra = {}
+    if link:  # bytes over the link per second against what the link gave in this process a moment ago
+        extra = {"link": link, "pcie_GBps": round(per_frame * steady * 1e6 / (w * h) / 1e9, 1),
+                 "pcie_frac": round(per_frame * steady * 1e6 / (w * h) / 1e9 / link["both_directions_GBps"], 3)}
     return {"value": round(steady, 1), "unit": "MPix/s", "frames": n, "frames_per_job": frames_per_job, "depth": depth, "pipelines": pipelines,
-            "compression_ratio": round(n * h * w * c / total_len, 4),
-            "pcie_bytes_per_frame": int(2 * (h * w * c + total_len / n)), "backpressure_hits": sum(r[2] for r in res),
+            "compression_ratio": round(n * h * w * c / total_len, 4), "threads_pinned_to_gpu_numa_node": bool(local), **extra,
+            "pcie_bytes_per_frame": per_frame, "backpressure_hits": sum(r[2] for r in res),
             "note": "end to end over PCIe from/to pinned host memory, steady state (every pipeline's first 4 frames excluded), every frame bit-exact; never part of `value`"}
 
 
@@ -773,8 +839,14 @@ def main():
         want = lambda leg: not only or leg in only  # noqa: E731
         legacy_box = {}
 
-        def leg_c5():
-            also["c5_stream_pcie"] = c5_stream(frames_np, args.tile_w, args.tile_h, planar)
+        def leg_c5():  # three repetitions: the pipeline's steady state is sensitive to how the copies of the jobs fall over each other (tools/c5_repeat.py)
+            link = link_rate()
+            runs = sorted((c5_stream(frames_np, args.tile_w, args.tile_h, planar, link=link) for _ in range(3)), key=lambda r: r["value"])
+            leg = dict(runs[1])  # the median run
+            leg["runs_MPix_s"] = [r["value"] for r in runs]
+            leg["spread"] = round((runs[-1]["value"] - runs[0]["value"]) / runs[-1]["value"], 3)
+            leg["note"] = "median of three repetitions in this process; " + leg["note"]
+            also["c5_stream_pcie"] = leg
 
         def leg_c4():
             n4 = max(4, sub // 2)

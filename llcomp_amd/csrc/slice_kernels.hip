@@ -63,15 +63,6 @@ struct ProbeStamp {
 #ifndef LLMI_EXP
 #define LLMI_EXP 0
 #endif
-// code-shape variants under measurement (bit mask; the product build fixes the winners below)
-//   1: decoder once-per-sample bins as selects on VCC instead of an exec-masked patch region
-//   2: encoder once-per-sample bins likewise
-//   4: runs on one slot (unary tail, mantissa tail) take the probability of the NEXT bin from the half-entry they have just
-//      selected (byte 1) and request the successor's entry before they renormalise: the LDS round trip of the state walk
-//      overlaps a whole bin instead of sitting between two bins
-#ifndef LLMI_OPT
-#define LLMI_OPT 0
-#endif
 __device__ __forceinline__ void exp_pad() {
 #if LLMI_EXP == 1
     uint32_t t;
@@ -317,26 +308,6 @@ __device__ __forceinline__ uint32_t enc_step_msb(RangeEnc& e, uint32_t& bits, en
     enc_renorm(e);
     return off;
 }
-// The same with the state walk decoupled from the coder's chain.  `half` = the half-entry that led to the current state
-// (byte 0 = the state, byte 1 = its probability): the multiply takes the probability from there, so `cur` -- the entry of
-// the current state, requested a whole bin ago -- is only needed for the select of the next half.  Returns the new half.
-__device__ __forceinline__ uint32_t enc_step_msb_early(RangeEnc& e, uint32_t& bits, uint32_t half, entry_t cur) {
-    uint32_t nh, r1;
-    unsigned long long saved_exec;
-    asm("v_add_co_u32_e32 %[bits], vcc, %[bits], %[bits]\n\t"
-        "v_mul_u32_u24_sdwa %[r1], %[half], %[range] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-        "v_lshrrev_b32_e32 %[r1], 8, %[r1]\n\t"
-        "v_sub_u32_e32 %[range], %[range], %[r1]\n\t"
-        "v_cndmask_b32_e32 %[nh], %[lo], %[hi], vcc\n\t"
-        "s_and_saveexec_b64 %[save], vcc\n\t"
-        "v_add_u32_e32 %[low], %[low], %[range]\n\t"
-        "v_mov_b32_e32 %[range], %[r1]\n\t"
-        "s_mov_b64 exec, %[save]"
-        : [bits] "+v"(bits), [range] "+v"(e.range), [low] "+v"(e.low), [nh] "=&v"(nh), [r1] "=&v"(r1), [save] "=&s"(saved_exec)
-        : [half] "v"(half), [lo] "v"(uint32_t(cur)), [hi] "v"(uint32_t(cur >> 32))
-        : "vcc");
-    return nh;
-}
 // a slot that is coded at most once per sample; the bit as a mask (all ones / zero) ...
 template <int SLOT, bool INLDS>
 __device__ __forceinline__ void enc_once_m(RangeEnc& e, Bank& bank, const Entries& E, uint32_t m) {
@@ -350,7 +321,7 @@ template <int SLOT, bool INLDS>
 __device__ __forceinline__ void enc_once(RangeEnc& e, Bank& bank, const Entries& E, bool bit) {
     const entry_t en = E.get<SLOT>();
     const uint32_t r1 = __umul24(e.range, prob_of(en)) >> 8;
-    if constexpr (INLDS && !(LLMI_OPT & 2)) {
+    if constexpr (INLDS) {
         e.range -= r1;
         put_state<SLOT, true>(bank, uint32_t(en));
         if (bit) {
@@ -400,13 +371,11 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, Bank& bank, const entr
                     for (uint32_t i = 0; i < ones; ++i) {  // (rotated: one compare per bin)
                         // the successor on a 1 is known before this bin is coded: its entry is requested first and has
                         // the whole renormalisation to arrive (the state chain does not depend on low / range)
-                        const uint32_t h = uint32_t(cur >> 32);  // byte 0: the successor state, byte 1: its probability
-                        cur = entry_at(tab, h);
+                        cur = entry_at(tab, uint32_t(cur >> 32));
                         e.low += e.range;
                         e.range = r1;
                         enc_renorm(e);
-                        if constexpr (LLMI_OPT & 4) r1 = __umul24(e.range, byte_of(h, 1)) >> 8;  // (no wait for `cur`: it has until the next `cur >> 32`)
-                        else r1 = __umul24(e.range, prob_of(cur)) >> 8;
+                        r1 = __umul24(e.range, prob_of(cur)) >> 8;
                         e.range -= r1;
                     }
                     enc_renorm(e);
@@ -419,21 +388,11 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, Bank& bank, const entr
                 uint32_t nx;
                 // remaining mantissa bits left-aligned, followed by a sentinel 1: the loop needs no counter
                 uint32_t bits = ((a << 1) | 1u) << (32 - ex);
-                if constexpr (LLMI_OPT & 4) {
-                    uint32_t half = uint32_t(cur) >> 8;  // byte 1 = probability of slot 6's state (byte 2 of its own entry)
-                    do {
-                        half = enc_step_msb_early(e, bits, half, cur);
-                        cur = entry_at(tab, half);  // requested before the renormalisation, needed one bin later
-                        enc_renorm(e);
-                    } while (bits != 0x80000000u);
-                    put_state<6, INLDS>(bank, half);
-                } else {
                 do {
                     nx = enc_step_msb(e, bits, cur);  // successor's table offset
                     cur = *reinterpret_cast<const entry_t*>(reinterpret_cast<const char*>(tab) + nx);
                 } while (bits != 0x80000000u);
                 put_state<6, INLDS>(bank, nx >> 3);
-                }
             }
         }
         enc_once<7, INLDS>(e, bank, E, res < 0);
@@ -698,7 +657,7 @@ __device__ __forceinline__ uint32_t dec_step_acc(RangeDec& d, uint32_t P, entry_
 template <int SLOT, bool CHECKED, bool INLDS>
 __device__ __forceinline__ bool dec_once(RangeDec& d, Bank& bank, const Entries& E) {
     const entry_t en = E.get<SLOT>();
-    if constexpr (INLDS && !(LLMI_OPT & 1)) {
+    if constexpr (INLDS) {
         // every lane takes the bit-0 outcome (range = r0, low stays, successor = low half of the entry, stored straight
         // away); the lanes that decode a 1 patch up inside one exec-masked region (see enc_once)
         if (CHECKED && d.win <= 1) dec_append(d);
@@ -746,10 +705,9 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entr
                 // happens once, behind the loop.
                 entry_t cur = E.e4;
                 int n = 0;  // bins of the unary tail: n - 1 ones and the closing zero
-                uint32_t h = uint32_t(cur) >> 8;  // byte 1 = probability of the state being coded (LLMI_OPT & 4)
                 for (;;) {
                     if (CHECKED && d.win <= 1) dec_append(d);
-                    const uint32_t r1 = __umul24(d.range, (LLMI_OPT & 4) ? byte_of(h, 1) : prob_of(cur)) >> 8;
+                    const uint32_t r1 = __umul24(d.range, prob_of(cur)) >> 8;
                     d.range -= r1;
                     ++n;
                     uint32_t diff;
@@ -757,11 +715,7 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entr
                     d.low = diff;
                     d.range = r1;
                     if (CHECKED && n > 29) break;  // exponent would exceed 31
-                    // the successor on a 1 (byte 0 of the high half, its probability in byte 1) is requested BEFORE the
-                    // refill; the next bin multiplies with the probability carried in `h` and needs the entry only when it
-                    // moves on again
-                    h = uint32_t(cur >> 32);
-                    cur = entry_at(tab, h);
+                    cur = entry_at(tab, uint32_t(cur >> 32));  // requested before the refill, needed by the next bin
                     dec_refill(d);
                 }
                 dec_refill(d);

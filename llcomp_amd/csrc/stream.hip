@@ -9,9 +9,14 @@
 //   decode  H2D container -> kernels -> D2H frame + status (event e2)
 // The size of a container is known on the GPU only.  Nobody waits for it at submit time: the 16-byte mailbox copy is
 // queued behind the kernels and whoever enters the library next (submit, wait or poll) looks at the events of the
-// jobs in flight ("pump") and queues the container copies whose size has arrived; wait() itself polls (20 us naps), so
-// the copies of younger jobs start while the caller waits for the oldest.  With two or more slots busy the
-// copies of one job overlap the kernels of the others in both PCIe directions.
+// jobs in flight ("pump") and queues the container copies whose size has arrived; wait() blocks on the EVENT that comes
+// next -- the size mailbox of the oldest encode job that still lacks one, else the oldest job's last copy -- with the
+// object's mutex released, pumps, and blocks again, so the copies of younger jobs start while the caller waits for the
+// oldest (round 2 polled with 20 us naps under the mutex).  With two or more slots busy the copies of one job overlap the
+// kernels of the others in both PCIe directions.
+// Failures: a submit that fails after its first copy was queued drains the lane's stream before it returns (the caller
+// may free its buffer as soon as it sees the error), and a HIP error on a job in flight becomes that job's status
+// (LLCOMP_MI_HIP_ERROR through wait()) instead of an error of the call that would leave the job at the head of the queue.
 // Back-pressure: submit returns LLCOMP_MI_BUSY when every slot is occupied (in flight, or finished and not yet
 // released); the caller takes a result (llcomp_mi_stream_wait), uses it and releases the slot.
 // Results come back in submission order.  One stream object is driven by one thread at a time (calls are serialised by
@@ -19,12 +24,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <chrono>
 #include <cstring>
 #include <deque>
 #include <mutex>
 #include <new>
-#include <thread>
 #include <vector>
 
 #include "../../include/llcomp_mi.h"
@@ -101,16 +104,31 @@ int start_container_copy(llcomp_mi_stream* s, Slot& sl) {
     return LLCOMP_MI_OK;
 }
 
-int pump(llcomp_mi_stream* s) {
+// a HIP error on a job in flight: the job fails (reported through wait()), the pipeline goes on
+void fail_job(Slot& sl, int status) {
+    (void)hipGetLastError();
+    if (sl.lane && sl.lane->stream) (void)hipStreamSynchronize(sl.lane->stream);  // nothing of it may still be in flight when the slot is reused
+    sl.status = status;
+    sl.state = kFailed;
+}
+
+void pump(llcomp_mi_stream* s) {
     for (uint32_t i : s->fifo) {
         Slot& sl = s->slots[i];
         if (sl.state != kEncSizing) continue;
         const hipError_t q = hipEventQuery(sl.e1);
         if (q == hipErrorNotReady) continue;
-        if (q != hipSuccess) return LLCOMP_MI_HIP_ERROR;
-        if (int rc = start_container_copy(s, sl)) return rc;
+        if (q != hipSuccess) { fail_job(sl, LLCOMP_MI_HIP_ERROR); continue; }
+        if (int rc = start_container_copy(s, sl)) fail_job(sl, rc);
     }
-    return LLCOMP_MI_OK;
+}
+
+// a submit that fails after work was queued on the lane's stream: drain it, so that "not accepted" means "not touching the
+// caller's buffer any more"
+int drained(HostLane* l, int rc) {
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(l->stream);
+    return rc;
 }
 
 int free_slot(llcomp_mi_stream* s) {
@@ -193,14 +211,14 @@ int llcomp_mi_stream_submit_encode(llcomp_mi_stream* s, const uint8_t* px, uint6
     std::lock_guard<std::mutex> lock(s->mu);
     DeviceGuard guard(s->device);
     if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
-    if (int rc = pump(s)) return rc;
+    pump(s);
     const int i = free_slot(s);
     if (i < 0) return LLCOMP_MI_BUSY;
     Slot& sl = s->slots[size_t(i)];
     HostLane* l = sl.lane;
     LLMI_HIP_TRY(hipMemcpyAsync(l->d_px, px, s->raw * s->fpj, hipMemcpyHostToDevice, l->stream));  // the job's frames, back to back
-    if (int rc = lane_enqueue_encode(l)) return rc;
-    LLMI_HIP_TRY(hipEventRecord(sl.e1, l->stream));
+    if (int rc = lane_enqueue_encode(l)) return drained(l, rc);
+    if (hipEventRecord(sl.e1, l->stream) != hipSuccess) return drained(l, LLCOMP_MI_HIP_ERROR);
     sl.state = kEncSizing;
     sl.kind = LLCOMP_MI_JOB_ENCODE;
     sl.tag = tag;
@@ -236,12 +254,17 @@ int llcomp_mi_stream_submit_decode_batch(llcomp_mi_stream* s, const uint8_t* con
     std::lock_guard<std::mutex> lock(s->mu);
     DeviceGuard guard(s->device);
     if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
-    if (int rc = pump(s)) return rc;
+    pump(s);
     const int i = free_slot(s);
     if (i < 0) return LLCOMP_MI_BUSY;
     Slot& sl = s->slots[size_t(i)];
     HostLane* l = sl.lane;
     uint64_t payload_bytes = 0;
+    if (s->fpj > 1) {  // (checked before anything is queued)
+        uint64_t all = 0;
+        for (uint32_t f = 0; f < s->fpj; ++f) all += pay[f];
+        if (all > l->payload_cap) return LLCOMP_MI_OUTPUT_OVERFLOW;
+    }
     if (s->fpj == 1) {
         // a container longer than the slot's buffer carries bytes no slice can use (the table is bounds-checked on the GPU)
         const uint64_t n = std::min<uint64_t>(lens[0], uint64_t(l->head_bytes) + l->payload_cap);
@@ -249,17 +272,18 @@ int llcomp_mi_stream_submit_decode_batch(llcomp_mi_stream* s, const uint8_t* con
         payload_bytes = n - l->head_bytes;
     } else {
         for (uint32_t f = 0; f < s->fpj; ++f) {
-            if (payload_bytes + pay[f] > l->payload_cap) return LLCOMP_MI_OUTPUT_OVERFLOW;
-            LLMI_HIP_TRY(hipMemcpyAsync(l->d_len() + size_t(f) * s->spf, data[f] + LLCOMP_MI_SLICED_HEADER_BYTES, 4ull * s->spf,
-                                        hipMemcpyHostToDevice, l->stream));
-            if (pay[f])
-                LLMI_HIP_TRY(hipMemcpyAsync(l->d_payload() + payload_bytes, data[f] + head1, pay[f], hipMemcpyHostToDevice, l->stream));
+            if (hipMemcpyAsync(l->d_len() + size_t(f) * s->spf, data[f] + LLCOMP_MI_SLICED_HEADER_BYTES, 4ull * s->spf,
+                               hipMemcpyHostToDevice, l->stream) != hipSuccess)
+                return drained(l, LLCOMP_MI_HIP_ERROR);
+            if (pay[f] && hipMemcpyAsync(l->d_payload() + payload_bytes, data[f] + head1, pay[f], hipMemcpyHostToDevice, l->stream) != hipSuccess)
+                return drained(l, LLCOMP_MI_HIP_ERROR);
             payload_bytes += pay[f];
         }
     }
-    if (int rc = lane_enqueue_decode(l, payload_bytes)) return rc;
-    LLMI_HIP_TRY(hipMemcpyAsync(sl.h_out, l->d_px, s->raw * s->fpj, hipMemcpyDeviceToHost, l->stream));
-    LLMI_HIP_TRY(hipEventRecord(sl.e2, l->stream));
+    if (int rc = lane_enqueue_decode(l, payload_bytes)) return drained(l, rc);
+    if (hipMemcpyAsync(sl.h_out, l->d_px, s->raw * s->fpj, hipMemcpyDeviceToHost, l->stream) != hipSuccess ||
+        hipEventRecord(sl.e2, l->stream) != hipSuccess)
+        return drained(l, LLCOMP_MI_HIP_ERROR);
     sl.state = kCopying;
     sl.kind = LLCOMP_MI_JOB_DECODE;
     sl.tag = tag;
@@ -298,14 +322,14 @@ int llcomp_mi_stream_poll(llcomp_mi_stream* s) {
     std::lock_guard<std::mutex> lock(s->mu);
     DeviceGuard guard(s->device);
     if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
-    if (int rc = pump(s)) return rc;
+    pump(s);
     if (s->fifo.empty()) return LLCOMP_MI_OK;
     Slot& sl = s->slots[s->fifo.front()];
     if (sl.state == kFailed) return LLCOMP_MI_OK;
     if (sl.state == kCopying) {
         const hipError_t q = hipEventQuery(sl.e2);
         if (q == hipSuccess) return LLCOMP_MI_OK;
-        if (q != hipErrorNotReady) return LLCOMP_MI_HIP_ERROR;
+        if (q != hipErrorNotReady) { fail_job(sl, LLCOMP_MI_HIP_ERROR); return LLCOMP_MI_OK; }  // wait() reports it
     }
     return LLCOMP_MI_BUSY;  // the oldest job is still in flight
 }
@@ -313,24 +337,32 @@ int llcomp_mi_stream_poll(llcomp_mi_stream* s) {
 int llcomp_mi_stream_wait(llcomp_mi_stream* s, llcomp_mi_stream_result* r) {
     if (!s || !r) return LLCOMP_MI_BAD_ARGS;
     std::memset(r, 0, sizeof(*r));
-    std::lock_guard<std::mutex> lock(s->mu);
+    std::unique_lock<std::mutex> lock(s->mu);
     if (s->fifo.empty()) return LLCOMP_MI_BAD_ARGS;  // nothing was submitted
     DeviceGuard guard(s->device);
     if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
-    if (int rc = pump(s)) return rc;
     const uint32_t i = s->fifo.front();
     Slot& sl = s->slots[i];
-    // Wait for the oldest job by polling, not by blocking on its event: while this thread waits, the size mailboxes of
-    // YOUNGER encode jobs keep arriving, and their container copies have to be queued right away or the D2H link idles.
+    // Block on the event that comes NEXT, not on the oldest job's last one: while this thread waits for the oldest job,
+    // the size mailboxes of younger encode jobs keep arriving, and their container copies have to be queued when they do
+    // or the D2H link idles.  Jobs run in submission order on lanes of equal speed, so the next event is the mailbox of
+    // the oldest job that still lacks one, else the oldest job's final copy.  The mutex is released while blocked.
     for (;;) {
-        if (int rc = pump(s)) return rc;
+        pump(s);
         if (sl.state == kFailed) break;
-        if (sl.state == kCopying) {
+        hipEvent_t next = nullptr;
+        for (uint32_t j : s->fifo)
+            if (s->slots[j].state == kEncSizing) { next = s->slots[j].e1; break; }
+        if (!next) {
             const hipError_t q = hipEventQuery(sl.e2);
             if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) return LLCOMP_MI_HIP_ERROR;
+            if (q != hipErrorNotReady) { fail_job(sl, LLCOMP_MI_HIP_ERROR); break; }
+            next = sl.e2;
         }
-        std::this_thread::sleep_for(std::chrono::microseconds(20));
+        lock.unlock();
+        const hipError_t e = hipEventSynchronize(next);
+        lock.lock();
+        if (e != hipSuccess) { fail_job(sl, LLCOMP_MI_HIP_ERROR); break; }
     }
     if (sl.state == kCopying && sl.kind == LLCOMP_MI_JOB_DECODE) sl.status = status_from_bits(uint32_t(sl.lane->h_meta[1]));
     s->fifo.pop_front();
