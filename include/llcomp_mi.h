@@ -24,7 +24,11 @@
 extern "C" {
 #endif
 
-#define LLCOMP_MI_ABI_VERSION 2
+/* ABI 3.  The library and its callers are built from ONE header: structs have one layout per ABI version (llcomp_mi_opts is
+ * checked through struct_size and refused when it differs; llcomp_mi_info and llcomp_mi_stream_result are written in full),
+ * so a binding compares llcomp_mi_abi_version() with the LLCOMP_MI_ABI_VERSION it was generated from and refuses to run on
+ * a mismatch -- there is no cross-version compatibility mode. */
+#define LLCOMP_MI_ABI_VERSION 3
 
 /* Wire formats.  LEGACY is the reference's own: [0x79][channels u8][width u16 LE][height u16 LE] + ONE
  * range-coded stream (llcomp.hpp:375-378); it is a single serial chain (one GPU lane).  SLICED is this
@@ -61,8 +65,7 @@ typedef struct llcomp_mi_opts {
     uint32_t tile_h;      /* slice height in pixels, 0 = full height  (SLICED only) */
     uint32_t planar;      /* 1 = one slice per colour-transformed channel plane, 0 = channels interleaved */
     int32_t device;       /* HIP device ordinal, -1 = current device */
-    uint32_t small_model; /* 1 = code like a reference built with LargeModel = false.  This field was added in ABI 2:
-                             struct_size 24 (without it) is still accepted and means 0. */
+    uint32_t small_model; /* 1 = code like a reference built with LargeModel = false */
 } llcomp_mi_opts;
 #define LLCOMP_MI_FLAG_SMALL_MODEL 1u /* llcomp_mi_decode_flags / llcomp_mi_codec_create_ex */
 
@@ -87,6 +90,9 @@ int llcomp_mi_encode_into(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c,
                           size_t out_cap, size_t* out_len);
 int llcomp_mi_decode_into(const uint8_t* data, size_t len, int32_t device, uint8_t* px, size_t px_cap, uint32_t* w,
                           uint32_t* h, uint32_t* c);
+/* ... with flags, as llcomp_mi_decode_flags (a LEGACY stream written with the small model) */
+int llcomp_mi_decode_into_flags(const uint8_t* data, size_t len, int32_t device, uint32_t flags, uint8_t* px, size_t px_cap,
+                                uint32_t* w, uint32_t* h, uint32_t* c);
 /* The host-buffer calls keep a few idle coding lanes (GBs of HBM workspace for a 4K frame) for the next call of the same
  * shape, and the library parks the device memory of destroyed codecs / streams / lanes for reuse instead of returning it
  * to the driver (up to the pool limit per device; released by itself when an allocation OF THE LIBRARY fails).  This

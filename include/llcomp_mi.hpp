@@ -51,6 +51,11 @@ namespace detail {
     if (status == LLCOMP_MI_BAD_ARGS || status == LLCOMP_MI_OUT_OF_RANGE) throw std::invalid_argument(msg);
     throw std::runtime_error(msg);
 }
+// this header and the library it is linked against must come from the same ABI version (llcomp_mi.h: one struct layout per version)
+inline void check_abi() {
+    static const bool ok = llcomp_mi_abi_version() == LLCOMP_MI_ABI_VERSION;
+    if (!ok) throw std::runtime_error("libllcomp_mi.so was built from another llcomp_mi.h (ABI version mismatch): rebuild");
+}
 }  // namespace detail
 
 inline std::vector<uint8_t> compressImage(const std::vector<uint8_t>& rgb, int width, int height, int channels,
@@ -58,6 +63,7 @@ inline std::vector<uint8_t> compressImage(const std::vector<uint8_t>& rgb, int w
     if (width <= 0 || height <= 0 || channels <= 0 ||
         rgb.size() != size_t(width) * size_t(height) * size_t(channels))  // the reference only asserts this (:361)
         detail::raise(LLCOMP_MI_BAD_ARGS);
+    detail::check_abi();
     llcomp_mi_opts o{};
     o.struct_size = sizeof(o);
     o.format = opt.sliced ? LLCOMP_MI_FORMAT_SLICED : LLCOMP_MI_FORMAT_LEGACY;
@@ -76,6 +82,7 @@ inline std::vector<uint8_t> compressImage(const std::vector<uint8_t>& rgb, int w
 }
 
 inline RawImage decompressImage(const std::vector<uint8_t>& data, int device = -1, bool legacy_small_model = false) {
+    detail::check_abi();
     uint8_t* px = nullptr;
     uint32_t w = 0, h = 0, c = 0;
     if (int rc = llcomp_mi_decode_flags(data.data(), data.size(), device, legacy_small_model ? LLCOMP_MI_FLAG_SMALL_MODEL : 0u, &px, &w, &h, &c))

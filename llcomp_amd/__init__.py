@@ -118,11 +118,11 @@ class PinnedBuffer:
     __del__ = close
 
 
-def compress_image_into(rgb, width, height, channels, out, *, format=FORMAT_LEGACY, tile_w=0, tile_h=0, planar=False, device=-1):
+def compress_image_into(rgb, width, height, channels, out, *, format=FORMAT_LEGACY, tile_w=0, tile_h=0, planar=False, device=-1, small_model=False):
     """llcomp_mi_encode_into: `rgb` and `out` are numpy uint8 arrays owned by the caller (pinned: PinnedBuffer.array);
     returns the container length.  Raises LlcompError(OUTPUT_OVERFLOW) with .needed set when `out` is too small."""
     L = _lib.load()
-    o = Opts(C.sizeof(Opts), format, tile_w, tile_h, int(bool(planar)), device, 0)
+    o = Opts(C.sizeof(Opts), format, tile_w, tile_h, int(bool(planar)), device, int(bool(small_model)))
     n = C.c_size_t()
     rc = L.llcomp_mi_encode_into(rgb.ctypes.data, width, height, channels, C.byref(o), out.ctypes.data, out.size, C.byref(n))
     if rc != OK:
@@ -132,11 +132,11 @@ def compress_image_into(rgb, width, height, channels, out, *, format=FORMAT_LEGA
     return n.value
 
 
-def decompress_image_into(data, out, *, device=-1):
-    """llcomp_mi_decode_into: `data` / `out` numpy uint8 arrays owned by the caller -> (width, height, channels)."""
+def decompress_image_into(data, out, *, device=-1, small_model=False):
+    """llcomp_mi_decode_into_flags: `data` / `out` numpy uint8 arrays owned by the caller -> (width, height, channels)."""
     L = _lib.load()
     w, h, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
-    rc = L.llcomp_mi_decode_into(data.ctypes.data, data.size, device, out.ctypes.data, out.size, C.byref(w), C.byref(h), C.byref(c))
+    rc = L.llcomp_mi_decode_into_flags(data.ctypes.data, data.size, device, 1 if small_model else 0, out.ctypes.data, out.size, C.byref(w), C.byref(h), C.byref(c))
     if rc != OK:
         e = LlcompError(rc)
         e.shape = (w.value, h.value, c.value)

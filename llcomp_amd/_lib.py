@@ -10,6 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # in-kernel clock stamps, csrc/Makefile `probe`); the tests, bench.py and smoke() never set it
 LIB_PATH = os.environ.get("LLCOMP_MI_LIB") or os.path.join(_HERE, "libllcomp_mi.so")
 
+ABI_VERSION = 3  # LLCOMP_MI_ABI_VERSION of the header this binding mirrors
+
 # every symbol include/llcomp_mi.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = [
     "llcomp_mi_encode", "llcomp_mi_decode", "llcomp_mi_free", "llcomp_mi_strerror", "llcomp_mi_abi_version",
@@ -24,7 +26,7 @@ SYMBOLS = [
     "llcomp_mi_stream_result_part", "llcomp_mi_stream_destroy", "llcomp_mi_stream_container_capacity",
     "llcomp_mi_stream_submit_encode", "llcomp_mi_stream_submit_decode", "llcomp_mi_stream_pending",
     "llcomp_mi_stream_poll", "llcomp_mi_stream_wait", "llcomp_mi_stream_release",
-    "llcomp_mi_set_pool_limit", "llcomp_mi_pool_limit", "llcomp_mi_pool_idle_bytes", "llcomp_mi_fnv1a64", "llcomp_mi_suggest_tile_w",
+    "llcomp_mi_set_pool_limit", "llcomp_mi_pool_limit", "llcomp_mi_pool_idle_bytes", "llcomp_mi_fnv1a64", "llcomp_mi_suggest_tile_w", "llcomp_mi_decode_into_flags",
 ]
 
 u8p = C.POINTER(C.c_uint8)
@@ -125,6 +127,9 @@ def load():
     L.llcomp_mi_encode_into.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Opts), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.llcomp_mi_decode_into.restype = C.c_int
     L.llcomp_mi_decode_into.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    if "LLCOMP_MI_LIB" not in os.environ or hasattr(L, "llcomp_mi_decode_into_flags"):
+        L.llcomp_mi_decode_into_flags.restype = C.c_int
+        L.llcomp_mi_decode_into_flags.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.llcomp_mi_host_alloc.restype = C.c_void_p
     L.llcomp_mi_host_alloc.argtypes = [C.c_size_t]
     L.llcomp_mi_host_free.restype = None
@@ -178,5 +183,7 @@ def load():
     L.llcomp_mi_stream_wait.argtypes = [C.c_void_p, C.POINTER(StreamResult)]
     L.llcomp_mi_stream_release.restype = C.c_int
     L.llcomp_mi_stream_release.argtypes = [C.c_void_p, C.c_uint32]
+    if "LLCOMP_MI_LIB" not in os.environ and L.llcomp_mi_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {L.llcomp_mi_abi_version()}, this binding was written for {ABI_VERSION}: rebuild the library")
     _lib = L
     return L

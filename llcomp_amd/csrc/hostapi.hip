@@ -203,9 +203,9 @@ int encode_common(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, const l
     o.struct_size = sizeof(o);
     o.format = LLCOMP_MI_FORMAT_LEGACY;
     o.device = -1;
-    if (opts) {  // struct_size 24 = the ABI-1 layout without small_model
-        if (opts->struct_size != sizeof(llcomp_mi_opts) && opts->struct_size != 24) return LLCOMP_MI_BAD_ARGS;
-        std::memcpy(&o, opts, opts->struct_size);
+    if (opts) {  // one layout per ABI version: a caller built against another header is refused, not half-read
+        if (opts->struct_size != sizeof(llcomp_mi_opts)) return LLCOMP_MI_BAD_ARGS;
+        std::memcpy(&o, opts, sizeof(o));
         if (o.small_model > 1) return LLCOMP_MI_BAD_ARGS;
     }
     if (o.format != LLCOMP_MI_FORMAT_LEGACY && o.format != LLCOMP_MI_FORMAT_SLICED) return LLCOMP_MI_BAD_ARGS;
@@ -326,8 +326,13 @@ int llcomp_mi_decode_flags(const uint8_t* data, size_t len, int32_t device, uint
 
 int llcomp_mi_decode_into(const uint8_t* data, size_t len, int32_t device, uint8_t* px, size_t px_cap, uint32_t* w, uint32_t* h,
                           uint32_t* c) {
-    if (!data || !px || !w || !h || !c) return LLCOMP_MI_BAD_ARGS;
-    return decode_common(data, len, device, 0, px, px_cap, nullptr, w, h, c);
+    return llcomp_mi_decode_into_flags(data, len, device, 0, px, px_cap, w, h, c);
+}
+
+int llcomp_mi_decode_into_flags(const uint8_t* data, size_t len, int32_t device, uint32_t flags, uint8_t* px, size_t px_cap, uint32_t* w,
+                                uint32_t* h, uint32_t* c) {
+    if (!data || !px || !w || !h || !c || (flags & ~LLCOMP_MI_FLAG_SMALL_MODEL)) return LLCOMP_MI_BAD_ARGS;
+    return decode_common(data, len, device, flags, px, px_cap, nullptr, w, h, c);
 }
 
 void llcomp_mi_trim(void) {

@@ -32,7 +32,7 @@ def test_header_symbols_all_exported(mi):
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in llcomp_mi.h but not exported by libllcomp_mi.so"
-    assert lib.llcomp_mi_abi_version() == 2
+    assert lib.llcomp_mi_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_struct_layouts_match_header(mi):

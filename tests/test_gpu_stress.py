@@ -99,6 +99,29 @@ def test_stress_parity(chunk):
         run_case(mi, orc, 1000 + chunk * 12 + i, check_legacy=(i % 6 == 0))
 
 
+@pytest.mark.gpu
+def test_stress_parity_without_parking():
+    """The sequence that showed zeroed cache lines in round 2: every new shape drops a cached lane, and with the
+    library's device-memory cache switched off (pool limit 0) every dropped buffer goes back to the driver with hipFree
+    and the next lane takes fresh memory with hipMalloc.  120 shapes, every container byte-exact against the oracle.  If
+    the corruption (profiles/r03_free_wipe.txt: not reproducible on round 3's boxes) ever comes back, this is where it
+    shows -- the parking in csrc/devmem.hip would otherwise hide it."""
+    import llcomp_amd as mi
+    import orc as orc_mod
+
+    assert mi.device_count() >= 1, "GPU tests need a HIP device"
+    orc = orc_mod.Orc()
+    before = int(mi._lib.load().llcomp_mi_pool_limit())
+    mi.trim()
+    mi.set_pool_limit(0)
+    try:
+        for i in range(120):
+            run_case(mi, orc, 9000 + i, check_legacy=False)
+        assert mi.pool_idle_bytes() == 0, "with a pool limit of 0 nothing may stay parked"
+    finally:
+        mi.set_pool_limit(before)
+
+
 ROW_WIDTHS = (1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 63, 64, 65, 66, 127, 129, 200, 257, 480, 500, 1000)
 ROW_TILES = (1, 2, 3, 7, 8, 9, 63, 64, 65, 128, 130)
 
