@@ -330,12 +330,14 @@ def link_rate(n=256 << 20, reps=6):
     return out
 
 
-def c5_stream(frames_np, tile_w, tile_h, planar, depth=8, frames_per_job=4, pipelines=2, encodes_in_flight=3, passes=4, pin=True, verify=True, link=None):
+def c5_stream(frames_np, tile_w, tile_h, planar, depth=6, frames_per_job=8, pipelines=2, encodes_in_flight=2, passes=4, pin=True, verify=True, link=None):
     """BASELINE config 5, PCIe inclusive: the frames stream host -> GPU -> host (container) -> GPU -> host through the
     product's pipeline (llcomp_mi_stream_*, jobs of `frames_per_job` frames), `passes` times over the batch; every frame verified
     bit-exact.  `pipelines` stream objects, each driven by its own thread over its own share of the frames: one pipeline
-    hands its results back in submission order and leaves the two DMA directions idle now and then (4.6 GPix/s; two
-    pipelines 6.0, two processes on one GPU 6.9 -- tools/c5_sweep.py)."""
+    hands its results back in submission order and leaves the two DMA directions idle now and then.  Defaults = the shape
+    that was both fastest and steadiest in tools/c5_repeat.py (profiles/r03_c5_repeat.txt): two pipelines, jobs of 8 frames
+    (200 MB copies), 6 slots, 2 encodes in flight each -- 5.65-6.07 GPix/s over five repetitions against 5.3-6.4 with jobs of
+    4 frames in 8 slots; the link gives 97 GB/s with both directions busy = 7.1 GPix/s at 114 MB per frame."""
     import threading
 
     import llcomp_amd as mi
