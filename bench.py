@@ -393,7 +393,7 @@ def c5_stream(frames_np, tile_w, tile_h, planar, depth=6, frames_per_job=8, pipe
             "note": "end to end over PCIe from/to pinned host memory, steady state (every pipeline's first 4 frames excluded), every frame bit-exact; never part of `value`"}
 
 
-def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank, check_one_piece=True, parts=0, group=None):
+def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank, check_one_piece=True, parts=0, group=None, height=None):
     """BASELINE config 4: `images` noise images of size x size RGB8, each sharded over all ranks; encode (+ exchange of the
     bitstream) and decode (+ exchange back) per step.  The batch is coded as up to three part batches on as many HIP streams
     (a ShardedCodec each) so that the exchange of one part overlaps the coding of the others.  Returns the max-over-ranks wall time."""
@@ -404,10 +404,11 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     from llcomp_amd import sharding
 
     dev = torch.device("cuda", local_rank)
+    height = height or size  # (tools/c4_overhead.py codes bands of the config-4 image: one rank's share at N > 1, on one GPU)
     # 3, 2 or 1 part batches (measured on one GPU: 2, 3 and 6 parts all take 82 ms per step), each spreading its containers evenly over the ranks
     halves = next(p for p in ((parts,) if parts else ()) + (3, 2, 1) if images % p == 0 and (images // p) % world == 0 or p == 1)
     per = images // halves
-    scs = [sharding.ShardedCodec(size, size, 3, tile_w, tile_h, True, images=per, device=dev, group=group) for _ in range(halves)]
+    scs = [sharding.ShardedCodec(size, height, 3, tile_w, tile_h, True, images=per, device=dev, group=group) for _ in range(halves)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(halves)]
     # uniform byte noise (torch Philox, seed 1234 + image): every rank draws the full image on its GPU and keeps its rows
     bands, first = [], None
@@ -417,7 +418,7 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
             b = k * per + j
             g = torch.Generator(device=dev)
             g.manual_seed(1234 + b)
-            full = torch.randint(0, 256, (1, size, size, 3), dtype=torch.uint8, device=dev, generator=g)
+            full = torch.randint(0, 256, (1, height, size, 3), dtype=torch.uint8, device=dev, generator=g)
             rows[j] = torch.cat([full[:, y0:y1] for y0, y1 in sc.rows], dim=1) if sc.rows else full[:, :0]
             if b == 0 and rank == sc.root_of[0] and check_one_piece:
                 first = full[0].cpu().numpy()
@@ -458,7 +459,7 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     dist.all_reduce(pb, op=dist.ReduceOp.SUM, group=group)
     payload_bytes = int(pb.item())
     if first is not None:
-        one = mi.compress_image(first, size, size, 3, format=mi.FORMAT_SLICED, tile_w=tile_w, tile_h=tile_h, planar=True, device=local_rank)
+        one = mi.compress_image(first, size, height, 3, format=mi.FORMAT_SLICED, tile_w=tile_w, tile_h=tile_h, planar=True, device=local_rank)
         assert bytes(conts[0][0].cpu().numpy()) == one, "sharded container differs from the one-piece container"
     # At least three more untimed passes, bound exactly like the timed ones (the results of pass i stay alive while pass
     # i + 1 runs): that is when torch's allocator takes its last segments from the driver.  With the results dropped at

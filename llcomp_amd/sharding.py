@@ -236,17 +236,38 @@ class ShardedCodec:
         in_exchange[self.xorder] = run - base[self.seg_root[self.xorder]]  # offset inside ITS gathering rank's buffer
         return seg_len, in_exchange, in_image, img_bytes, M
 
-    def _exchange(self, send, send_split, recv_split):
+    def _exchange(self, send, send_split, recv_split, m_max):
         """variable-size all-to-all of bytes (RCCL alltoallv on device tensors); returns the receive buffer on self.device"""
         n_send = int(sum(send_split))
         if self.world == 1 and not self.force_exchange:
             return send  # one rank: what it would send to itself is already in place
         self.exchanges += 1
-        recv = torch.empty(int(sum(recv_split)) + 16, dtype=torch.uint8, device=self.comm_device)
-        src = self._to_comm(send[:n_send]) if n_send else torch.empty(0, dtype=torch.uint8, device=self.comm_device)
-        dist.all_to_all_single(recv[: int(sum(recv_split))], src.contiguous(), output_split_sizes=[int(x) for x in recv_split],
-                               input_split_sizes=[int(x) for x in send_split], group=self.group)
+        send_split, recv_split = [int(x) for x in send_split], [int(x) for x in recv_split]
+        recv = torch.empty(sum(recv_split) + 16, dtype=torch.uint8, device=self.comm_device)
+        src = self._to_comm(send[:n_send]).contiguous() if n_send else torch.empty(0, dtype=torch.uint8, device=self.comm_device)
+        if m_max <= self.MAX_MESSAGE:  # (m_max = the largest message of ANY rank pair: the same decision on every rank)
+            dist.all_to_all_single(recv[: sum(recv_split)], src, output_split_sizes=recv_split, input_split_sizes=send_split, group=self.group)
+            return recv.to(self.device)
+        # A message beyond MAX_MESSAGE bytes goes in rounds of at most that many bytes per peer (a 2 GB self-message of one
+        # RCCL rank came back damaged on the MI355X box; real multi-rank messages are far smaller).  Every rank derives the
+        # same number of rounds from the same message matrix, so the collectives stay matched.
+        rounds = -(-int(m_max) // self.MAX_MESSAGE)
+        s_off = np.concatenate([[0], np.cumsum(send_split)]).astype(np.int64)
+        r_off = np.concatenate([[0], np.cumsum(recv_split)]).astype(np.int64)
+        for k in range(rounds):
+            lo = k * self.MAX_MESSAGE
+            s_len = [max(0, min(self.MAX_MESSAGE, n - lo)) for n in send_split]
+            r_len = [max(0, min(self.MAX_MESSAGE, n - lo)) for n in recv_split]
+            s_buf = torch.cat([src[s_off[p] + lo: s_off[p] + lo + s_len[p]] for p in range(self.world)]) if sum(s_len) else src[:0]
+            r_buf = torch.empty(sum(r_len), dtype=torch.uint8, device=self.comm_device)
+            dist.all_to_all_single(r_buf, s_buf, output_split_sizes=r_len, input_split_sizes=s_len, group=self.group)
+            at = 0
+            for p in range(self.world):
+                recv[r_off[p] + lo: r_off[p] + lo + r_len[p]] = r_buf[at: at + r_len[p]]
+                at += r_len[p]
         return recv.to(self.device)
+
+    MAX_MESSAGE = 1 << 30
 
     # ---- encode -------------------------------------------------------------------------------------------------
     def encode(self, local_px):
@@ -281,7 +302,7 @@ class ShardedCodec:
         if payload is None:
             payload = torch.empty(0, dtype=torch.uint8, device=self.device)
         # collective 2: every coding rank's packed payload to the gathering ranks, GPU to GPU
-        exchange = self._exchange(payload, M_h[self.rank], [M_h[s][self.rank] for s in range(self.world)])
+        exchange = self._exchange(payload, M_h[self.rank], [M_h[s][self.rank] for s in range(self.world)], max(max(r) for r in M_h))
         if not self.my_images:
             return {}
         # containers of my images = [header][table][payload], payload interleaved chunk by chunk by the device concatenator
@@ -337,9 +358,7 @@ class ShardedCodec:
         tabs = torch.empty(self.world * mine_tab.numel(), dtype=torch.int32, device=self.comm_device)
         dist.all_gather_into_tensor(tabs, mine_tab, group=self.group)    # collective 1: the slice tables of every image
         tabs = tabs.view(self.world, per_root * self.spf + 1)
-        bad = tabs[:, -1].cpu().tolist()
-        if any(bad):
-            raise ValueError("container does not match this ShardedCodec's geometry (rank(s) %s)" % [r for r, f in enumerate(bad) if f])
+        flags = tabs[:, -1].to(self.device).to(torch.int64)
         tabs = tabs[:, :-1].reshape(self.world, per_root, self.spf)
         slot = [0] * self.world
         pick = []
@@ -350,7 +369,12 @@ class ShardedCodec:
         # table can neither go negative nor size a copy beyond what the geometry allows (the decoder reports the damage)
         lens_c = self._as_lengths(torch.stack([tabs[r, j] for r, j in pick]).reshape(-1).to(self.device))
         seg_len, in_exchange, in_image, img_bytes, M = self._segment_tables(lens_c)
-        M_h = M.cpu().tolist()                               # host round trip: message sizes
+        host = torch.cat([M.reshape(-1), flags]).cpu().tolist()   # the one host round trip: message sizes + every rank's verdict on its containers
+        ww = self.world * self.world
+        bad = host[ww:]
+        if any(bad):
+            raise ValueError("container does not match this ShardedCodec's geometry (rank(s) %s)" % [r for r, f in enumerate(bad) if f])
+        M_h = [host[r * self.world:(r + 1) * self.world] for r in range(self.world)]
         # my containers -> send buffer ordered (coding rank, frame, chunk); the table may promise more than a damaged
         # container holds: clip, the decoder reports it
         n_out = int(sum(M_h[s][self.rank] for s in range(self.world)))
@@ -364,7 +388,7 @@ class ShardedCodec:
                 seg_clip = torch.minimum(seg_len[idx], torch.clamp(int(cont.numel()) - src_off, min=0))
                 _copy_segments(cont, send, src_off, in_exchange[idx].contiguous(), seg_clip.contiguous(), int(cont.numel()))
         # collective 2: every rank gets the bytes of its slices, already in its codec's order
-        recv = self._exchange(send, [M_h[s][self.rank] for s in range(self.world)], M_h[self.rank])
+        recv = self._exchange(send, [M_h[s][self.rank] for s in range(self.world)], M_h[self.rank], max(max(r) for r in M_h))
         out = torch.empty((self.images, self.local_h, self.w, self.c), dtype=torch.uint8, device=self.device)
         if self.band is None:
             self._pending_decode = (out, None)

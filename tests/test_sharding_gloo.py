@@ -97,6 +97,14 @@ def _worker(rank, world, port, case, q):
         px = sc.gather_pixels(out)
         if rank == 0:
             assert np.array_equal(px.numpy(), full)
+        # the same through the chunked exchange (messages cut into rounds of at most MAX_MESSAGE bytes per peer)
+        sc3 = sharding.ShardedCodec(w, h, c, tw, th, planar, images=images, chunks_per_rank=cpr, root=root, device=torch.device("cpu"),
+                                    band_factory=oracle_band_factory(orc))
+        sc3.MAX_MESSAGE = 97
+        c3 = sc3.encode(band)
+        for b in want_mine:
+            assert bytes(c3[b].numpy()) == bytes(conts[b].numpy())
+        assert np.array_equal(sc3.decode(c3).numpy(), full[sc3.frame_images][:, rows])
         # two part batches in bench.py's software-pipelined order (begin / finish halves interleaved): same bytes, same rows
         sc2 = sharding.ShardedCodec(w, h, c, tw, th, planar, images=images, chunks_per_rank=cpr, root=root, device=torch.device("cpu"),
                                     band_factory=oracle_band_factory(orc))
