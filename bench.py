@@ -437,14 +437,26 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
             with torch.cuda.stream(streams[k]):
                 return fn(*a, **kw)
 
-        for k in range(halves + 2):
-            if k < halves:
+        if os.environ.get("LLCOMP_BENCH_C4_ORDER", "one-ahead") == "deep":
+            # every part's coding queued before the host waits for the first part's sizes.  Measured (tools/c4_overhead.py,
+            # profiles/r03_c4_overhead.jsonl): 2-3 % SLOWER than one part ahead at every modelled rank count -- the path's cost
+            # beside the coding is not host latency
+            for k in range(halves):
                 on(k, scs[k].encode_begin, bands[k])
-            if 1 <= k <= halves:
-                conts[k - 1] = on(k - 1, scs[k - 1].encode_finish)
-                on(k - 1, scs[k - 1].decode_begin, conts[k - 1], validate=False)  # straight from encode: no header round trip
-            if k >= 2:
-                outs[k - 2] = on(k - 2, scs[k - 2].decode_finish)
+            for k in range(halves):
+                conts[k] = on(k, scs[k].encode_finish)
+                on(k, scs[k].decode_begin, conts[k], validate=False)  # straight from encode: no header round trip
+            for k in range(halves):
+                outs[k] = on(k, scs[k].decode_finish)
+        else:  # round 2's order: one part of coding ahead of the host
+            for k in range(halves + 2):
+                if k < halves:
+                    on(k, scs[k].encode_begin, bands[k])
+                if 1 <= k <= halves:
+                    conts[k - 1] = on(k - 1, scs[k - 1].encode_finish)
+                    on(k - 1, scs[k - 1].decode_begin, conts[k - 1], validate=False)
+                if k >= 2:
+                    outs[k - 2] = on(k - 2, scs[k - 2].decode_finish)
         # every part has drained its own stream by now (decode_finish reads its status); the device-wide wait costs
         # microseconds and keeps steps from interleaving in the runtime's queues (without it some runs of this leg took
         # twice as long per step, with identical kernels and allocator statistics)

@@ -30,11 +30,14 @@ torch.cuda.synchronize()
 os.dup2(fd, 1)
 for n in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     h = 8192 // n
-    dt, pay = bench.c4_run(24, 8192, 512, 1, 6, 3, 0, 1, 0, check_one_piece=False, height=h)
-    sharded_ms = dt / 6 * 1e3
     frames = bench.make_frames("g3", 24, 0, w=8192, h=h, c=3, distinct=2)
     m = bench.measure(frames, 512, 1, True, 3, 6, 2, 0)
     plain_ms = m["dt"] / m["steps"] * 1e3
-    print(json.dumps({"ranks_modelled": n, "rows_per_rank": h, "sharded_path_ms_per_step": round(sharded_ms, 2), "plain_codec_ms_per_step": round(plain_ms, 2),
-                      "overhead_ms": round(sharded_ms - plain_ms, 2), "efficiency": round(plain_ms / sharded_ms, 3), **bench.c4_run.last_detail}), flush=True)
+    del frames
+    for order in ("deep", "one-ahead"):  # bench.py's step order (all parts' coding queued first) and round 2's
+        os.environ["LLCOMP_BENCH_C4_ORDER"] = order
+        dt, pay = bench.c4_run(24, 8192, 512, 1, 6, 3, 0, 1, 0, check_one_piece=False, height=h)
+        sharded_ms = dt / 6 * 1e3
+        print(json.dumps({"ranks_modelled": n, "rows_per_rank": h, "order": order, "sharded_path_ms_per_step": round(sharded_ms, 2), "plain_codec_ms_per_step": round(plain_ms, 2),
+                          "overhead_ms": round(sharded_ms - plain_ms, 2), "efficiency": round(plain_ms / sharded_ms, 3), **bench.c4_run.last_detail}), flush=True)
 dist.destroy_process_group()
