@@ -174,6 +174,11 @@ int llcomp_mi_codec_model(llcomp_mi_codec* codec, const void* d_px, void* d_sym,
  * max_len = an upper bound of the lengths (sizes the grid only); n_seg <= 65535.  Asynchronous on `stream`. */
 int llcomp_mi_device_copy_segments(const void* d_src, void* d_dst, const void* d_src_off, const void* d_dst_off,
                                    const void* d_len, uint32_t n_seg, uint64_t max_len, void* stream);
+/* Sums over ranges of a u32 table in HBM: d_out[i] (u64) = sum of min(d_vals[j], cap) for j in [d_start[i], d_start[i] + d_count[i])
+ * (d_start, d_count: u64[n] in HBM).  The multi-GPU path derives the byte counts of its (image, chunk) segments from the
+ * slice-length tables with it.  Asynchronous on `stream`. */
+int llcomp_mi_device_range_sums(const void* d_vals, const void* d_start, const void* d_count, void* d_out, uint32_t n, uint32_t cap,
+                                void* stream);
 /* The u32 status word written by encode/decode holds bit flags (1 overflow, 2 bad exponent, 4 truncated);
  * this maps it to an llcomp_mi_status. */
 uint32_t llcomp_mi_status_from_bits(uint32_t bits);

@@ -26,7 +26,7 @@ SYMBOLS = [
     "llcomp_mi_stream_result_part", "llcomp_mi_stream_destroy", "llcomp_mi_stream_container_capacity",
     "llcomp_mi_stream_submit_encode", "llcomp_mi_stream_submit_decode", "llcomp_mi_stream_pending",
     "llcomp_mi_stream_poll", "llcomp_mi_stream_wait", "llcomp_mi_stream_release",
-    "llcomp_mi_set_pool_limit", "llcomp_mi_pool_limit", "llcomp_mi_pool_idle_bytes", "llcomp_mi_fnv1a64", "llcomp_mi_suggest_tile_w", "llcomp_mi_decode_into_flags",
+    "llcomp_mi_set_pool_limit", "llcomp_mi_pool_limit", "llcomp_mi_pool_idle_bytes", "llcomp_mi_fnv1a64", "llcomp_mi_suggest_tile_w", "llcomp_mi_decode_into_flags", "llcomp_mi_device_range_sums",
 ]
 
 u8p = C.POINTER(C.c_uint8)
@@ -136,6 +136,9 @@ def load():
     L.llcomp_mi_host_free.argtypes = [C.c_void_p]
     L.llcomp_mi_device_copy_segments.restype = C.c_int
     L.llcomp_mi_device_copy_segments.argtypes = [C.c_void_p] * 5 + [C.c_uint32, C.c_uint64, C.c_void_p]
+    if "LLCOMP_MI_LIB" not in os.environ or hasattr(L, "llcomp_mi_device_range_sums"):
+        L.llcomp_mi_device_range_sums.restype = C.c_int
+        L.llcomp_mi_device_range_sums.argtypes = [C.c_void_p] * 4 + [C.c_uint32, C.c_uint32, C.c_void_p]
     L.llcomp_mi_decode_flags.restype = C.c_int
     L.llcomp_mi_decode_flags.argtypes = [u8p, C.c_size_t, C.c_int32, C.c_uint32, C.POINTER(u8p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.llcomp_mi_codec_create_ex.restype = C.c_int

@@ -320,6 +320,15 @@ int llcomp_mi_device_copy_segments(const void* d_src, void* d_dst, const void* d
     return LLCOMP_MI_OK;
 }
 
+int llcomp_mi_device_range_sums(const void* d_vals, const void* d_start, const void* d_count, void* d_out, uint32_t n, uint32_t cap,
+                                void* stream) {
+    if (!n) return LLCOMP_MI_OK;
+    if (!d_vals || !d_start || !d_count || !d_out) return LLCOMP_MI_BAD_ARGS;
+    HIP_TRY(launch_range_sums(static_cast<const uint32_t*>(d_vals), static_cast<const uint64_t*>(d_start), static_cast<const uint64_t*>(d_count),
+                              static_cast<uint64_t*>(d_out), n, cap, static_cast<hipStream_t>(stream)));
+    return LLCOMP_MI_OK;
+}
+
 int llcomp_mi_codec_set_profiling(llcomp_mi_codec* k, int enable) {
     if (!k) return LLCOMP_MI_BAD_ARGS;
     k->profiling = enable != 0;

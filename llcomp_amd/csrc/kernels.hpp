@@ -66,6 +66,10 @@ hipError_t launch_stage_streams(const Geometry& g, const uint8_t* d_payload, uin
 // alignment); max_len = an upper bound of the lengths (grid sizing only).  The device-side concatenator of the multi-GPU path.
 hipError_t launch_copy_segments(const uint8_t* d_src, uint8_t* d_dst, const uint64_t* d_src_off, const uint64_t* d_dst_off,
                                 const uint64_t* d_len, uint32_t n_seg, uint64_t max_len, hipStream_t stream);
+// out[i] = sum over j in [start[i], start[i] + count[i]) of min(vals[j], cap); everything in HBM.  (Multi-GPU path: byte counts
+// of (image, chunk) segments from the slice-length tables.)
+hipError_t launch_range_sums(const uint32_t* d_vals, const uint64_t* d_start, const uint64_t* d_count, uint64_t* d_out, uint32_t n,
+                             uint32_t cap, hipStream_t stream);
 // One lane per slice: range decoder + adaptive states + context model on reconstructed samples.
 // llcomp.hpp:91-127, 219-247, 486-530.  d_rec int16 in LANE ORDER.
 // d_units: the slices' streams in stream lane order (launch_stage_streams).

@@ -477,6 +477,21 @@ __global__ __launch_bounds__(256) void k_copy_segments(const uint8_t* __restrict
     }
 }
 
+// Sums of ranges of a u32 table: out[i] = sum of min(vals[j], cap) for j in [start[i], start[i] + count[i]).  The multi-GPU
+// path (llcomp_amd/sharding.py) turns slice lengths into the byte counts of its (image, chunk) segments with it: one launch
+// instead of a prefix sum over every slice plus a dozen gathers.  One block per range.
+__global__ __launch_bounds__(256) void k_range_sums(const uint32_t* __restrict__ vals, const uint64_t* __restrict__ start,
+                                                    const uint64_t* __restrict__ count, uint64_t* __restrict__ out, uint32_t cap) {
+    __shared__ unsigned long long part[4];
+    const uint64_t s = start[blockIdx.x], n = count[blockIdx.x];
+    unsigned long long acc = 0;
+    for (uint64_t j = threadIdx.x; j < n; j += 256) acc += min(vals[s + j], cap);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
 // ---- image order <-> lane order -------------------------------------------------------------------------------------
 // The serial kernels run one slice per lane, 64 slices ("lane group") per wavefront, all lanes at the same sample
 // index k.  Their per-sample arrays therefore live in LANE ORDER  [group][k][64 lanes]  so that one wavefront access
@@ -973,6 +988,13 @@ hipError_t launch_copy_segments(const uint8_t* d_src, uint8_t* d_dst, const uint
     const uint64_t pieces = (max_len / 4 + kSegPieceDwords - 1) / kSegPieceDwords;
     const uint32_t gx = uint32_t(std::min<uint64_t>(std::max<uint64_t>(pieces, 1), 1024));
     k_copy_segments<<<dim3(gx, n_seg), dim3(256), 0, stream>>>(d_src, d_dst, d_src_off, d_dst_off, d_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_range_sums(const uint32_t* d_vals, const uint64_t* d_start, const uint64_t* d_count, uint64_t* d_out, uint32_t n,
+                             uint32_t cap, hipStream_t stream) {
+    if (!n) return hipSuccess;
+    k_range_sums<<<dim3(n), dim3(256), 0, stream>>>(d_vals, d_start, d_count, d_out, cap);
     return hipGetLastError();
 }
 

@@ -156,29 +156,54 @@ class ShardedCodec:
         self.max_local = max(self.local_slices)
         factory = band_factory or _HipBand
         self.band = factory(images, w, self.local_h, c, self.tile_w, self.tile_h, self.planar, device) if self.local_h else None
-        # slice permutation: container order (image, tile row, ...) <- position of (rank r, frame f, local slice s) in the
-        # all_gather'ed [world, images * max_local] table of slice lengths
+        # Everything below is geometry, fixed at construction.  The slice lengths of every rank travel in ONE all_gather'ed
+        # int32 table [world][images * max_local + 1] (the last word of a row = that rank's coder status); `n1` = its row stride.
+        n_ch = len(self.chunks)
+        self.n1 = n1 = images * self.max_local + 1
+        # slice permutation: container order (image, tile row, ...) <- position in the flattened gathered table
         src = np.empty((images, self.spf), dtype=np.int64)
+        enc_start = np.empty((images, n_ch), dtype=np.int64)   # where the slices of segment (image, chunk) start in that table
         seen = [0] * world
-        for t0, t1, o in self.chunks:
+        for ci, (t0, t1, o) in enumerate(self.chunks):
             n = (t1 - t0) * self.per_row
             for b in range(images):
-                src[b, t0 * self.per_row:t1 * self.per_row] = o * images * self.max_local + frame_of[b] * self.local_slices[o] + seen[o] + np.arange(n)
+                first = o * n1 + frame_of[b] * self.local_slices[o] + seen[o]
+                src[b, t0 * self.per_row:t1 * self.per_row] = first + np.arange(n)
+                enc_start[b, ci] = first
             seen[o] += n
-        self.perm = torch.from_numpy(src.reshape(-1)).to(device)
-        # segments = (image, chunk): the unit the concatenator moves.  All of this is geometry, fixed at construction.
-        seg = [(b, ci) for b in range(images) for ci in range(len(self.chunks))]
-        t = lambda v: torch.tensor(v, dtype=torch.int64, device=device)  # noqa: E731
-        self.seg_first = t([b * self.spf + self.chunks[ci][0] * self.per_row for b, ci in seg])
-        self.seg_count = t([(self.chunks[ci][1] - self.chunks[ci][0]) * self.per_row for b, ci in seg])
-        self.seg_image = t([b for b, ci in seg])
-        self.seg_owner = t([self.chunks[ci][2] for b, ci in seg])
-        self.seg_root = t([self.root_of[b] for b, ci in seg])
+        # segments = (image, chunk), index b * n_ch + ci: the unit the concatenator moves, a contiguous run of slices both in
+        # the owner's table and in the container
+        self.n_seg = images * n_ch
+        seg = [(b, ci) for b in range(images) for ci in range(n_ch)]
+        self.seg_count_h = np.array([(self.chunks[ci][1] - self.chunks[ci][0]) * self.per_row for b, ci in seg], dtype=np.int64)
+        self.seg_image_h = np.array([b for b, ci in seg], dtype=np.int64)
+        self.seg_owner_h = np.array([self.chunks[ci][2] for b, ci in seg], dtype=np.int64)
+        self.seg_root_h = np.array([self.root_of[b] for b, ci in seg], dtype=np.int64)
+        dec_start = np.array([b * self.spf + self.chunks[ci][0] * self.per_row for b, ci in seg], dtype=np.int64)
         # exchange order: (gathering rank, coding rank, frame, chunk) -- the order of the bytes in a gathering rank's receive
         # buffer (encode) / send buffer (decode)
         key = [(self.root_of[b], self.chunks[ci][2], frame_of[b], ci) for b, ci in seg]
-        self.xorder = t(sorted(range(len(seg)), key=lambda i: key[i]))
-        self.seg_mine = t([i for i, (b, ci) in enumerate(seg) if self.root_of[b] == self.rank])  # segments of the images I gather
+        self.xorder_h = np.array(sorted(range(len(seg)), key=lambda i: key[i]), dtype=np.int64)
+        self.seg_mine_h = np.array([i for i, (b, ci) in enumerate(seg) if self.root_of[b] == self.rank], dtype=np.int64)
+        t = lambda v: torch.as_tensor(np.ascontiguousarray(v), dtype=torch.int64).to(device)  # noqa: E731
+        self.enc_start_d, self.dec_start_d, self.seg_count_d = t(enc_start.reshape(-1)), t(dec_start), t(self.seg_count_h)
+        # container-order slice tables of the images I gather, as indices into the flattened gathered table
+        self.perm_mine_d = t(src[self.my_images].reshape(-1)) if self.my_images else None
+        # decode: the tables of all images arrive as [world][per_root * spf + 1] (a flag word per rank); container order of
+        # image b = row root_of[b], slot = its position among that rank's images
+        self.per_root = max(1, max(sum(1 for b in range(images) if self.root_of[b] == r) for r in range(world)))
+        slot, pick = [0] * world, []
+        for b in range(images):
+            pick.append(self.root_of[b] * (self.per_root * self.spf + 1) + slot[self.root_of[b]] * self.spf)
+            slot[self.root_of[b]] += 1
+        self.dec_src_d = t((np.array(pick, dtype=np.int64)[:, None] + np.arange(self.spf)[None, :]).reshape(-1))
+        # ... and this rank's slices in ITS codec's order (frame, local tile rows) as indices into that container-order table
+        inv = np.zeros(images * self.local_slices[self.rank], dtype=np.int64)
+        mine_rows = src - self.rank * n1
+        own = (src >= self.rank * n1) & (src < self.rank * n1 + n1 - 1)
+        bb, ss = np.nonzero(own)
+        inv[mine_rows[bb, ss]] = bb * self.spf + ss
+        self.inv_mine_d = t(inv)
         self._pending = None
         self._pending_decode = None
         self.header = torch.tensor(list(bytes([MAGIC_SLICED, 1, c, 1 if self.planar else 0]) + b"".join(
@@ -197,44 +222,60 @@ class ShardedCodec:
     def _to_comm(self, t):
         return t if t.device == self.comm_device else t.to(self.comm_device)
 
-    def _all_lens(self, lens, status=None):
-        """([world * images * max_local] int64 on self.device: every rank's slice lengths, zero padded; [world] int64: every
-        rank's coder status word).  The status rides along in the same all_gather, so every rank learns of a failed local
-        encode before the payload collective and all of them raise together (nobody is left waiting in all_to_all)."""
-        n = self.images * self.max_local
-        mine = torch.zeros(n + 1, dtype=torch.int32, device=self.device)
+    def _gather_lens(self, lens, status=None):
+        """int32 [world * n1] on self.device: every rank's slice lengths (zero padded) followed by its coder status word.  The
+        status rides along in the same all_gather, so every rank learns of a failed local encode before the payload collective
+        and all of them raise together (nobody is left waiting in all_to_all)."""
+        mine = torch.zeros(self.n1, dtype=torch.int32, device=self.device)
         if lens is not None:
             mine[: lens.numel()] = lens
         if status is not None:
-            mine[n] = status.reshape(-1)[0].to(self.device)
-        out = torch.empty(self.world * (n + 1), dtype=torch.int32, device=self.comm_device)
+            mine[self.n1 - 1] = status.reshape(-1)[0].to(self.device)
+        out = torch.empty(self.world * self.n1, dtype=torch.int32, device=self.comm_device)
         dist.all_gather_into_tensor(out, self._to_comm(mine), group=self.group)
-        out = out.to(self.device).view(self.world, n + 1).to(torch.int64)
-        return self._as_lengths(out[:, :n].reshape(-1)), out[:, n].contiguous()
+        return out.to(self.device)
 
     def _as_lengths(self, t):
         """int32 words read as the u32 they are on the wire, clamped to what a slice can hold"""
         return torch.clamp(t.to(torch.int64) & 0xFFFFFFFF, max=self.slice_cap)
 
-    def _segment_tables(self, lens_c):
-        """From the container-order slice lengths [images * spf]: per (image, chunk) segment its byte count, its offset in
-        the gathering rank's exchange buffer and its offset inside its image's payload; per image its payload bytes; and the
-        message matrix M[coding rank][gathering rank] in bytes."""
-        csum = torch.zeros(lens_c.numel() + 1, dtype=torch.int64, device=self.device)
-        torch.cumsum(lens_c, 0, out=csum[1:])
-        seg_len = csum[self.seg_first + self.seg_count] - csum[self.seg_first]
-        in_image = csum[self.seg_first] - csum[self.seg_image * self.spf]
-        ar = torch.arange(self.images + 1, device=self.device) * self.spf
-        img_bytes = csum[ar[1:]] - csum[ar[:-1]]
-        M = torch.zeros(self.world * self.world, dtype=torch.int64, device=self.device).index_add_(0, self.seg_owner * self.world + self.seg_root, seg_len)
-        M = M.view(self.world, self.world)
-        ordered = seg_len[self.xorder]
-        run = torch.cumsum(ordered, 0) - ordered                      # offset in the concatenation of ALL exchange buffers
-        recv_total = M.sum(0)                                         # bytes every gathering rank holds
-        base = torch.cumsum(recv_total, 0) - recv_total
-        in_exchange = torch.empty_like(seg_len)
-        in_exchange[self.xorder] = run - base[self.seg_root[self.xorder]]  # offset inside ITS gathering rank's buffer
-        return seg_len, in_exchange, in_image, img_bytes, M
+    def _range_sums(self, table_i32, start_d):
+        """int64 [n_seg] on self.device: bytes of every (image, chunk) segment = sum of its slices' lengths (read as u32, clamped
+        to a slice's capacity) -- ONE launch (llcomp_mi_device_range_sums); torch arithmetic for the CPU tensors of the gloo tests"""
+        if table_i32.is_cuda:
+            out = torch.empty(self.n_seg, dtype=torch.int64, device=self.device)
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            _check(_lib.load().llcomp_mi_device_range_sums(table_i32.data_ptr(), start_d.data_ptr(), self.seg_count_d.data_ptr(), out.data_ptr(),
+                                                           self.n_seg, self.slice_cap, st))
+            return out
+        csum = torch.zeros(table_i32.numel() + 1, dtype=torch.int64)
+        torch.cumsum(self._as_lengths(table_i32), 0, out=csum[1:])
+        return csum[start_d + self.seg_count_d] - csum[start_d]
+
+    def _host_tables(self, seg_len):
+        """From the byte count of every (image, chunk) segment (numpy int64 [n_seg], on the host: a few hundred numbers): its
+        offset in the gathering rank's exchange buffer, its offset inside its image's payload, every image's payload bytes and
+        the message matrix M[coding rank][gathering rank]."""
+        per_image = seg_len.reshape(self.images, -1)
+        in_image = (np.cumsum(per_image, axis=1) - per_image).reshape(-1)
+        img_bytes = per_image.sum(axis=1)
+        M = np.zeros((self.world, self.world), dtype=np.int64)
+        np.add.at(M, (self.seg_owner_h, self.seg_root_h), seg_len)
+        ordered = seg_len[self.xorder_h]
+        run = np.cumsum(ordered) - ordered                               # offset in the concatenation of ALL exchange buffers
+        recv_total = M.sum(axis=0)                                       # bytes every gathering rank holds
+        base = np.cumsum(recv_total) - recv_total
+        in_exchange = np.empty_like(seg_len)
+        in_exchange[self.xorder_h] = run - base[self.seg_root_h[self.xorder_h]]   # offset inside ITS gathering rank's buffer
+        return in_exchange, in_image, img_bytes, M
+
+    def _offsets_to_device(self, *rows):
+        """small int64 rows (numpy) -> one [k, n] tensor on self.device in one asynchronous copy from pinned memory (no host wait
+        behind the work already queued on the stream)"""
+        t = torch.from_numpy(np.ascontiguousarray(np.stack(rows).astype(np.int64)))
+        if self.device.type == "cuda":
+            return t.pin_memory().to(self.device, non_blocking=True)
+        return t
 
     def _exchange(self, send, send_split, recv_split, m_max):
         """variable-size all-to-all of bytes (RCCL alltoallv on device tensors); returns the receive buffer on self.device"""
@@ -283,42 +324,45 @@ class ShardedCodec:
         self._pending = self.band.encode(local_px) if self.band is not None else None
 
     def encode_finish(self):
-        """the exchange: slice-table all_gather, message sizes to the host, all-to-all of the payloads, concatenator"""
+        """the exchange: slice-table all_gather, segment byte counts to the host, all-to-all of the payloads, concatenator.
+        Device work beside the collectives: one range-sum launch, one gather of my images' slice tables, one concatenator
+        launch (round 2 ran ~60 small torch kernels here, each queued behind the other streams' slice kernels)."""
         payload = lens = status = None
         if self._pending is not None:
             payload, lens, total, status = self._pending
         self._pending = None
-        all_lens, all_status = self._all_lens(lens, status)  # collective 1: slice-length tables (+ every rank's status word)
-        lens_c = all_lens[self.perm]                         # container order
-        seg_len, in_exchange, in_image, img_bytes, M = self._segment_tables(lens_c)
-        host = torch.cat([M.reshape(-1), img_bytes, all_status]).cpu()   # the one host round trip: message and container sizes
-        ww = self.world * self.world
-        for r, bits in enumerate(host[ww + self.images:].tolist()):  # the same verdict on every rank, before collective 2
+        gathered = self._gather_lens(lens, status)           # collective 1: slice-length tables (+ every rank's status word)
+        seg_len_d = self._range_sums(gathered, self.enc_start_d)
+        status_d = gathered.view(self.world, self.n1)[:, self.n1 - 1].to(torch.int64)
+        host = torch.cat([seg_len_d, status_d]).cpu().numpy()  # the one host round trip: segment bytes (=> every size) + verdicts
+        seg_len = host[: self.n_seg]
+        for r, bits in enumerate(host[self.n_seg:].tolist()):  # the same verdict on every rank, before collective 2
             if bits:
                 code = self.band.status_code(bits) if hasattr(self.band, "status_code") else 7
                 raise LlcompError(code, f"rank {r}'s local encode failed, status bits {bits}")
-        M_h = host[:ww].view(self.world, self.world).tolist()
-        img_b = host[ww:ww + self.images].tolist()
+        in_exchange, in_image, img_bytes, M = self._host_tables(seg_len)
         if payload is None:
             payload = torch.empty(0, dtype=torch.uint8, device=self.device)
         # collective 2: every coding rank's packed payload to the gathering ranks, GPU to GPU
-        exchange = self._exchange(payload, M_h[self.rank], [M_h[s][self.rank] for s in range(self.world)], max(max(r) for r in M_h))
+        exchange = self._exchange(payload, M[self.rank].tolist(), M[:, self.rank].tolist(), int(M.max()))
         if not self.my_images:
             return {}
         # containers of my images = [header][table][payload], payload interleaved chunk by chunk by the device concatenator
         head = HEADER + 4 * self.spf
-        sizes = [head + img_b[b] for b in self.my_images]
+        sizes = [head + int(img_bytes[b]) for b in self.my_images]
         bases = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         buf = torch.empty(int(bases[-1]) + 16, dtype=torch.uint8, device=self.device)
-        table = lens_c.to(torch.int32).view(self.images, self.spf)
-        base_of = torch.zeros(self.images, dtype=torch.int64, device=self.device)
+        table = self._as_lengths(gathered[self.perm_mine_d]).to(torch.int32).view(len(self.my_images), self.spf)  # container order
+        base_of = np.zeros(self.images, dtype=np.int64)
         for j, b in enumerate(self.my_images):
             buf[bases[j]:bases[j] + HEADER] = self.header
-            buf[bases[j] + HEADER:bases[j] + head] = table[b].view(torch.uint8)  # little-endian u32, as on the wire
-            base_of[b] = int(bases[j])
-        mine = self.seg_mine
-        dst_off = base_of[self.seg_image[mine]] + head + in_image[mine]
-        _copy_segments(exchange, buf, in_exchange[mine].contiguous(), dst_off, seg_len[mine].contiguous(), max(sizes))
+            buf[bases[j] + HEADER:bases[j] + head] = table[j].view(torch.uint8)  # little-endian u32, as on the wire
+            base_of[b] = bases[j]
+        mine = self.seg_mine_h
+        offs = self._offsets_to_device(in_exchange[mine], base_of[self.seg_image_h[mine]] + head + in_image[mine], seg_len[mine])
+        _copy_segments(exchange, buf, offs[0], offs[1], offs[2], max(sizes))
+        if offs.is_cuda:
+            offs.record_stream(torch.cuda.current_stream(self.device))
         return {b: buf[bases[j]:bases[j + 1]] for j, b in enumerate(self.my_images)}
 
     # ---- decode -------------------------------------------------------------------------------------------------
@@ -342,65 +386,58 @@ class ShardedCodec:
         return out
 
     def decode_begin(self, containers, validate=True):
-        """the exchange back (slice-table all_gather, message sizes to the host, all-to-all of the payloads) and the local
+        """the exchange back (slice-table all_gather, segment byte counts to the host, all-to-all of the payloads) and the local
         decode, enqueued on the current stream; nothing waits for the decoded pixels"""
         head = HEADER + 4 * self.spf
-        per_root = max(1, max(sum(1 for b in range(self.images) if self.root_of[b] == r) for r in range(self.world)))
         # [per_root * spf slice lengths | 1 flag]: a rank that holds a container it cannot use says so in the flag word of the
         # same all_gather, and every rank raises together (a lone raise would leave the others waiting in the collective)
-        mine_tab = torch.zeros(per_root * self.spf + 1, dtype=torch.int32, device=self.comm_device)
+        row = self.per_root * self.spf + 1
+        mine_tab = torch.zeros(row, dtype=torch.int32, device=self.comm_device)
         for j, b in enumerate(self.my_images):
             cont = containers.get(b) if hasattr(containers, "get") else containers[b]
             if cont is None or cont.numel() < head or (validate and bytes(cont[:HEADER].cpu().numpy()) != bytes(self.header.cpu().numpy())):
                 mine_tab[-1] = 1
                 continue
             mine_tab[j * self.spf:(j + 1) * self.spf] = self._to_comm(cont[HEADER:head].clone().view(torch.int32))  # (clone: dword alignment)
-        tabs = torch.empty(self.world * mine_tab.numel(), dtype=torch.int32, device=self.comm_device)
+        tabs = torch.empty(self.world * row, dtype=torch.int32, device=self.comm_device)
         dist.all_gather_into_tensor(tabs, mine_tab, group=self.group)    # collective 1: the slice tables of every image
-        tabs = tabs.view(self.world, per_root * self.spf + 1)
-        flags = tabs[:, -1].to(self.device).to(torch.int64)
-        tabs = tabs[:, :-1].reshape(self.world, per_root, self.spf)
-        slot = [0] * self.world
-        pick = []
-        for b in range(self.images):
-            pick.append((self.root_of[b], slot[self.root_of[b]]))
-            slot[self.root_of[b]] += 1
-        # the tables come out of containers: read as the u32 they are and clamped to a slice's capacity, so that a damaged
-        # table can neither go negative nor size a copy beyond what the geometry allows (the decoder reports the damage)
-        lens_c = self._as_lengths(torch.stack([tabs[r, j] for r, j in pick]).reshape(-1).to(self.device))
-        seg_len, in_exchange, in_image, img_bytes, M = self._segment_tables(lens_c)
-        host = torch.cat([M.reshape(-1), flags]).cpu().tolist()   # the one host round trip: message sizes + every rank's verdict on its containers
-        ww = self.world * self.world
-        bad = host[ww:]
+        tabs = tabs.to(self.device)
+        # The tables come out of containers: read as the u32 they are and clamped to a slice's capacity wherever a size is
+        # derived from them, so that a damaged table can neither go negative nor size a copy beyond what the geometry allows
+        # (the decoder reports the damage).
+        lens_raw = tabs[self.dec_src_d]                                  # container order, [images * spf] int32
+        seg_len_d = self._range_sums(lens_raw, self.dec_start_d)
+        flags_d = tabs.view(self.world, row)[:, row - 1].to(torch.int64)
+        host = torch.cat([seg_len_d, flags_d]).cpu().numpy()             # the one host round trip: segment bytes + every rank's verdict on its containers
+        bad = host[self.n_seg:].tolist()
         if any(bad):
             raise ValueError("container does not match this ShardedCodec's geometry (rank(s) %s)" % [r for r, f in enumerate(bad) if f])
-        M_h = [host[r * self.world:(r + 1) * self.world] for r in range(self.world)]
+        seg_len = host[: self.n_seg]
+        in_exchange, in_image, img_bytes, M = self._host_tables(seg_len)
         # my containers -> send buffer ordered (coding rank, frame, chunk); the table may promise more than a damaged
         # container holds: clip, the decoder reports it
-        n_out = int(sum(M_h[s][self.rank] for s in range(self.world)))
+        n_out = int(M[:, self.rank].sum())
         send = torch.zeros(n_out + 16, dtype=torch.uint8, device=self.device)
-        if self.my_images:
-            n_ch = len(self.chunks)
-            for b in self.my_images:  # one concatenator launch per container: its (image, chunk) segments are consecutive
-                cont = containers[b]
-                idx = torch.arange(b * n_ch, (b + 1) * n_ch, device=self.device)
-                src_off = head + in_image[idx]
-                seg_clip = torch.minimum(seg_len[idx], torch.clamp(int(cont.numel()) - src_off, min=0))
-                _copy_segments(cont, send, src_off, in_exchange[idx].contiguous(), seg_clip.contiguous(), int(cont.numel()))
+        n_ch = len(self.chunks)
+        for b in self.my_images:  # one concatenator launch per container: its (image, chunk) segments are consecutive
+            cont = containers[b]
+            idx = np.arange(b * n_ch, (b + 1) * n_ch)
+            src_off = head + in_image[idx]
+            seg_clip = np.minimum(seg_len[idx], np.maximum(int(cont.numel()) - src_off, 0))
+            offs = self._offsets_to_device(src_off, in_exchange[idx], seg_clip)
+            _copy_segments(cont, send, offs[0], offs[1], offs[2], int(cont.numel()))
+            if offs.is_cuda:
+                offs.record_stream(torch.cuda.current_stream(self.device))
         # collective 2: every rank gets the bytes of its slices, already in its codec's order
-        recv = self._exchange(send, [M_h[s][self.rank] for s in range(self.world)], M_h[self.rank], max(max(r) for r in M_h))
+        recv = self._exchange(send, M[:, self.rank].tolist(), M[self.rank].tolist(), int(M.max()))
         out = torch.empty((self.images, self.local_h, self.w, self.c), dtype=torch.uint8, device=self.device)
         if self.band is None:
             self._pending_decode = (out, None)
             return
-        # this rank's slice lengths in ITS codec's order (frame, local tile rows): the inverse of the permutation
-        all_order = torch.empty(self.world * self.images * self.max_local, dtype=torch.int64, device=self.device)
-        all_order[self.perm] = lens_c
-        per = self.local_slices[self.rank]
-        base = self.rank * self.images * self.max_local
-        my_lens = all_order[base: base + self.images * per].to(torch.int32).contiguous()
+        # this rank's slice lengths in ITS codec's order (frame, local tile rows)
+        my_lens = self._as_lengths(lens_raw[self.inv_mine_d]).to(torch.int32).contiguous()
         # (recv and my_lens stay referenced until decode_finish: the kernels that read them are only queued here)
-        self._pending_decode = (out, self.band.decode(recv, int(sum(M_h[self.rank])), my_lens, out), recv, my_lens)
+        self._pending_decode = (out, self.band.decode(recv, int(M[self.rank].sum()), my_lens, out), recv, my_lens)
 
     def gather_pixels(self, local_out, dst=0):
         """rank `dst`: the full batch [images, h, w, c] assembled from every rank's decoded rows (one message per rank);
