@@ -222,28 +222,31 @@ def test_empty_and_mismatched_inputs_are_rejected(mi):
     assert e.value.status == mi.BAD_ARGS
 
 
-def test_abi1_opts_struct_still_accepted(mi, orc):
-    """llcomp_mi_opts grew a trailing field in ABI 2 (small_model); a caller compiled against ABI 1 passes struct_size 24."""
+def test_opts_struct_of_another_abi_is_refused(mi, orc):
+    """One struct layout per ABI version (llcomp_mi.h): llcomp_mi_opts is checked through struct_size and a caller built
+    against another header -- ABI 1 had no small_model field and passed 24 -- is refused instead of being half-read; the
+    binding checks llcomp_mi_abi_version() when it loads the library."""
     import ctypes as C
 
     from llcomp_amd import _lib
 
     class Opts1(C.Structure):
         _fields_ = [("struct_size", C.c_uint32), ("format", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32),
-                    ("planar", C.c_uint32), ("device", C.c_int32)]
+                    ("planar", C.c_uint32), ("device", C.c_int32), ("pad", C.c_uint32)]
 
     img = make_image("mid", 50, 20, 3)
     L = _lib.load()
-    o = Opts1(24, mi.FORMAT_SLICED, 16, 1, 1, -1)
+    assert L.llcomp_mi_abi_version() == _lib.ABI_VERSION
     out, n = _lib.u8p(), C.c_size_t()
-    rc = L.llcomp_mi_encode(img.ctypes.data_as(_lib.u8p), 50, 20, 3, C.cast(C.byref(o), C.POINTER(_lib.Opts)), C.byref(out), C.byref(n))
-    assert rc == mi.OK
+    for size in (24, 20, 32):
+        o = Opts1(size, mi.FORMAT_SLICED, 16, 1, 1, -1, 0)
+        assert L.llcomp_mi_encode(img.ctypes.data_as(_lib.u8p), 50, 20, 3, C.cast(C.byref(o), C.POINTER(_lib.Opts)), C.byref(out), C.byref(n)) == mi.BAD_ARGS
+    o = Opts1(C.sizeof(_lib.Opts), mi.FORMAT_SLICED, 16, 1, 1, -1, 0)
+    assert L.llcomp_mi_encode(img.ctypes.data_as(_lib.u8p), 50, 20, 3, C.cast(C.byref(o), C.POINTER(_lib.Opts)), C.byref(out), C.byref(n)) == mi.OK
     try:
         assert C.string_at(out, n.value) == orc.compress_sliced(img, 16, 1, True)
     finally:
         L.llcomp_mi_free(out)
-    o.struct_size = 20
-    assert L.llcomp_mi_encode(img.ctypes.data_as(_lib.u8p), 50, 20, 3, C.cast(C.byref(o), C.POINTER(_lib.Opts)), C.byref(out), C.byref(n)) == mi.BAD_ARGS
 
 
 # ---- stage A kernel alone vs the oracle's intermediate dump ------------------------------------------------------
