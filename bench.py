@@ -260,7 +260,8 @@ def brief(m, **extra):
 def profile_numbers(F, tile_w, tile_h, planar, content, S, dom):
     """HBM-side bytes and VALU instructions per launch of kernel `dom` from the committed rocprofv3 PMC passes of THIS
     configuration (profiles/*_traffic.json); (None, None, None) when no committed profile matches."""
-    for name in ("r02_default_traffic.json", "r02_single_stream_traffic.json", "r01_default_traffic.json", "r01_single_stream_traffic.json"):
+    for name in ("r03_default_traffic.json", "r03_single_stream_traffic.json", "r02_default_traffic.json", "r02_single_stream_traffic.json",
+                 "r01_default_traffic.json", "r01_single_stream_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
             same = all(tj["config"].get(k) == v for k, v in (("frames_per_step_per_gpu", F), ("tile_w", tile_w), ("tile_h", tile_h),

@@ -113,6 +113,14 @@ namespace llcomp_mi {
 void codec_release(llcomp_mi_codec* k) {
     if (!k) return;
     DeviceGuard guard(k->device);
+    // The event travels with the blocks only while the codec's last call is still running.  Usually it has long finished:
+    // then the blocks are parked without it (an event must not outlive the stream it was recorded on -- a lane's private
+    // stream is destroyed right after this -- and a finished event has nothing left to say).  A query that fails (the
+    // caller destroyed its stream, which drains it) counts as finished.
+    if (k->done && k->done->ev && hipEventQuery(k->done->ev) != hipErrorNotReady) {
+        (void)hipGetLastError();
+        k->done.reset();
+    }
     dev_free(k->d_sym_or_rec, k->done);
     dev_free(k->d_lane_order, k->done);
     dev_free(k->d_states, k->done);

@@ -29,6 +29,7 @@ void lane_destroy(HostLane* l) {
     {
         DeviceGuard guard(l->k ? l->k->device : 0);
         if (l->stream) (void)hipStreamSynchronize(l->stream);
+        if (l->k) l->k->done.reset();  // the lane's stream is drained and about to be destroyed: no event may refer to it afterwards
         dev_free(l->d_px);
         dev_free(l->d_container);
         dev_free(l->d_len_legacy);

@@ -122,6 +122,42 @@ def test_stress_parity_without_parking():
         mi.set_pool_limit(before)
 
 
+@pytest.mark.gpu
+def test_parked_blocks_outlive_the_streams_of_their_lanes():
+    """Blocks of a destroyed codec object are parked with the event of its last call; a host-call lane destroys its private
+    stream right after parking.  An event must never be waited for after its stream is gone (round 3 found the HIP runtime
+    answering hipErrorCapturedEvent, a sticky error that surfaced in the next torch call): lane churn over more shapes than
+    the lane cache holds, then new codec objects of the same sizes take the parked blocks, and the process stays healthy."""
+    import torch
+
+    import llcomp_amd as mi
+    import orc as orc_mod
+
+    orc = orc_mod.Orc()
+    rng = np.random.default_rng(77)
+    shapes = [(int(rng.integers(200, 420)), int(rng.integers(40, 90)), 3) for _ in range(10)]
+    for rep in range(2):
+        for w, h, c in shapes:  # ten shapes through a four-lane cache: six lanes are destroyed per pass
+            img = rng.integers(0, 256, size=(h, w, c), dtype=np.uint8)
+            s = mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=64, tile_h=1, planar=True)
+            assert s == orc.compress_sliced(img, 64, 1, True)
+            assert np.array_equal(mi.decompress_image(s).pixels, img)
+        for w, h, c in shapes:  # device-resident codec objects of the same shapes reuse the parked workspaces
+            codec = mi.Codec(1, w, h, c, 64, 1, True)
+            img = torch.randint(0, 256, (h, w, c), dtype=torch.uint8, device="cuda")
+            pay = torch.empty(codec.max_payload_bytes, dtype=torch.uint8, device="cuda")
+            ln = torch.empty(codec.n_slices, dtype=torch.int32, device="cuda")
+            tot, st = torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros(2, dtype=torch.int32, device="cuda")
+            out = torch.empty_like(img)
+            stream = torch.cuda.current_stream().cuda_stream
+            codec.encode(img.data_ptr(), pay.data_ptr(), pay.numel(), ln.data_ptr(), tot.data_ptr(), st.data_ptr(), stream)
+            codec.decode(pay.data_ptr(), pay.numel(), ln.data_ptr(), out.data_ptr(), st[1:].data_ptr(), stream)
+            codec.close()  # work may still be in flight: the blocks are parked behind the codec's event
+            torch.cuda.synchronize()
+            assert st.tolist() == [0, 0] and torch.equal(out, img)
+    assert float(torch.zeros(1, device="cuda").item()) == 0.0  # no sticky HIP error left behind
+
+
 ROW_WIDTHS = (1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 63, 64, 65, 66, 127, 129, 200, 257, 480, 500, 1000)
 ROW_TILES = (1, 2, 3, 7, 8, 9, 63, 64, 65, 128, 130)
 
