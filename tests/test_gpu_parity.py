@@ -493,6 +493,10 @@ def test_cli_roundtrip_matches_reference_behaviour(mi, orc, tmp_path):
     # sliced container through the CLI, damaged input -> exit code 1 with the reference's message
     assert subprocess.run([exe_c, str(ppm), "--sliced", "16x1"]).returncode == 0
     assert (tmp_path / "a.ppm.llcomp").read_bytes() == orc.compress_sliced(img, 16, 1, True)
+    # --sliced auto: one-row slices of the width the library suggests for one image per call
+    h_, w_, c_ = img.shape
+    assert subprocess.run([exe_c, str(ppm), "--sliced", "auto"]).returncode == 0
+    assert (tmp_path / "a.ppm.llcomp").read_bytes() == orc.compress_sliced(img, mi.suggest_tile_w(1, w_, h_, c_, True), 1, True)
     # the LargeModel = false variant through the CLIs: the sliced container carries the flag, the reference format needs it said
     orc.set_small_model(True)
     try:
