@@ -642,6 +642,22 @@ def clock_numbers():
     return None
 
 
+class quiet_stdout:
+    """RCCL prints a version banner on STDOUT when a communicator comes up; stdout carries exactly one JSON line, so the file
+    descriptor points at stderr while communicators are created (init, new_group, their first collective)"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 class Watchdog:
     """The secondary legs of the N > 1 line run behind this: if they have not finished `seconds` after arm(), rank 0 prints
     the line with what it has (the headline is complete by then) and every rank leaves with exit code 0 -- a leg that hangs
@@ -736,26 +752,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
         sk.close()
-    # RCCL prints a version banner on STDOUT when its communicator comes up; stdout carries exactly one JSON line, so the
-    # file descriptor points at stderr until the communicator exists (init + a first collective)
-    sys.stdout.flush()
-    saved_fd = os.dup(1)
-    os.dup2(2, 1)
-    try:
+    with quiet_stdout():
         if args.rehearse_one_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         warm = torch.zeros(1, device="cuda")
         dist.all_reduce(warm)
-        solo = dist.new_group(ranks=[0]) if world > 1 else None  # rank 0 alone: the one-GPU point of the config-4 curve
-        if solo is not None and rank == 0:
-            dist.all_reduce(warm, group=solo)
         torch.cuda.synchronize()
-    finally:
-        sys.stdout.flush()
-        os.dup2(saved_fd, 1)
-        os.close(saved_fd)
     barrier = dist.barrier if world > 1 else None
 
     planar = not args.interleaved
@@ -780,6 +784,13 @@ def main():
         n4 = max(3, args.steps // 2)
         c4 = {}
         try:
+            # rank 0 alone = the one-GPU point of the config-4 curve.  The subgroup is made HERE, behind the watchdog and
+            # after the headline is complete: a communicator split that the runtime refuses costs this leg, not the line
+            with quiet_stdout():
+                solo = dist.new_group(ranks=[0])
+                if rank == 0:
+                    dist.all_reduce(warm, group=solo)
+                    torch.cuda.synchronize()
             one = None
             if rank == 0:  # the one-GPU point of the same batch, same code path, on a one-rank subgroup
                 dt1, pay1 = c4_run(B, size, args.c4_tile_w, args.c4_tile_h, n4, 3, local_rank, 1, 0, parts=args.c4_parts, group=solo)
