@@ -293,7 +293,7 @@ def gpu_local_cpus(device=0):
         return None
 
 
-def link_rate(n=256 << 20, reps=6):
+def link_rate(n=256 << 20, reps=6, streams=None):
     """what the host link gives on this box right now: copies between hipHostMalloc'ed (pinned, GPU-local) memory and HBM, H2D
     alone, D2H alone and both directions at once on two HIP streams, 256 MiB each, in GB/s -- what the PCIe-inclusive config-5
     leg is to be read against.  (Plain hipMemcpyAsync through ctypes: the same calls and the same kind of buffers as the
@@ -310,7 +310,7 @@ def link_rate(n=256 << 20, reps=6):
     hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     h_a, h_b = mi.PinnedBuffer(n), mi.PinnedBuffer(n)
     d_a, d_b = torch.empty(n, dtype=torch.uint8, device="cuda"), torch.empty(n, dtype=torch.uint8, device="cuda")
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    s1, s2 = streams or (torch.cuda.Stream(), torch.cuda.Stream())
 
     def run(h2d, d2h, k):
         torch.cuda.synchronize()

@@ -14,7 +14,7 @@ frames = bench.make_frames("g3", 32, 0, distinct=8)
 print("link:", json.dumps(bench.link_rate()), " env:", {k: v for k, v in os.environ.items() if k.startswith(("HSA_", "GPU_", "HIP_"))}, flush=True)
 local = bench.gpu_local_cpus(0)
 print("gpu-local cpus:", len(local or []), "of", len(os.sched_getaffinity(0)), "usable", flush=True)
-VARIANTS = (("default", {}), ("no pinning", {"pin": False}), ("no verification", {"verify": False}),
+VARIANTS = (("default", {}), ("long: 8 passes", {"passes": 8}), ("long3: 8 passes 3 pipelines", {"passes": 8, "pipelines": 3, "frames_per_job": 8, "depth": 4}), ("no pinning", {"pin": False}), ("no verification", {"verify": False}),
             ("4 pipelines depth 6", {"pipelines": 4, "depth": 6, "encodes_in_flight": 2}),
             ("3 pipelines depth 6", {"pipelines": 3, "depth": 6, "encodes_in_flight": 2, "frames_per_job": 2}),
             ("2 pipelines 8 frames/job", {"frames_per_job": 8, "depth": 6, "encodes_in_flight": 2}),
