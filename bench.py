@@ -310,21 +310,37 @@ def link_rate(n=256 << 20, reps=6, streams=None):
     hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     h_a, h_b = mi.PinnedBuffer(n), mi.PinnedBuffer(n)
     d_a, d_b = torch.empty(n, dtype=torch.uint8, device="cuda"), torch.empty(n, dtype=torch.uint8, device="cuda")
-    s1, s2 = streams or (torch.cuda.Stream(), torch.cuda.Stream())
+    # FRESH HIP streams of this function's own (not torch's pooled ones): which copy engine a stream's copies run on is decided
+    # inside the HIP runtime when the stream first copies, and a pooled stream that has already been used elsewhere can sit on
+    # a shared engine (profiles/r03_c5_repeat.txt, run 6)
+    hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    own = []
+    if streams is None:
+        for _ in range(2):
+            h = C.c_void_p()
+            assert hip.hipStreamCreateWithFlags(C.byref(h), 1) == 0
+            own.append(h)
+        s1h, s2h = own[0].value, own[1].value
+    else:
+        s1h, s2h = streams[0].cuda_stream, streams[1].cuda_stream
 
     def run(h2d, d2h, k):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(k):
             if h2d:
-                assert hip.hipMemcpyAsync(d_a.data_ptr(), h_a.ptr, n, 1, s1.cuda_stream) == 0
+                assert hip.hipMemcpyAsync(d_a.data_ptr(), h_a.ptr, n, 1, s1h) == 0
             if d2h:
-                assert hip.hipMemcpyAsync(h_b.ptr, d_b.data_ptr(), n, 2, s2.cuda_stream) == 0
+                assert hip.hipMemcpyAsync(h_b.ptr, d_b.data_ptr(), n, 2, s2h) == 0
         torch.cuda.synchronize()
         return (h2d + d2h) * k * n / (time.perf_counter() - t0) / 1e9
 
     run(True, True, 2)
     out = {"h2d_alone_GBps": round(run(True, False, reps), 1), "d2h_alone_GBps": round(run(False, True, reps), 1), "both_directions_GBps": round(run(True, True, reps), 1)}
+    torch.cuda.synchronize()
+    for h in own:
+        hip.hipStreamDestroy(h)
     h_a.close()
     h_b.close()
     del d_a, d_b
@@ -847,6 +863,10 @@ def main():
         return
 
     # ---- N = 1: BASELINE config 3 (headline) ------------------------------------------------------------------------
+    # What the host link gives, measured FIRST: the rate a stream's copies get depends on what the process has done before
+    # (the HIP runtime's copy-engine assignment: 57 / 57 / 97 GB/s in a fresh process, 57 / 30 / 57-80 on streams made after the
+    # headline leg -- profiles/r03_c5_repeat.txt run 6), so the reference for the config-5 leg is taken while the process is young
+    link0 = link_rate() if not args.no_also and (not args.also_only or "c5" in args.also_only.split(",")) else None
     frames_np = make_frames(args.content, F, rank)
     m = measure(frames_np, args.tile_w, args.tile_h, planar, args.streams, args.steps, args.warmup, local_rank, isolated=not args.no_isolated)
     res = headline(args, m, world, planar)
@@ -873,7 +893,7 @@ def main():
         legacy_box = {}
 
         def leg_c5():  # three repetitions: the pipeline's steady state is sensitive to how the copies of the jobs fall over each other (tools/c5_repeat.py)
-            link = link_rate()
+            link = dict(link0, measured="at the start of the process")
             c5_stream(frames_np, args.tile_w, args.tile_h, planar, passes=2)  # untimed: first touch of the pinned buffers, lanes, code objects
             runs = sorted((c5_stream(frames_np, args.tile_w, args.tile_h, planar, link=link) for _ in range(3)), key=lambda r: r["value"])
             leg = dict(runs[1])  # the median run
