@@ -654,31 +654,16 @@ __device__ __forceinline__ uint32_t dec_step_acc(RangeDec& d, uint32_t P, entry_
     }
     return nx;
 }
+// A slot that is decoded at most once per sample: selects on the borrow in VCC.  (Round 2 let every lane take the bit-0
+// outcome and the lanes with a 1 patch up inside an exec-masked region -- two vector instructions fewer, but three scalar
+// ones and an LDS store more, and scalar work is not free: 1 % slower, DESIGN.md section 4.  The ENCODER keeps its regions:
+// there the select form makes hipcc spill an entry to scratch, +14 %.)
 template <int SLOT, bool CHECKED, bool INLDS>
 __device__ __forceinline__ bool dec_once(RangeDec& d, Bank& bank, const Entries& E) {
     const entry_t en = E.get<SLOT>();
-    if constexpr (INLDS) {
-        // every lane takes the bit-0 outcome (range = r0, low stays, successor = low half of the entry, stored straight
-        // away); the lanes that decode a 1 patch up inside one exec-masked region (see enc_once)
-        if (CHECKED && d.win <= 1) dec_append(d);
-        const uint32_t r1 = __umul24(d.range, prob_of(en)) >> 8;
-        d.range -= r1;
-        put_state<SLOT, true>(bank, uint32_t(en));
-        uint32_t diff;
-        const bool bit = !__builtin_usub_overflow(d.low, d.range, &diff);
-        if (bit) {
-            asm volatile("" : "+v"(diff));  // (keeps hipcc from turning this region back into selects)
-            d.low = diff;
-            d.range = r1;
-            put_state<SLOT, true>(bank, uint32_t(en >> 32));
-        }
-        dec_refill(d);
-        return bit;
-    } else {
-        const bool bit = dec_core<CHECKED>(d, prob_of(en));
-        put_state<SLOT, INLDS>(bank, successor(en, bit));
-        return bit;
-    }
+    const bool bit = dec_core<CHECKED>(d, prob_of(en));
+    put_state<SLOT, INLDS>(bank, successor(en, bit));
+    return bit;
 }
 // getSymbol<true,4,6,7> (llcomp.hpp:219-247).  Returns false on "Invalid exponent".  Arithmetic modulo 2^32.
 template <bool ALL, bool CHECKED, bool INLDS>
@@ -837,7 +822,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                     atomicOr(status, kStBadExponent);
                     return;
                 }
-                hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true)));
+                hot = 2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true));  // (ballots are wave-uniform: scalar arithmetic)
                 if (neg) v = 0u - v;
                 const int val = int(int16_t(uint32_t(lv) + v));
                 held_val = val;
@@ -882,7 +867,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                             atomicOr(status, kStBadExponent);
                             return;
                         }
-                        hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true)));
+                        hot = 2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true));  // (ballots are wave-uniform: scalar arithmetic)
                         banks[size_t(ctx) << bsh] = bank_tagged<LDSTAB>(uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32), gpat);
                         if (neg) v = 0u - v;
                         *q = int16_t(uint32_t(predict(n)) + v);
@@ -931,7 +916,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                         atomicOr(status, kStBadExponent);
                         return;  // this lane's slice is unusable; the whole call reports the error
                     }
-                    hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true)));
+                    hot = 2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true));  // (ballots are wave-uniform: scalar arithmetic)
                     held_bank = uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32);
                     banks[size_t(ctx) << bsh] = bank_tagged<LDSTAB>(held_bank, gpat);
                     if (neg) v = 0u - v;
