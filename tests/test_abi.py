@@ -124,3 +124,26 @@ def test_band_concatenator_matches_oracle_container(mi, orc, shape, planar):
         assert mi.split_band(whole, a, b) == band
     with pytest.raises(mi.LlcompError):
         mi.merge_bands([bands[0], orc.compress_sliced(img[: th], tw + 1, th, planar)])
+
+
+def test_fnv_helper_matches_the_checker_and_continues_over_pieces(mi, orc):
+    """llcomp_mi_fnv1a64 (the checksum of the golden vectors) == the oracle's, also when a container lies in several pieces"""
+    from conftest import fnv_hex
+
+    data = bytes((i * 37 + 11) & 0xFF for i in range(5000))
+    assert mi.fnv1a64(data) == fnv_hex(orc, data)
+    assert mi.fnv1a64(data[:24], data[24:1000], np.frombuffer(data[1000:], dtype=np.uint8)) == fnv_hex(orc, data)
+    assert mi.fnv1a64(b"") == "%016x" % 1469598103934665603
+
+
+def test_suggested_slice_width(mi):
+    """llcomp_mi_suggest_tile_w: the widest one-row slice (64..480) that still gives about four wavefronts per SIMD"""
+    assert mi.suggest_tile_w(1, 3840, 2160, 3, True) == 80            # one 4K frame: 48 x 6480 slices
+    assert mi.suggest_tile_w(32, 3840, 2160, 3, True) == 480          # bench.py's batch: the throughput default
+    assert mi.suggest_tile_w(1, 3840, 2160, 3, False) == 64           # interleaved: a third of the slices, the floor
+    assert mi.suggest_tile_w(1, 100, 50, 3, True) == 100              # never wider than the image
+    assert mi.suggest_tile_w(4, 8192, 8192, 3, True) == 480
+    assert mi.suggest_tile_w(0, 10, 10, 3, True) == 0
+    for f in (1, 2, 3, 4, 8):
+        tw = mi.suggest_tile_w(f, 3840, 2160, 3, True)
+        assert 64 <= tw <= 480 and 3840 % tw == 0

@@ -355,6 +355,45 @@ def test_state_tables_survive_generation_wrap(mi, orc):
     codec.close()
 
 
+def test_device_range_sums_and_pool_limit(mi):
+    """two small entry points of the multi-GPU path / the device-memory cache"""
+    import ctypes as C
+
+    import torch
+
+    from llcomp_amd import _lib
+
+    L = _lib.load()
+    rng = np.random.default_rng(5)
+    vals = rng.integers(0, 5000, size=100_000, dtype=np.uint32)
+    vals[77] = 0xFFFFFFF0  # a damaged length: clamped to the cap, never negative
+    start = np.array([0, 10, 70, 5000, 99_990, 100_000], dtype=np.int64)
+    count = np.array([10, 100, 20, 60_000, 10, 0], dtype=np.int64)
+    cap = 4000
+    d_vals, d_start, d_count = (torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda() for a in (vals, start, count))
+    d_out = torch.full((len(start),), -1, dtype=torch.int64, device="cuda")
+    assert L.llcomp_mi_device_range_sums(d_vals.data_ptr(), d_start.data_ptr(), d_count.data_ptr(), d_out.data_ptr(), len(start), cap,
+                                         torch.cuda.current_stream().cuda_stream) == mi.OK
+    want = [int(np.minimum(vals[s:s + n], cap).astype(np.int64).sum()) for s, n in zip(start, count)]
+    assert d_out.cpu().tolist() == want
+    # pool limit: with a budget of 0 nothing stays parked when a codec object goes
+    before = int(L.llcomp_mi_pool_limit())
+    try:
+        mi.trim()
+        mi.set_pool_limit(1 << 30)
+        c1 = mi.Codec(2, 640, 360, 3, 64, 1, True)
+        c1.close()
+        parked = mi.pool_idle_bytes()
+        assert 0 < parked <= 1 << 30
+        mi.set_pool_limit(0)
+        assert mi.pool_idle_bytes() == 0
+        c2 = mi.Codec(2, 640, 360, 3, 64, 1, True)
+        c2.close()
+        assert mi.pool_idle_bytes() == 0
+    finally:
+        mi.set_pool_limit(before)
+
+
 def test_payload_capacity_overflow_is_reported(mi):
     import torch
 
