@@ -141,7 +141,8 @@ def test_suggested_slice_width(mi):
     assert mi.suggest_tile_w(1, 3840, 2160, 3, True) == 80            # one 4K frame: 48 x 6480 slices
     assert mi.suggest_tile_w(32, 3840, 2160, 3, True) == 480          # bench.py's batch: the throughput default
     assert mi.suggest_tile_w(1, 3840, 2160, 3, False) == 64           # interleaved: a third of the slices, the floor
-    assert mi.suggest_tile_w(1, 100, 50, 3, True) == 100              # never wider than the image
+    assert mi.suggest_tile_w(1, 100, 50, 3, True) == 64               # a small image: the floor
+    assert mi.suggest_tile_w(1, 40, 50, 3, True) == 40                # never wider than the image
     assert mi.suggest_tile_w(4, 8192, 8192, 3, True) == 480
     assert mi.suggest_tile_w(0, 10, 10, 3, True) == 0
     for f in (1, 2, 3, 4, 8):
