@@ -8,10 +8,10 @@
 //     from a 64-bit register window inside one exec-masked region and tops the window up once per sample, the
 //     encoder renormalises in 6 instructions with eager carry propagation, its output bytes go to a per-lane LDS
 //     staging area that is filled linearly and flushed 16 bytes at a time;
-//   * the model table lives in LDS as 8-byte entries {P, next0, next1, P(next0), P(next1)}: the 8 entries of a
-//     context are requested together when the context is known; the decoder's mantissa tail takes the probability
-//     of the next bin from the half-entry it just selected while the successor's entry is still on its way, and the
-//     encoder (whose bins are known in advance) requests a successor before it codes the bin that leads there;
+//   * the model table lives in LDS as 8-byte entries {next0, P, 8*next0 | next1, P, 8*next1}: the 8 entries of a
+//     context are requested together when the context is known; a run of bins on one slot walks from entry to entry
+//     through the pre-scaled offsets (one shift by a constant per bin), and the encoder (whose bins are known in
+//     advance) requests a successor before it codes the bin that leads there;
 //   * 1-row slices (tile_h == 1) can only ever reach 3 contexts (llcomp.hpp:417-429 with h == 0: hash =
 //     605*quant5(L-l)), so their 24 state bytes stay in LDS and the kernel touches no state memory in HBM at all;
 //     taller slices keep a private 63 KB table (u64 per context) in HBM, fetched one context per sample -- or in
@@ -121,8 +121,8 @@ __device__ __forceinline__ void put_state(Bank& b, uint32_t ns) {  // ns: new st
     else set_slot_state<SLOT>(b.w, ns & 0xFF);
 }
 // successor state / successor probability of entry e for the coded bit
-__device__ __forceinline__ uint32_t prob_of(entry_t e) { return byte_of(uint32_t(e), 2); }
-// half of the entry that belongs to the coded bit: byte0 = successor state, byte1 = its probability
+__device__ __forceinline__ uint32_t prob_of(entry_t e) { return byte_of(uint32_t(e), 1); }
+// half of the entry that belongs to the coded bit: byte0 = successor state, upper half = byte offset of its entry
 __device__ __forceinline__ uint32_t successor(entry_t e, bool bit) { return bit ? uint32_t(e >> 32) : uint32_t(e); }
 
 // State tables in HBM (2-D tiles with several slices per wavefront) are NOT cleared per call: that was 6 GB of memset per
@@ -168,12 +168,9 @@ __device__ __forceinline__ void fetch_rest(Entries& E, const uint32_t (&bank)[2]
     E.e7 = tab[slot_state<7>(bank)];
 }
 
-// tab[nx & 0xFF] with the byte extraction and the scaling in ONE SDWA shift (hipcc emits v_and + v_lshl next to inline asm)
+// the entry of the successor that half-entry `nx` names: its byte offset sits pre-scaled in the upper half (tables.hpp)
 __device__ __forceinline__ entry_t entry_at(const entry_t* tab, uint32_t nx) {
-    uint32_t off;
-    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
-        : "=v"(off) : "v"(3u), "v"(nx));
-    return *reinterpret_cast<const entry_t*>(reinterpret_cast<const char*>(tab) + off);
+    return *reinterpret_cast<const entry_t*>(reinterpret_cast<const char*>(tab) + (nx >> 16));
 }
 
 // ================================================ ENCODER ========================================================
@@ -293,17 +290,17 @@ __device__ __forceinline__ uint32_t enc_step_msb(RangeEnc& e, uint32_t& bits, en
     // then patch it up under exec = VCC: low += r0, range = r1, successor = high half.  Eight vector instructions; the
     // two scalar ones ride along for free (the kernels are bound by VALU issue).
     asm("v_add_co_u32_e32 %[bits], vcc, %[bits], %[bits]\n\t"
-        "v_mul_u32_u24_sdwa %[r1], %[lo], %[range] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+        "v_mul_u32_u24_sdwa %[r1], %[lo], %[range] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
         "v_lshrrev_b32_e32 %[r1], 8, %[r1]\n\t"
         "v_sub_u32_e32 %[range], %[range], %[r1]\n\t"
-        "v_lshlrev_b32_sdwa %[off], %[three], %[lo] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_lshrrev_b32_e32 %[off], 16, %[lo]\n\t"
         "s_and_saveexec_b64 %[save], vcc\n\t"
         "v_add_u32_e32 %[low], %[low], %[range]\n\t"
         "v_mov_b32_e32 %[range], %[r1]\n\t"
-        "v_lshlrev_b32_sdwa %[off], %[three], %[hi] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_lshrrev_b32_e32 %[off], 16, %[hi]\n\t"
         "s_mov_b64 exec, %[save]"
         : [bits] "+v"(bits), [range] "+v"(e.range), [low] "+v"(e.low), [off] "=&v"(off), [r1] "=&v"(r1), [save] "=&s"(saved_exec)
-        : [lo] "v"(uint32_t(cur)), [hi] "v"(uint32_t(cur >> 32)), [three] "v"(3u)  // byte 2 of lo = probability of this state
+        : [lo] "v"(uint32_t(cur)), [hi] "v"(uint32_t(cur >> 32))  // byte 1 of lo = probability of this state
         : "vcc");
     enc_renorm(e);
     return off;
@@ -722,13 +719,13 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entr
         w += w + uint32_t(!dec_once<5, CHECKED, INLDS>(d, bank, E));
         if (ex > 1) {
             entry_t cur = E.e6;
-            uint32_t nx = uint32_t(cur) >> 8;
+            uint32_t nx;
             // w has ex + 1 significant bits when the mantissa is complete.  `limit` is hidden from the optimiser, which
             // would otherwise turn `w < limit` into a shift by a register + compare (two 4-cycle ops per step).
             uint32_t limit = ones + 1;
             asm volatile("" : "+v"(limit));
             do {
-                nx = dec_step_acc<CHECKED>(d, (nx >> 8) & 0xFF, cur, w);
+                nx = dec_step_acc<CHECKED>(d, prob_of(cur), cur, w);
                 cur = entry_at(tab, nx);
             } while (w < limit);
             put_state<6, INLDS>(bank, nx);

@@ -5,8 +5,11 @@
 //   P(bit==1)*256 = mps ? 254 - kLpsProb[level] : kLpsProb[level]
 //   bit == mps -> level+1 (saturating at 63);  bit != mps -> level==0 ? flip mps : kLpsFall[level]
 // entry_lo/entry_hi fold that into one 8-byte LDS entry per state, arranged so that ONE select on the coded bit yields
-// both the successor state and the successor's probability:
-//   lo: byte0 next state if bit 0 | byte1 P(that state) | byte2 P(this state)        hi: byte0 next state if bit 1 | byte1 P(that state)
+// the successor both as a state byte (what a context's bank stores) and as the byte offset of ITS entry in the table
+// (pre-scaled, in the upper half: the address of the next entry is one shift by a constant, a 2-cycle operation, where a
+// byte extraction + scaling is a 4-cycle SDWA shift in every bin of a run):
+//   lo: byte0 next state if bit 0 | byte1 P(this state) | bits 16..31 8 * that next state
+//   hi: byte0 next state if bit 1 | byte1 P(this state) | bits 16..31 8 * that next state
 #pragma once
 #include <cstdint>
 
@@ -32,7 +35,8 @@ constexpr uint32_t state_next(uint32_t s, uint32_t bit) {
     if (level == 0) return mps ^ 1;
     return 2 * kLpsFall[level] + mps;
 }
-constexpr uint32_t entry_lo(uint32_t s) { return state_next(s, 0) | (state_prob(state_next(s, 0)) << 8) | (state_prob(s) << 16); }
-constexpr uint32_t entry_hi(uint32_t s) { return state_next(s, 1) | (state_prob(state_next(s, 1)) << 8); }
+constexpr uint32_t entry_half(uint32_t s, uint32_t bit) { return state_next(s, bit) | (state_prob(s) << 8) | (state_next(s, bit) << 19); }
+constexpr uint32_t entry_lo(uint32_t s) { return entry_half(s, 0); }
+constexpr uint32_t entry_hi(uint32_t s) { return entry_half(s, 1); }
 
 }  // namespace llcomp_mi
