@@ -23,6 +23,7 @@ using namespace llcomp_mi;
 namespace llcomp_mi {
 
 int status_from_bits(uint32_t bits) {
+    if (bits & kStInternal) return LLCOMP_MI_HIP_ERROR;
     if (bits & kStBadExponent) return LLCOMP_MI_BAD_EXPONENT;
     if (bits & kStTruncated) return LLCOMP_MI_TRUNCATED;
     if (bits & kStOverflow) return LLCOMP_MI_OUTPUT_OVERFLOW;

@@ -9,7 +9,7 @@
 namespace llcomp_mi {
 
 // status word bits written by kernels (atomicOr); mapped to llcomp_mi_status by the host
-enum : uint32_t { kStOverflow = 1u, kStBadExponent = 2u, kStTruncated = 4u };
+enum : uint32_t { kStOverflow = 1u, kStBadExponent = 2u, kStTruncated = 4u, kStInternal = 8u /* a kernel found its own assumptions violated */ };
 
 // Stage A (encode side): pixels u8 [frames][h][w][c] -> per-sample symbols u32, low 16 bits folded context, high
 // 16 bits folded residual (llcomp.hpp:396-436).  Layout [frames][h][w][c] for interleaved slices, plane-major

@@ -21,6 +21,14 @@
 #include "device_common.hpp"
 #include "kernels.hpp"
 
+// The encoder's sample of the 1-row-slice kernels as one hand-written block (enc_rows_asm.hpp); 0 = hipcc's code everywhere.
+#ifndef LLMI_ASM_ENC
+#define LLMI_ASM_ENC 1
+#endif
+#if LLMI_ASM_ENC
+#include "enc_rows_asm.hpp"
+#endif
+
 namespace llcomp_mi {
 
 namespace {
@@ -112,12 +120,17 @@ struct Bank {
     uint32_t w[2];
     uint8_t* lds;
 };
+// Row banks in LDS: [context][word 0 / 1][lane] dwords, so that the 64 lanes of a byte store (or of a word read) sit in 64
+// consecutive dwords -- conflict-free.  (As [context][lane] 8-byte entries every byte store of a new state was a 2-way
+// bank conflict: 28 of the ~150 LDS cycles of a sample.)  State byte k of a lane: word k / 4, 256 bytes further on.
+constexpr uint32_t kRowBankWords = 3 * 2 * 64;
+__device__ __forceinline__ constexpr uint32_t rowbank_byte(int slot) { return uint32_t(slot >> 2) * 256u + uint32_t(slot & 3); }
 template <int SLOT, bool INLDS>
 __device__ __forceinline__ void put_state(Bank& b, uint32_t ns) {  // ns: new state in byte 0
 #if LLMI_EXP == 7
     if constexpr (INLDS) return;
 #endif
-    if constexpr (INLDS) b.lds[SLOT] = uint8_t(ns);
+    if constexpr (INLDS) b.lds[rowbank_byte(SLOT)] = uint8_t(ns);
     else set_slot_state<SLOT>(b.w, ns & 0xFF);
 }
 // successor state / successor probability of entry e for the coded bit
@@ -407,7 +420,22 @@ __device__ __forceinline__ void enc_finish_and_count(RangeEnc& e, int32_t& n_byt
 // wavefront (1..64).
 // LDSTAB: one slice per wavefront (a lone whole-image stream, a handful of big tiles) -- its 63 KB state table fits in
 // LDS, which takes the HBM round trip of every context fetch off the serial chain.
-extern __shared__ __attribute__((aligned(8))) unsigned char dyn_lds[];
+extern __shared__ __attribute__((aligned(32))) unsigned char dyn_lds[];
+// LDS of the 1-row-slice encoder with the hand-written sample: everything sits in the dynamic block, which starts at LDS
+// address 0 when a kernel has no static LDS -- the block addresses the model table with offsets relative to 0 (the kernel
+// checks that and refuses to run otherwise).
+constexpr uint32_t kRowsEncTabOff = 0, kRowsEncStageOff = 1024, kRowsEncBankOff = 1024 + 16 + 32 * 64;
+constexpr uint32_t kRowsEncLdsBytes = kRowsEncBankOff + 3 * 64 * 8;
+// rare: a carry that the block could not finish inside the staging area goes on into the bytes already stored to HBM
+__device__ __forceinline__ void enc_carry_back_flushed(RangeEnc& e) {
+    for (int32_t k = e.flushed - 1; k >= 0; --k) {
+        if (k >= e.cap) break;  // beyond the scratch capacity: the slice is reported as overflowed anyway
+        uint8_t* g = unit_byte(e, uint32_t(k));
+        const uint32_t v = *g;
+        *g = uint8_t(v + 1);
+        if (v != 0xFF) break;
+    }
+}
 template <bool LDSTAB>
 __device__ __forceinline__ void clear_lds_states() {
     if constexpr (LDSTAB) {
@@ -420,9 +448,27 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
                                                       const SYM* __restrict__ sym, uint64_t* __restrict__ states,
                                                       uint8_t* __restrict__ scratch, uint32_t* __restrict__ slice_len,
                                                       uint64_t* __restrict__ group_sum, uint32_t* status, const uint64_t gpat) {
-    __shared__ entry_t tab[128];
-    __shared__ __attribute__((aligned(32))) uint8_t stage[kStagePad + kStageBytes * 64];
-    __shared__ unsigned long long rowbank[ROWS ? 3 * 64 : 1];
+    constexpr bool ASM = ROWS && LLMI_ASM_ENC != 0;
+    entry_t* tab;
+    uint8_t* stage;
+    uint32_t* rowbank;
+    if constexpr (ASM) {
+        static_assert(kStagePad == 16 && kStageBytes == 32, "kRowsEncBankOff");
+        tab = reinterpret_cast<entry_t*>(dyn_lds + kRowsEncTabOff);
+        stage = dyn_lds + kRowsEncStageOff;
+        rowbank = reinterpret_cast<uint32_t*>(dyn_lds + kRowsEncBankOff);
+        if (uint32_t(uintptr_t((lds_u8_ptr)dyn_lds)) != 0) {  // (folds away: the address is a link-time constant)
+            if (threadIdx.x == 0) atomicOr(status, kStInternal);
+            return;
+        }
+    } else {
+        __shared__ entry_t s_tab[128];
+        __shared__ __attribute__((aligned(32))) uint8_t s_stage[kStagePad + kStageBytes * 64];
+        __shared__ uint32_t s_rowbank[ROWS ? kRowBankWords : 1];
+        tab = s_tab;
+        stage = s_stage;
+        rowbank = s_rowbank;
+    }
     clear_lds_states<LDSTAB>();
     load_table(tab);
     const uint32_t id = blockIdx.x * lpw + threadIdx.x;
@@ -448,9 +494,12 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     if constexpr (ROWS) {
         // contexts 0 / 605 / 1210 only: their state bytes sit in LDS, [context][lane] (a read + a write per sample
         // instead of selecting among / writing back to three register pairs: twelve v_cndmask)
-        rowbank[threadIdx.x] = rowbank[64 + threadIdx.x] = rowbank[128 + threadIdx.x] = 0;
+        for (uint32_t k = 0; k < 6; ++k) rowbank[k * 64 + threadIdx.x] = 0;
         uint32_t s0 = p0[0];
         uint32_t s1 = total > 1 ? p0[GW] : 0;
+#if LLMI_ASM_ENC
+        EncRowsExtra xs{0u, 0u, 0u};
+#endif
         for (uint32_t i = 0; i < total; ++i) {
             // Memory operations of one wave retire in order and s_waitcnt counts loads and stores together, so the
             // order inside an iteration is: consume what was requested a sample ago (long back, no stall) -> issue the
@@ -468,11 +517,19 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
                 cidx = ((s0 & 0xFFFF) * 109u) >> 16;  // 0 / 605 / 1210 -> 0 / 1 / 2
                 res = int(s0) >> 16;
             }
-            unsigned long long* bp = &rowbank[cidx * 64 + threadIdx.x];
-            const unsigned long long b64 = *bp;
-            Bank bank{{uint32_t(b64), uint32_t(b64 >> 32)}, reinterpret_cast<uint8_t*>(bp)};  // new states: byte stores
+            uint32_t* bp = &rowbank[cidx * 128 + threadIdx.x];
+#if LLMI_ASM_ENC
+            enc_rows_sample_asm(e.low, e.range, e.wp, xs, uint32_t(uintptr_t((lds_u8_ptr) reinterpret_cast<uint8_t*>(bp))), res, e.base);
+            if (__builtin_expect(xs.any_pend != 0, 0)) {
+                xs.any_pend = 0;
+                if (xs.pend) enc_carry_back_flushed(e);
+                xs.pend = 0;
+            }
+#else
+            Bank bank{{bp[0], bp[64]}, reinterpret_cast<uint8_t*>(bp)};  // new states: byte stores
             if (hot) enc_residual<true, true>(e, bank, tab, res); else enc_residual<false, true>(e, bank, tab, res);
             hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(res != 0)) >= __popcll(__ballot(true)));
+#endif
             s0 = s1;
             s1 = s2;
         }
@@ -748,7 +805,10 @@ __device__ __forceinline__ bool dec_sample(RangeDec& d, Bank& bank, const entry_
         d.low = s_low; d.range = s_range; d.win = s_win;
         bank.w[0] = s_b0; bank.w[1] = s_b1;
         if constexpr (INLDS)  // the fast path has already stored new states: put the old ones back
-            *reinterpret_cast<unsigned long long*>(bank.lds) = (unsigned long long)s_b0 | ((unsigned long long)s_b1 << 32);
+        {
+            reinterpret_cast<uint32_t*>(bank.lds)[0] = s_b0;
+            reinterpret_cast<uint32_t*>(bank.lds)[64] = s_b1;
+        }
         ok = dec_residual<false, true, INLDS>(d, bank, tab, v);
     }
     return ok;
@@ -761,7 +821,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                                                       uint64_t* __restrict__ states, int16_t* __restrict__ rec,
                                                       uint32_t* status, const uint64_t gpat) {
     __shared__ entry_t tab[128];
-    __shared__ unsigned long long rowbank[ROWS ? 3 * 64 : 1];
+    __shared__ uint32_t rowbank[ROWS ? kRowBankWords : 1];
     clear_lds_states<LDSTAB>();
     load_table(tab);
     const uint32_t lpw = lpw_and_flags & 0xFF;
@@ -791,7 +851,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
         // one-row slice (llcomp.hpp:494-509 with h == 0): l = left (128 at the start), everything above = l, so
         // hash = 605*quant5(L - l), prediction = l.  The three banks sit in LDS ([context][lane], see the encoder); no
         // state memory in HBM.
-        rowbank[threadIdx.x] = rowbank[64 + threadIdx.x] = rowbank[128 + threadIdx.x] = 0;
+        for (uint32_t k = 0; k < 6; ++k) rowbank[k * 64 + threadIdx.x] = 0;
         int l[NCH], L[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) l[k] = L[k] = 128;
@@ -810,9 +870,8 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 const uint32_t aq = uint32_t(dq < 0 ? -dq : dq);
                 const bool neg = dq < 0;               // hash = 605*quant5(L-l) < 0
                 const uint32_t cidx = min(aq, 1u) + (aq > 3 ? 1u : 0u);  // |quant5(L - l)|
-                unsigned long long* bp = &rowbank[cidx * 64 + threadIdx.x];
-                const unsigned long long b64 = *bp;
-                Bank bank{{uint32_t(b64), uint32_t(b64 >> 32)}, reinterpret_cast<uint8_t*>(bp)};
+                uint32_t* bp = &rowbank[cidx * 128 + threadIdx.x];
+                Bank bank{{bp[0], bp[64]}, reinterpret_cast<uint8_t*>(bp)};
                 uint32_t v;
                 const bool ok = dec_sample<true>(d, bank, tab, hot, replay_always, v);
                 if (!ok) {
@@ -997,7 +1056,7 @@ hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* 
     const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
     uint64_t* const d_group_sum = encoder_writes_group_sums(g) ? d_group_off : nullptr;
     if (model_is_fused(g)) {  // planar 1-row slices: 16-bit symbols, always the ROWS kernel
-        k_encode_slices<1, true, uint16_t><<<dim3(blocks), dim3(64), 0, stream>>>(
+        k_encode_slices<1, true, uint16_t><<<dim3(blocks), dim3(64), LLMI_ASM_ENC ? kRowsEncLdsBytes : 0, stream>>>(
             g, lpw, static_cast<const uint16_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status, gpat);
         return hipGetLastError();
     }
@@ -1008,7 +1067,7 @@ hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* 
             const hipError_t e = allow_big_lds(kernel);
             if (e != hipSuccess) return e;
         }
-        kernel<<<dim3(blocks), dim3(64), T ? kLdsTableBytes : 0, stream>>>(
+        kernel<<<dim3(blocks), dim3(64), T ? kLdsTableBytes : (R && LLMI_ASM_ENC ? kRowsEncLdsBytes : 0), stream>>>(
             g, lpw, static_cast<const uint32_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status, gpat);
     });
     return hipGetLastError();
