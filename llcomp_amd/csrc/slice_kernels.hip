@@ -857,20 +857,32 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
         for (int k = 0; k < NCH; ++k) l[k] = L[k] = 128;
         // The previous sample is stored only AFTER the window top-up of the next one, so the top-up never waits for a
         // store that was issued a moment ago (see the encoder).  The very first store is a dummy to sample 0's own slot.
+        // Per-sample bookkeeping in 2-cycle operations only (add / sub / and / xor / right shifts; tools/ubench/valu_rate3:
+        // compares, selects on a scalar mask, min / max, LEFT shifts and everything with a scalar operand cost 4):
+        //   * the context index |quant5(L - l)| = [|d| >= 1] + [|d| >= 4] goes straight into the byte offset of its row
+        //     bank (512 bytes per context): bit 31 of |d| + (2^31 - t) says |d| >= t, shifted down to bit 9;
+        //   * "no L at x <= 1" (llcomp.hpp:496) without a select: L starts equal to l, and behind sample 0 L takes the
+        //     decoded value instead of the old l, so L - l is 0 at x = 0 and x = 1 by itself;
+        //   * the sign fold is (v ^ s) - s with s = (L - l) >> 31; LargeModel = false masks the difference to 0;
+        //   * the store goes through a running 32-bit byte offset from the wave-uniform base (one instruction).
         int held_val = 0;
-        uint32_t held_off = lane_in_group;
+        uint32_t held_ofs = lane_in_group * 2, next_ofs = held_ofs, step_ofs = 2u << g.lane_shift;
+        uint32_t large = small_model ? 0u : ~0u, first = ~0u;
+        asm volatile("" : "+v"(large), "+v"(first), "+v"(step_ofs));  // (vector values: keeps hipcc from going back to selects)
+        uint8_t* const bank0 = reinterpret_cast<uint8_t*>(rowbank) + threadIdx.x * 4;
         for (uint32_t x = 0; x < r.sw; ++x) {
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 if (window_low(d)) dec_append(d);
-                gbase[held_off] = int16_t(held_val);
-                const int lv = l[k];                 // x == 0: 128
-                const int Lv = x > 1 ? L[k] : lv;    // llcomp.hpp:496
-                const int dq = small_model ? 0 : Lv - lv;  // LargeModel = false: no quant5 term, one context
-                const uint32_t aq = uint32_t(dq < 0 ? -dq : dq);
-                const bool neg = dq < 0;               // hash = 605*quant5(L-l) < 0
-                const uint32_t cidx = min(aq, 1u) + (aq > 3 ? 1u : 0u);  // |quant5(L - l)|
-                uint32_t* bp = &rowbank[cidx * 128 + threadIdx.x];
+                asm volatile("global_store_short %0, %1, %2" : : "v"(held_ofs), "v"(held_val), "s"(gbase) : "memory");
+                const int lv = l[k];  // x == 0: 128
+                const int dq = (L[k] - lv) & int(large);
+                int sg = dq >> 31;  // hash = 605*quant5(L-l) < 0: the residual was folded
+                asm volatile("" : "+v"(sg));  // (or hipcc forms |d| with v_max and the offset with v_and_or: 4-cycle operations)
+                const uint32_t aq = uint32_t((dq ^ sg) - sg);
+                uint32_t o1 = ((aq + 0x7FFFFFFFu) >> 22) & 0x200u, o2 = ((aq + 0x7FFFFFFCu) >> 22) & 0x200u;
+                asm volatile("" : "+v"(o1), "+v"(o2));
+                uint32_t* bp = reinterpret_cast<uint32_t*>(bank0 + (o1 + o2));  // |quant5(L - l)| * 512
                 Bank bank{{bp[0], bp[64]}, reinterpret_cast<uint8_t*>(bp)};
                 uint32_t v;
                 const bool ok = dec_sample<true>(d, bank, tab, hot, replay_always, v);
@@ -879,15 +891,17 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                     return;
                 }
                 hot = 2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true));  // (ballots are wave-uniform: scalar arithmetic)
-                if (neg) v = 0u - v;
+                v = (v ^ uint32_t(sg)) - uint32_t(sg);
                 const int val = int(int16_t(uint32_t(lv) + v));
                 held_val = val;
-                held_off = ((x * NCH + uint32_t(k)) << g.lane_shift) + lane_in_group;
-                L[k] = lv;
+                held_ofs = next_ofs;
+                next_ofs += step_ofs;
+                L[k] = lv ^ ((lv ^ val) & int(first));
                 l[k] = val;
             }
+            first = 0;
         }
-        gbase[held_off] = int16_t(held_val);
+        asm volatile("global_store_short %0, %1, %2" : : "v"(held_ofs), "v"(held_val), "s"(gbase) : "memory");
     } else {
         // Neighbours of the row above rotate through registers (tl <- t <- tr); the two values the NEXT pixel needs
         // from memory (top-right, top-top) are loaded while the current one decodes.

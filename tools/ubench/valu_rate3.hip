@@ -3,6 +3,7 @@
 // valu_rate2.hip: 128 independent instructions per loop iteration over 8 registers, whole GPU filled.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #define BODY(TXT, ...) { _Pragma("unroll") for (int u = 0; u < 16; ++u) { REP8(TXT) } }
@@ -13,7 +14,8 @@ __global__ void k(unsigned* out, int iters, unsigned seed) {
     unsigned long long q[4];
     for (int i = 0; i < 8; ++i) r[i] = threadIdx.x * 7u + i + seed;
     for (int i = 0; i < 4; ++i) q[i] = (unsigned long long)(threadIdx.x * 11u + i + seed) << 20;
-    unsigned m = seed | 1u, c8 = 8;
+    unsigned m = seed | 1u, c8 = 8, zero = seed >> 31;
+    unsigned long long sq = __builtin_amdgcn_readfirstlane(seed) * 0x100000001ull;
     unsigned sm = __builtin_amdgcn_readfirstlane(seed | 0x100u);
     __shared__ unsigned char lds[64 * 64];
     unsigned la = threadIdx.x * 36u;
@@ -59,6 +61,16 @@ __global__ void k(unsigned* out, int iters, unsigned seed) {
 #define A37(i) asm volatile("v_subrev_u32 %0, %0, %1" : "+v"(r[i]) : "v"(m));
 #define A38(i) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(r[i]));
 #define A39(i) asm volatile("v_and_b32 %0, %1, %0" : "+v"(r[i]) : "s"(sm));
+#define A40(i) asm volatile("v_cndmask_b32_e64 %0, 0, 1, vcc" : "=v"(r[i]));
+#define A41(i) asm volatile("v_cndmask_b32 %0, %1, %0, vcc" : "+v"(r[i]) : "v"(zero));
+#define A42(i) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(r[i]) : "v"(c8));
+#define A43(i) asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(q[i & 3]) : "v"(c8));
+#define A44(i) asm volatile("v_min_u32 %0, %0, %1" : "+v"(r[i]) : "v"(m));
+#define A45(i) asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(q[i & 3]) : "s"(sq));
+#define A46(i) asm volatile("v_cmp_gt_u32_e64 s[20:21], %1, %0" : : "v"(r[i]), "s"(sm) : "s20", "s21");
+#define A47(i) asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(r[i]));
+#define A48(i) asm volatile("s_mov_b64 exec, exec");
+#define A49(i) asm volatile("s_or_b64 s[20:21], s[20:21], vcc" ::: "s20", "s21");
 #define CASE(N) else if (KIND == N) BODY(A##N)
         if (KIND == 31 || KIND == 33 || KIND == 34) {
             asm volatile("s_mov_b64 s[22:23], exec\n s_mov_b64 exec, 0" ::: "s22", "s23");
@@ -67,7 +79,8 @@ __global__ void k(unsigned* out, int iters, unsigned seed) {
         }
         CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
         CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26) CASE(27) CASE(28)
-        CASE(29) CASE(30) CASE(32) CASE(35) CASE(36) CASE(37) CASE(38) CASE(39)
+        CASE(29) CASE(30) CASE(32) CASE(35) CASE(36) CASE(37) CASE(38) CASE(39) CASE(40) CASE(41) CASE(42) CASE(43) CASE(44) CASE(45) CASE(46)
+        CASE(47) CASE(48) CASE(49)
     }
     unsigned s = lds[threadIdx.x];
     for (int i = 0; i < 8; ++i) s ^= r[i];
@@ -94,17 +107,24 @@ double run(int waves_per_simd, int iters) {
     return ms * 1e-3 * 2.4e9 / (double(iters) * 16 * 8 * waves_per_simd);
 }
 
-int main() {
-    static const char* names[] = {"v_add_u32 vgpr", "v_add_u32 sgpr", "v_add_u32 literal", "v_add_co_u32", "v_addc_co_u32", "v_lshlrev imm", "v_lshlrev sgpr",
-        "v_lshrrev_b64", "v_alignbyte", "v_perm", "v_mul_u32_u24", "v_mul_u24_sdwa", "lshl_sdwa vgpr-amount", "lshl_sdwa inline-amount", "v_cmp sgpr", "v_cmpx",
-        "v_xor", "v_or", "v_max_i32", "v_ffbh", "v_lshl_or", "v_mov_sdwa", "v_sub_sdwa", "v_and literal", "v_cndmask 0,v,vcc", "v_mad_u32_u24", "v_lshl_add",
-        "v_lshrrev 24", "s_nop 0", "s_mov_b64 s,exec", "saveexec+restore (pair)", "v_add exec=0", "ds_write_b8", "ds_write_b8 exec=0", "v_mul_u24 exec=0",
-        "v_cmp+cbranch_vccz+nop (3)", "v_sub_co_u32", "v_subrev_u32", "v_bfe_u32 imm", "v_and sgpr"};
-    for (int w : {8}) {
-        printf("waves/SIMD=%d\n", w);
-#define R(ID) printf("  %-28s %.2f\n", names[ID], run<ID>(w, 300)); fflush(stdout);
-        R(0) R(1) R(2) R(3) R(4) R(5) R(6) R(7) R(8) R(9) R(10) R(11) R(12) R(13) R(14) R(15) R(16) R(17) R(18) R(19) R(20) R(21) R(22) R(23) R(24)
-        R(25) R(26) R(27) R(28) R(29) R(30) R(31) R(32) R(33) R(34) R(35) R(36) R(37) R(38) R(39)
+#define NAMES {"v_add_u32 vgpr", "v_add_u32 sgpr", "v_add_u32 literal", "v_add_co_u32", "v_addc_co_u32", "v_lshlrev imm", "v_lshlrev sgpr", \
+        "v_lshrrev_b64", "v_alignbyte", "v_perm", "v_mul_u32_u24", "v_mul_u24_sdwa", "lshl_sdwa vgpr-amount", "lshl_sdwa inline-amount", "v_cmp sgpr", "v_cmpx", \
+        "v_xor", "v_or", "v_max_i32", "v_ffbh", "v_lshl_or", "v_mov_sdwa", "v_sub_sdwa", "v_and literal", "v_cndmask 0,v,vcc", "v_mad_u32_u24", "v_lshl_add", \
+        "v_lshrrev 24", "s_nop 0", "s_mov_b64 s,exec", "saveexec+restore (pair)", "v_add exec=0", "ds_write_b8", "ds_write_b8 exec=0", "v_mul_u24 exec=0", \
+        "v_cmp+cbranch_vccz+nop (3)", "v_sub_co_u32", "v_subrev_u32", "v_bfe_u32 imm", "v_and sgpr", \
+        "v_cndmask_e64 0,1,vcc", "v_cndmask vzero,v,vcc", "v_lshrrev vgpr-amount", "v_lshlrev_b64 vgpr-amount", "v_min_u32", "v_lshl_add_u64 sgpr", "v_cmp_e64 sgpr", \
+        "v_ashrrev 31", "s_mov_b64 exec,exec", "s_or_b64 s,s,vcc"}
+template <int K0>
+void run_one(int kind, int w, const char* const* names) {
+    if constexpr (K0 < 50) {
+        if (kind == K0) { printf("  %-28s %.2f\n", names[K0], run<K0>(w, 300)); fflush(stdout); return; }
+        run_one<K0 + 1>(kind, w, names);
     }
+}
+int main(int argc, char** argv) {
+    static const char* names[] = NAMES;
+    const int w = 8;
+    printf("waves/SIMD=%d\n", w);
+    for (int a = 1; a < argc; ++a) run_one<0>(atoi(argv[a]), w, names);
     return 0;
 }
