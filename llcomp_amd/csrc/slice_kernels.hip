@@ -105,11 +105,11 @@ __device__ __forceinline__ void load_table(entry_t* tab) {
 __device__ __forceinline__ uint32_t byte_of(uint32_t w, int k) { return (w >> (8 * k)) & 0xFF; }
 __device__ __forceinline__ uint32_t consume_here(uint32_t v);
 template <int SLOT>
-__device__ __forceinline__ uint32_t slot_state(const uint32_t (&bank)[2]) {
+__device__ __forceinline__ uint32_t slot_state(const uint32_t* bank) {
     return byte_of(bank[SLOT >> 2], SLOT & 3);
 }
 template <int SLOT>
-__device__ __forceinline__ void set_slot_state(uint32_t (&bank)[2], uint32_t ns) {
+__device__ __forceinline__ void set_slot_state(uint32_t* bank, uint32_t ns) {
     constexpr int W = SLOT >> 2, SH = (SLOT & 3) * 8;
     bank[W] = (bank[W] & ~(0xFFu << SH)) | (ns << SH);
 }
@@ -117,7 +117,7 @@ __device__ __forceinline__ void set_slot_state(uint32_t (&bank)[2], uint32_t ns)
 // a new state is then ONE byte store and the words below are a read-only copy; otherwise the words are updated and
 // written back by the caller.
 struct Bank {
-    uint32_t w[2];
+    uint32_t w[4];  // (w[2], w[3]: only the decoder's wide row banks, below)
     uint8_t* lds;
 };
 // Row banks in LDS: [context][word 0 / 1][lane] dwords, so that the 64 lanes of a byte store (or of a word read) sit in 64
@@ -125,6 +125,18 @@ struct Bank {
 // bank conflict: 28 of the ~150 LDS cycles of a sample.)  State byte k of a lane: word k / 4, 256 bytes further on.
 constexpr uint32_t kRowBankWords = 3 * 2 * 64;
 __device__ __forceinline__ constexpr uint32_t rowbank_byte(int slot) { return uint32_t(slot >> 2) * 256u + uint32_t(slot & 3); }
+// The DECODER's row banks are wide: 16 bits per slot, holding the TABLE OFFSET of the slot's state (8 * state, what the upper
+// half of a half-entry carries anyway) instead of the state byte -- [context][word 0..3][lane] dwords, slot k in half k & 1 of
+// word k / 2.  The address of a slot's entry is then a mask or a right shift by a constant (2-cycle operations) where the
+// byte form needs an SDWA shift (4 cycles), eight times per sample; a new state is one 16-bit store straight out of the
+// half-entry's upper half.  (4 KB of LDS per wavefront with the table: fits eight wavefronts per SIMD.  The encoder's
+// staging area leaves no room for the same there.)
+constexpr uint32_t kWideBankWords = 3 * 4 * 64;
+__device__ __forceinline__ constexpr uint32_t widebank_byte(int slot) { return uint32_t(slot >> 1) * 256u + uint32_t(slot & 1) * 2u; }
+template <int SLOT>
+__device__ __forceinline__ uint32_t wide_offset(const uint32_t (&w)[4]) {
+    return (SLOT & 1) ? (w[SLOT >> 1] >> 16) : (w[SLOT >> 1] & 0xFFFFu);
+}
 template <int SLOT, bool INLDS>
 __device__ __forceinline__ void put_state(Bank& b, uint32_t ns) {  // ns: new state in byte 0
 #if LLMI_EXP == 7
@@ -168,10 +180,10 @@ struct Entries {
         else return e7;
     }
 };
-__device__ __forceinline__ void fetch_slot0(Entries& E, const uint32_t (&bank)[2], const entry_t* tab) {
+__device__ __forceinline__ void fetch_slot0(Entries& E, const uint32_t* bank, const entry_t* tab) {
     E.e0 = tab[slot_state<0>(bank)];
 }
-__device__ __forceinline__ void fetch_rest(Entries& E, const uint32_t (&bank)[2], const entry_t* tab) {
+__device__ __forceinline__ void fetch_rest(Entries& E, const uint32_t* bank, const entry_t* tab) {
     E.e1 = tab[slot_state<1>(bank)];
     E.e2 = tab[slot_state<2>(bank)];
     E.e3 = tab[slot_state<3>(bank)];
@@ -594,6 +606,29 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
 }
 
 // ================================================ DECODER ========================================================
+// new state of a slot from the half-entry that belongs to the decoded bit (byte 0 = state, upper half = table offset)
+template <int SLOT, bool INLDS>
+__device__ __forceinline__ void dec_put_state(Bank& b, uint32_t half) {
+    if constexpr (INLDS) *reinterpret_cast<uint16_t*>(b.lds + widebank_byte(SLOT)) = uint16_t(half >> 16);
+    else set_slot_state<SLOT>(b.w, half & 0xFF);
+}
+template <int SLOT, bool INLDS>
+__device__ __forceinline__ entry_t dec_entry(const Bank& b, const entry_t* tab) {
+    if constexpr (INLDS) return *reinterpret_cast<const entry_t*>(reinterpret_cast<const char*>(tab) + wide_offset<SLOT>(b.w));
+    else return tab[slot_state<SLOT>(b.w)];
+}
+template <bool INLDS>
+__device__ __forceinline__ void dec_fetch_slot0(Entries& E, const Bank& b, const entry_t* tab) { E.e0 = dec_entry<0, INLDS>(b, tab); }
+template <bool INLDS>
+__device__ __forceinline__ void dec_fetch_rest(Entries& E, const Bank& b, const entry_t* tab) {
+    E.e1 = dec_entry<1, INLDS>(b, tab);
+    E.e2 = dec_entry<2, INLDS>(b, tab);
+    E.e3 = dec_entry<3, INLDS>(b, tab);
+    E.e4 = dec_entry<4, INLDS>(b, tab);
+    E.e5 = dec_entry<5, INLDS>(b, tab);
+    E.e6 = dec_entry<6, INLDS>(b, tab);
+    E.e7 = dec_entry<7, INLDS>(b, tab);
+}
 // Range decoder of one lane (llcomp.hpp:91-127).  The stream is consumed through a 64-bit register window (next byte
 // = window & 0xFF) that is topped up with aligned dword loads, one dword prefetched ahead; bytes past the end of the
 // slice read as 0 (llcomp.hpp:475-479).  The fill level is not counted: a SENTINEL 1 bit sits right above the valid
@@ -716,20 +751,20 @@ template <int SLOT, bool CHECKED, bool INLDS>
 __device__ __forceinline__ bool dec_once(RangeDec& d, Bank& bank, const Entries& E) {
     const entry_t en = E.get<SLOT>();
     const bool bit = dec_core<CHECKED>(d, prob_of(en));
-    put_state<SLOT, INLDS>(bank, successor(en, bit));
+    dec_put_state<SLOT, INLDS>(bank, successor(en, bit));
     return bit;
 }
 // getSymbol<true,4,6,7> (llcomp.hpp:219-247).  Returns false on "Invalid exponent".  Arithmetic modulo 2^32.
 template <bool ALL, bool CHECKED, bool INLDS>
 __device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entry_t* tab, uint32_t& out) {
     Entries E;
-    fetch_slot0(E, bank.w, tab);
-    if (ALL) fetch_rest(E, bank.w, tab);
+    dec_fetch_slot0<INLDS>(E, bank, tab);
+    if (ALL) dec_fetch_rest<INLDS>(E, bank, tab);
     if (dec_once<0, CHECKED, INLDS>(d, bank, E)) {
         out = 0;
         return true;
     }
-    if (!ALL) fetch_rest(E, bank.w, tab);
+    if (!ALL) dec_fetch_rest<INLDS>(E, bank, tab);
     int ex = 0;
     bool ok = true;
     if (dec_once<1, CHECKED, INLDS>(d, bank, E)) {
@@ -763,7 +798,7 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entr
                 // longer than 31 is "Invalid exponent" (llcomp.hpp:230-235) and is confirmed by the checked replay
                 if (ex > 31) ok = false;
                 const uint32_t nx = uint32_t(cur);
-                put_state<4, INLDS>(bank, nx);
+                dec_put_state<4, INLDS>(bank, nx);
             }
         }
     }
@@ -785,7 +820,7 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entr
                 nx = dec_step_acc<CHECKED>(d, prob_of(cur), cur, w);
                 cur = entry_at(tab, nx);
             } while (w < limit);
-            put_state<6, INLDS>(bank, nx);
+            dec_put_state<6, INLDS>(bank, nx);
         }
     }
     uint32_t v = w ^ ones;
@@ -798,16 +833,18 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entr
 template <bool INLDS>
 __device__ __forceinline__ bool dec_sample(RangeDec& d, Bank& bank, const entry_t* tab, bool hot, bool replay_always,
                                            uint32_t& v) {
-    const uint32_t s_low = d.low, s_range = d.range, s_b0 = bank.w[0], s_b1 = bank.w[1];
+    const uint32_t s_low = d.low, s_range = d.range, s_b0 = bank.w[0], s_b1 = bank.w[1], s_b2 = bank.w[2], s_b3 = bank.w[3];
     const unsigned long long s_win = d.win;
     bool ok = hot ? dec_residual<true, false, INLDS>(d, bank, tab, v) : dec_residual<false, false, INLDS>(d, bank, tab, v);
     if (__builtin_expect(!ok || d.win == 0 || replay_always, 0)) {
         d.low = s_low; d.range = s_range; d.win = s_win;
         bank.w[0] = s_b0; bank.w[1] = s_b1;
-        if constexpr (INLDS)  // the fast path has already stored new states: put the old ones back
-        {
+        if constexpr (INLDS) {  // the fast path has already stored new states: put the old ones back
+            bank.w[2] = s_b2; bank.w[3] = s_b3;
             reinterpret_cast<uint32_t*>(bank.lds)[0] = s_b0;
             reinterpret_cast<uint32_t*>(bank.lds)[64] = s_b1;
+            reinterpret_cast<uint32_t*>(bank.lds)[128] = s_b2;
+            reinterpret_cast<uint32_t*>(bank.lds)[192] = s_b3;
         }
         ok = dec_residual<false, true, INLDS>(d, bank, tab, v);
     }
@@ -821,7 +858,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                                                       uint64_t* __restrict__ states, int16_t* __restrict__ rec,
                                                       uint32_t* status, const uint64_t gpat) {
     __shared__ entry_t tab[128];
-    __shared__ uint32_t rowbank[ROWS ? kRowBankWords : 1];
+    __shared__ uint32_t rowbank[ROWS ? kWideBankWords : 1];
     clear_lds_states<LDSTAB>();
     load_table(tab);
     const uint32_t lpw = lpw_and_flags & 0xFF;
@@ -851,7 +888,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
         // one-row slice (llcomp.hpp:494-509 with h == 0): l = left (128 at the start), everything above = l, so
         // hash = 605*quant5(L - l), prediction = l.  The three banks sit in LDS ([context][lane], see the encoder); no
         // state memory in HBM.
-        for (uint32_t k = 0; k < 6; ++k) rowbank[k * 64 + threadIdx.x] = 0;
+        for (uint32_t k = 0; k < 12; ++k) rowbank[k * 64 + threadIdx.x] = 0;
         int l[NCH], L[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) l[k] = L[k] = 128;
@@ -860,7 +897,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
         // Per-sample bookkeeping in 2-cycle operations only (add / sub / and / xor / right shifts; tools/ubench/valu_rate3:
         // compares, selects on a scalar mask, min / max, LEFT shifts and everything with a scalar operand cost 4):
         //   * the context index |quant5(L - l)| = [|d| >= 1] + [|d| >= 4] goes straight into the byte offset of its row
-        //     bank (512 bytes per context): bit 31 of |d| + (2^31 - t) says |d| >= t, shifted down to bit 9;
+        //     bank (1024 bytes per context): bit 31 of |d| + (2^31 - t) says |d| >= t, shifted down to bit 10;
         //   * "no L at x <= 1" (llcomp.hpp:496) without a select: L starts equal to l, and behind sample 0 L takes the
         //     decoded value instead of the old l, so L - l is 0 at x = 0 and x = 1 by itself;
         //   * the sign fold is (v ^ s) - s with s = (L - l) >> 31; LargeModel = false masks the difference to 0;
@@ -880,10 +917,10 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 int sg = dq >> 31;  // hash = 605*quant5(L-l) < 0: the residual was folded
                 asm volatile("" : "+v"(sg));  // (or hipcc forms |d| with v_max and the offset with v_and_or: 4-cycle operations)
                 const uint32_t aq = uint32_t((dq ^ sg) - sg);
-                uint32_t o1 = ((aq + 0x7FFFFFFFu) >> 22) & 0x200u, o2 = ((aq + 0x7FFFFFFCu) >> 22) & 0x200u;
+                uint32_t o1 = ((aq + 0x7FFFFFFFu) >> 21) & 0x400u, o2 = ((aq + 0x7FFFFFFCu) >> 21) & 0x400u;
                 asm volatile("" : "+v"(o1), "+v"(o2));
-                uint32_t* bp = reinterpret_cast<uint32_t*>(bank0 + (o1 + o2));  // |quant5(L - l)| * 512
-                Bank bank{{bp[0], bp[64]}, reinterpret_cast<uint8_t*>(bp)};
+                uint32_t* bp = reinterpret_cast<uint32_t*>(bank0 + (o1 + o2));  // |quant5(L - l)| * 1024
+                Bank bank{{bp[0], bp[64], bp[128], bp[192]}, reinterpret_cast<uint8_t*>(bp)};
                 uint32_t v;
                 const bool ok = dec_sample<true>(d, bank, tab, hot, replay_always, v);
                 if (!ok) {
