@@ -221,6 +221,9 @@ struct RangeEnc {
     uint8_t* area;    // the same as a pointer (into the block's __shared__ array: the compiler emits LDS accesses)
     int32_t flushed;  // bytes already stored to HBM (multiple of 16)
     uint8_t* out;     // this lane's first 16-byte unit in the stream lane order array
+    uint8_t* gout;    // WAVE-UNIFORM: first unit of the lane group (all lanes of a wavefront belong to one group) ...
+    uint32_t oofs;    // ... and the byte offset from there of the unit the next flush stores: one scalar-base store and one
+    uint32_t ostep;   //     2-cycle add per flush instead of 64-bit address arithmetic (ostep = 16 << lane_shift, a vector value)
     int32_t cap;
     uint32_t shift;   // lane_shift
 };
@@ -245,7 +248,8 @@ __device__ __forceinline__ void enc_flush16(RangeEnc& e) {
     v.x = a[0]; v.y = a[1]; v.z = a[2]; v.w = a[3];
     rest.x = a[4]; rest.y = a[5]; rest.z = a[6]; rest.w = a[7];
     // `flushed` is a multiple of 16: its unit starts (flushed << lane_shift) bytes after the lane's first unit
-    if (e.flushed + 16 <= e.cap) *reinterpret_cast<uint4*>(e.out + (size_t(uint32_t(e.flushed)) << e.shift)) = v;
+    if (e.flushed + 16 <= e.cap) *reinterpret_cast<uint4*>(e.gout + e.oofs) = v;
+    e.oofs += e.ostep;
     a[0] = rest.x; a[1] = rest.y; a[2] = rest.z; a[3] = rest.w;
     e.flushed += 16;
     e.wp -= 16;
@@ -493,6 +497,10 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     e.base = uint32_t(uintptr_t((lds_u8_ptr)stage)) + kStagePad + threadIdx.x * kStageBytes;
     e.wp = e.base - 1;  // position -1: the dummy byte of the first renormalisation (see the staging area)
     e.out = scratch + ((((size_t(id >> g.lane_shift) * (g.slice_cap >> 4)) << g.lane_shift) + (id & ((1u << g.lane_shift) - 1))) << 4);
+    e.gout = scratch + (((size_t(__builtin_amdgcn_readfirstlane(id >> g.lane_shift)) * (g.slice_cap >> 4)) << g.lane_shift) << 4);
+    e.oofs = (id & ((1u << g.lane_shift) - 1)) << 4;
+    e.ostep = 16u << g.lane_shift;
+    asm volatile("" : "+v"(e.ostep));
     e.cap = int32_t(g.slice_cap);
     e.shift = g.lane_shift;
     const uint32_t n_row = r.sw * (NCH ? uint32_t(NCH) : g.nch);  // samples per slice row (NCH == 0: any channel count)
@@ -507,41 +515,72 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
         // contexts 0 / 605 / 1210 only: their state bytes sit in LDS, [context][lane] (a read + a write per sample
         // instead of selecting among / writing back to three register pairs: twelve v_cndmask)
         for (uint32_t k = 0; k < 6; ++k) rowbank[k * 64 + threadIdx.x] = 0;
-        uint32_t s0 = p0[0];
-        uint32_t s1 = total > 1 ? p0[GW] : 0;
+        // Symbols come through a wave-uniform base (all lanes of a wavefront sit in one lane group) and a running 32-bit byte
+        // offset: one global_load with a scalar base and one 2-cycle add per sample, no 64-bit address arithmetic.
+        const uint32_t grp = __builtin_amdgcn_readfirstlane(id >> g.lane_shift);
+        const char* const gsym = reinterpret_cast<const char*>(sym + ((size_t(grp) * g.slice_samples) << g.lane_shift));
+        uint32_t sofs = (id & ((1u << g.lane_shift) - 1)) * uint32_t(sizeof(SYM)), sstep = uint32_t(sizeof(SYM)) << g.lane_shift;
+        asm volatile("" : "+v"(sstep));  // (a vector value: a VALU add with a scalar operand costs twice as much)
+        auto load_sym = [&](uint32_t ofs) -> uint32_t { return *reinterpret_cast<const SYM*>(gsym + ofs); };
+        uint32_t s0 = load_sym(sofs);
+        sofs += sstep;
+        uint32_t s1 = total > 1 ? load_sym(sofs) : 0;
+        sofs += sstep;
+        uint32_t bank_base = uint32_t(uintptr_t((lds_u8_ptr) reinterpret_cast<uint8_t*>(rowbank))) + threadIdx.x * 4;
+        asm volatile("" : "+v"(bank_base));
 #if LLMI_ASM_ENC
         EncRowsExtra xs{0u, 0u, 0u};
 #endif
-        for (uint32_t i = 0; i < total; ++i) {
-            // Memory operations of one wave retire in order and s_waitcnt counts loads and stores together, so the
-            // order inside an iteration is: consume what was requested a sample ago (long back, no stall) -> issue the
-            // next prefetch -> issue the stores of the previous sample's output.  Nothing is ever waited for right
-            // after it was issued.
-            s0 = consume_here(s0);  // loaded two samples ago
-            const uint32_t s2 = i + 2 < total ? p0[size_t(i + 2) * GW] : 0;
-            if (e.wp >= e.base + 16) enc_flush16(e);  // 16 bytes staged (LDS addresses: no wrap-around, wp >= base - 1)
-            uint32_t cidx;
+        // one sample: context -> row bank, residual -> bins
+        auto code = [&](uint32_t sy) {
+            uint32_t bofs;  // |quant5(L - l)| * 512: byte offset of the context's row bank
             int res;
             if constexpr (sizeof(SYM) == 2) {  // fused stage A: |quant5| in bits 12..13, residual in bits 0..11
-                cidx = s0 >> 12;
-                res = int(s0 << 20) >> 20;
+                bofs = (sy >> 3) & 0x600u;
+                res = int(sy << 20) >> 20;
             } else {
-                cidx = ((s0 & 0xFFFF) * 109u) >> 16;  // 0 / 605 / 1210 -> 0 / 1 / 2
-                res = int(s0) >> 16;
+                bofs = (((sy & 0xFFFF) * 109u) >> 7) & 0x600u;  // 0 / 605 / 1210 -> 0 / 1 / 2
+                res = int(sy) >> 16;
             }
-            uint32_t* bp = &rowbank[cidx * 128 + threadIdx.x];
 #if LLMI_ASM_ENC
-            enc_rows_sample_asm(e.low, e.range, e.wp, xs, uint32_t(uintptr_t((lds_u8_ptr) reinterpret_cast<uint8_t*>(bp))), res, e.base);
+            enc_rows_sample_asm(e.low, e.range, e.wp, xs, bank_base + bofs, res, e.base);
             if (__builtin_expect(xs.any_pend != 0, 0)) {
                 xs.any_pend = 0;
                 if (xs.pend) enc_carry_back_flushed(e);
                 xs.pend = 0;
             }
 #else
+            uint32_t* bp = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(rowbank) + threadIdx.x * 4 + bofs);
             Bank bank{{bp[0], bp[64]}, reinterpret_cast<uint8_t*>(bp)};  // new states: byte stores
             if (hot) enc_residual<true, true>(e, bank, tab, res); else enc_residual<false, true>(e, bank, tab, res);
             hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(res != 0)) >= __popcll(__ballot(true)));
 #endif
+        };
+        // Memory operations of one wave retire in order and s_waitcnt counts loads and stores together, so the order
+        // inside an iteration is: consume what was requested a sample ago (long back, no stall) -> issue the next prefetch
+        // -> issue the stores of the previous sample's output.  Nothing is ever waited for right after it was issued.
+        // When all slices of the wavefront have the same length (all but those with the ragged last tile column), the bulk
+        // runs under a scalar loop counter with no per-lane tests; the last two samples, and ragged wavefronts, take
+        // the loop with the tests.
+        const uint32_t total0 = __builtin_amdgcn_readfirstlane(total);
+        const bool same = __builtin_amdgcn_ballot_w64(total != total0) == 0;
+        const uint32_t n_bulk = same && total0 > 2 ? total0 - 2 : 0;
+        uint32_t i = 0;
+        for (; i < n_bulk; ++i) {
+            s0 = consume_here(s0);  // loaded two samples ago
+            const uint32_t s2 = load_sym(sofs);
+            sofs += sstep;
+            if (e.wp >= e.base + 16) enc_flush16(e);  // 16 bytes staged (LDS addresses: no wrap-around, wp >= base - 1)
+            code(s0);
+            s0 = s1;
+            s1 = s2;
+        }
+        for (; i < total; ++i) {
+            s0 = consume_here(s0);
+            const uint32_t s2 = i + 2 < total ? load_sym(sofs) : 0;
+            sofs += sstep;
+            if (e.wp >= e.base + 16) enc_flush16(e);
+            code(s0);
             s0 = s1;
             s1 = s2;
         }
