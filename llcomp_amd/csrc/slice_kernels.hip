@@ -946,7 +946,11 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
         uint32_t large = small_model ? 0u : ~0u, first = ~0u;
         asm volatile("" : "+v"(large), "+v"(first), "+v"(step_ofs));  // (vector values: keeps hipcc from going back to selects)
         uint8_t* const bank0 = reinterpret_cast<uint8_t*>(rowbank) + threadIdx.x * 4;
-        for (uint32_t x = 0; x < r.sw; ++x) {
+        // "Invalid exponent" (llcomp.hpp:230-235) does not leave the loop: the lane notes it and decodes on (whatever it
+        // reads stays inside its own stream and slice, and the call reports the error) -- so the loop has no per-lane exit,
+        // and when all slices of the wavefront are equally wide it runs under a scalar counter with no per-lane tests at all.
+        bool bad = false;
+        auto pixel = [&]() {
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 if (window_low(d)) dec_append(d);
@@ -960,12 +964,8 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 asm volatile("" : "+v"(o1), "+v"(o2));
                 uint32_t* bp = reinterpret_cast<uint32_t*>(bank0 + (o1 + o2));  // |quant5(L - l)| * 1024
                 Bank bank{{bp[0], bp[64], bp[128], bp[192]}, reinterpret_cast<uint8_t*>(bp)};
-                uint32_t v;
-                const bool ok = dec_sample<true>(d, bank, tab, hot, replay_always, v);
-                if (!ok) {
-                    atomicOr(status, kStBadExponent);
-                    return;
-                }
+                uint32_t v = 0;
+                if (!dec_sample<true>(d, bank, tab, hot, replay_always, v)) bad = true;
                 hot = 2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true));  // (ballots are wave-uniform: scalar arithmetic)
                 v = (v ^ uint32_t(sg)) - uint32_t(sg);
                 const int val = int(int16_t(uint32_t(lv) + v));
@@ -976,7 +976,13 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 l[k] = val;
             }
             first = 0;
-        }
+        };
+        const uint32_t sw0 = __builtin_amdgcn_readfirstlane(r.sw);
+        const uint32_t n_bulk = __builtin_amdgcn_ballot_w64(r.sw != sw0) == 0 ? sw0 : 0;
+        uint32_t x = 0;
+        for (; x < n_bulk; ++x) pixel();
+        for (; x < r.sw; ++x) pixel();
+        if (bad) atomicOr(status, kStBadExponent);
         asm volatile("global_store_short %0, %1, %2" : : "v"(held_ofs), "v"(held_val), "s"(gbase) : "memory");
     } else {
         // Neighbours of the row above rotate through registers (tl <- t <- tr); the two values the NEXT pixel needs
