@@ -5,24 +5,28 @@ slots, every instruction with its class.
 
     python tools/bin_table.py [llcomp_amd/csrc/slice_kernels.s] > profiles/r03_bin_instruction_table.txt
 
-Classes and what one more instruction of a class per bin costs (measured, profiles/r03_sensitivity.jsonl, encoder alone on
-the GPU, 1010 cycles per wavefront-sample at 8 wavefronts per SIMD):
-  V2  simple vector op (VOP1/VOP2 e32: add, sub, mov, and, or, shift by a constant, cndmask on VCC)          ~1.0 cycle
-  V4  VOP3 / SDWA / VOPC / carry ops / 24-bit multiply (two dwords of encoding, or a second pass)              ~3.1 cycles
-  S   scalar ALU, exec-mask bookkeeping, s_waitcnt, s_nop                                                      ~1.4 cycles
-  B   branch (s_cbranch_*, s_branch)                                                                           (with S)
-  L   LDS access                                                                                               ~1.7 cycles (byte store)
-  M   global memory access"""
+Classes = issue cost per wavefront-instruction per SIMD at 8 wavefronts per SIMD (tools/ubench/valu_rate3.hip,
+profiles/r03_valu_rate3.txt):
+  V2  2.4-2.7 cycles: add / sub / and / or / xor / mov, RIGHT shifts (constant or register amount), cndmask on VCC -- with
+      VGPR, inline-constant or literal operands
+  V4  4.1-4.6 cycles: everything else -- compares, carry ops, 24-bit multiply, SDWA, VOP3, min / max, ffbh, LEFT shifts (even by a
+      constant), 64-bit shifts, and any V2 operation that takes a SCALAR register operand
+  S   scalar ALU, exec-mask bookkeeping, s_waitcnt, s_nop (one scalar unit per CU: an operation that reads or writes EXEC
+      costs ~4 cycles of it per SIMD, s_nop 0.75)
+  B   branch (s_cbranch_*, s_branch)
+  L   LDS access
+  M   global memory access
+The encoder's loops are hand-written (llcomp_amd/csrc/enc_rows_asm.hpp): they are found by their labels inside the block."""
 import re
 import sys
 
 path = sys.argv[1] if len(sys.argv) > 1 else "llcomp_amd/csrc/slice_kernels.s"
-V2 = {"v_add_u32_e32", "v_sub_u32_e32", "v_subrev_u32_e32", "v_mov_b32_e32", "v_and_b32_e32", "v_or_b32_e32", "v_xor_b32_e32", "v_lshlrev_b32_e32",
-      "v_lshrrev_b32_e32", "v_ashrrev_i32_e32", "v_cndmask_b32_e32", "v_max_i32_e32", "v_min_u32_e32", "v_max_u32_e32", "v_min_i32_e32", "v_not_b32_e32",
-      "v_add_u16_e32", "v_mov_b64_e32"}
+V2 = {"v_add_u32_e32", "v_sub_u32_e32", "v_subrev_u32_e32", "v_mov_b32_e32", "v_and_b32_e32", "v_or_b32_e32", "v_xor_b32_e32",
+      "v_lshrrev_b32_e32", "v_ashrrev_i32_e32", "v_cndmask_b32_e32", "v_not_b32_e32", "v_mov_b64_e32"}
 
 
-def klass(op):
+def klass(text):
+    op = text.split()[0]
     if op.startswith(("s_cbranch", "s_branch")):
         return "B"
     if op.startswith("s_"):
@@ -32,14 +36,15 @@ def klass(op):
     if op.startswith(("global_", "flat_", "buffer_")):
         return "M"
     if op.startswith("v_"):
-        return "V2" if op in V2 else "V4"
+        scalar_operand = re.search(r",\s*s(\d+|\[)", text) is not None
+        return "V2" if op in V2 and not scalar_operand else "V4"
     return "?"
 
 
 def kernel_lines(text, mangled_part):
     lines = text.split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + mangled_part + r"\w*:", l))
-    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))  # (a kernel may hold several s_endpgm)
     return lines[start:end + 1]
 
 
@@ -83,11 +88,39 @@ def show(title, bl, idxs, skip_deeper=True):
         if skip_deeper and "Depth=3" in com and "Child Loop" not in com:
             continue
         for t in ins:
-            op = t.split()[0]
-            k = klass(op)
+            k = klass(t)
             tot[k] = tot.get(k, 0) + 1
             print(f"   {k:2s}  {t}")
     print("   => " + "  ".join(f"{k}: {v}" for k, v in sorted(tot.items())))
+
+
+def asm_loops(lines):
+    """the loops of the hand-written encoder block: .Ltail_N / .Lman_N up to the branch back to the label"""
+    for name, kind in ((".Ltail_", "unary tail: one iteration = one bin on slot 4"), (".Lman_", "mantissa tail: one iteration = one bin on slot 6")):
+        for i, l in enumerate(lines):
+            m = re.match(r"^\s*(" + re.escape(name) + r"\d+):", l)
+            if not m:
+                continue
+            body = []
+            for t in lines[i + 1:]:
+                t = t.split(";")[0].strip()
+                if not t or t.endswith(":") and not t.startswith(".Lback") and not t.startswith(".Lskip") and not t.startswith(".Lpatch"):
+                    if t.endswith(":"):
+                        break
+                    continue
+                if t.endswith(":"):
+                    continue
+                body.append(t)
+                if t == "s_branch " + m.group(1):
+                    break
+            print(f"\n-- hand-written loop {m.group(1)}  ({kind}; the carry subroutine, called once in ~1000 renormalisations, is out of line)")
+            tot = {}
+            for t in body:
+                k = klass(t)
+                tot[k] = tot.get(k, 0) + 1
+                print(f"   {k:2s}  {t}")
+            print("   => " + "  ".join(f"{k}: {v}" for k, v in sorted(tot.items())))
+            break  # (the block is instantiated twice, bulk loop and tail loop: identical text)
 
 
 def main():
@@ -101,9 +134,11 @@ def main():
         n_all = {}
         for lab, com, ins in bl:
             for t in ins:
-                k = klass(t.split()[0])
+                k = klass(t)
                 n_all[k] = n_all.get(k, 0) + 1
         print("static instruction count of the whole kernel: " + "  ".join(f"{k}: {v}" for k, v in sorted(n_all.items())))
+        if "k_encode" in key:
+            asm_loops(kernel_lines(text, key))
         for lab, body in ls:
             # the rare carry-propagation loops of the encoder live at depth 3 below these; classify by content
             ops = " ".join(t for j in body for t in bl[j][2])
