@@ -1,0 +1,59 @@
+// dec_rows_asm.hpp -- the mantissa run of the decoder for 1-row slices (slot 6 of getSymbol<true,4,6,7>, llcomp.hpp:236-243,
+// over the range decoder, llcomp.hpp:98-121), hand-written for gfx950.  Same bins and arithmetic as the loop around
+// dec_step_acc in slice_kernels.hip (which the checked replay and the other kernel families keep using).
+//
+// Why by hand: hipcc's loop ends on a compare of the gathered bits against a per-lane limit -- a 4-cycle operation per bin on
+// top of the add-with-carry that gathers them.  Here the register that gathers the bits (at its bottom) carries a marker bit
+// above them, placed so that it leaves the register as the carry of that same add-with-carry when the lane's last bit has
+// come in; the carry is the loop's exit mask.  (The caller merges the run into what it had gathered before, once per sample.)
+//
+// LDS contract: the model table sits at LDS address 0 (the kernel puts its LDS into the dynamic block and checks that).
+// Register contract: the window lives in v[46:47] and the current entry in v[48:49] (operands tied to those registers: the
+// block needs their halves by name), v50..v54 and s56..s61 are owned by the block; with hipcc's own needs the kernel stays
+// at 56 VGPRs / 64 SGPRs (eight wavefronts per SIMD with room to spare).
+#pragma once
+#include <cstdint>
+
+namespace llcomp_mi {
+
+// in: exec = the lanes with a mantissa run (exponent > 1); low / range as in RangeDec; win = the 64-bit stream window (sentinel
+// scheme of RangeDec); cur = entry of slot 6's state; wl = the marker bit (bit 32 - bins of the run), the run's inverted bits
+// below it on return.  Returns the
+// half-entry that belongs to the last decoded bit (the caller stores the slot's new state from it).  Never looks at the fill
+// level of the window (the unchecked fast path of dec_sample).
+__device__ __forceinline__ uint32_t dec_rows_mantissa_asm(uint32_t& low, uint32_t& range, unsigned long long& win,
+                                                          unsigned long long cur, uint32_t& wl) {
+    uint32_t nx;
+    asm volatile(
+        "s_mov_b64 s[56:57], exec\n"
+        ".Lm_%=:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mul_u32_u24_sdwa v50, v48, %[range] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_e32 v50, 8, v50\n\t"                   // r1
+        "v_sub_u32_e32 v51, %[range], v50\n\t"                // r0
+        "v_sub_co_u32_e32 v52, vcc, %[low], v51\n\t"          // borrow: the bit is 0
+        "s_nop 1\n\t"                                         // (VALU wrote VCC, VALU reads VCC: two wait states on gfx950)
+        "v_cndmask_b32_e32 %[range], v50, v51, vcc\n\t"
+        "v_cndmask_b32_e32 %[low], v52, %[low], vcc\n\t"
+        "v_cndmask_b32_e32 %[nx], v49, v48, vcc\n\t"
+        "v_addc_co_u32_e32 %[wl], vcc, %[wl], %[wl], vcc\n\t"  // 2w + borrow (inverted bits); carry out: this was the last bit
+        "s_mov_b64 s[58:59], vcc\n\t"
+        "v_lshrrev_b32_e32 v53, 16, %[nx]\n\t"
+        "ds_read_b64 v[48:49], v53\n\t"                       // successor's entry
+        "v_cmp_gt_u32_e32 vcc, %[c100], %[range]\n\t"         // refill (llcomp.hpp:115-120)
+        "s_and_saveexec_b64 s[60:61], vcc\n\t"
+        "s_cbranch_execz .Lr_%=\n\t"
+        "v_lshlrev_b32_e32 %[range], 8, %[range]\n\t"
+        "v_perm_b32 %[low], %[low], v46, %[sel]\n\t"          // low << 8 | next byte of the window
+        "v_lshrrev_b64 v[46:47], 8, v[46:47]\n"
+        ".Lr_%=:\n\t"
+        "s_andn2_b64 exec, s[60:61], s[58:59]\n\t"            // everybody back, minus the lanes that are done
+        "s_cbranch_execnz .Lm_%=\n\t"
+        "s_mov_b64 exec, s[56:57]\n\t"
+        : [low] "+v"(low), [range] "+v"(range), [wl] "+v"(wl), [nx] "=&v"(nx), "+{v[46:47]}"(win), "+{v[48:49]}"(cur)
+        : [c100] "s"(0x100u), [sel] "s"(0x06050400u)
+        : "vcc", "scc", "memory", "v50", "v51", "v52", "v53", "v54", "s56", "s57", "s58", "s59", "s60", "s61");
+    return nx;
+}
+
+}  // namespace llcomp_mi

@@ -28,6 +28,13 @@
 #if LLMI_ASM_ENC
 #include "enc_rows_asm.hpp"
 #endif
+// The decoder's mantissa run of the 1-row-slice kernels as a hand-written loop (dec_rows_asm.hpp); 0 = hipcc's loop.
+#ifndef LLMI_ASM_DEC
+#define LLMI_ASM_DEC 1
+#endif
+#if LLMI_ASM_DEC
+#include "dec_rows_asm.hpp"
+#endif
 
 namespace llcomp_mi {
 
@@ -442,6 +449,7 @@ extern __shared__ __attribute__((aligned(32))) unsigned char dyn_lds[];
 // checks that and refuses to run otherwise).
 constexpr uint32_t kRowsEncTabOff = 0, kRowsEncStageOff = 1024, kRowsEncBankOff = 1024 + 16 + 32 * 64;
 constexpr uint32_t kRowsEncLdsBytes = kRowsEncBankOff + 3 * 64 * 8;
+constexpr uint32_t kRowsDecBankOff = 1024, kRowsDecLdsBytes = kRowsDecBankOff + 3 * 4 * 64 * 4;  // table, wide row banks
 // rare: a carry that the block could not finish inside the staging area goes on into the bytes already stored to HBM
 __device__ __forceinline__ void enc_carry_back_flushed(RangeEnc& e) {
     for (int32_t k = e.flushed - 1; k >= 0; --k) {
@@ -823,6 +831,7 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entr
                     const uint32_t r1 = __umul24(d.range, prob_of(cur)) >> 8;
                     d.range -= r1;
                     ++n;
+                    asm volatile("" : "+v"(n));  // (a per-lane counter: hipcc counts in a scalar and copies it out, a 4-cycle v_mov per bin)
                     uint32_t diff;
                     if (__builtin_usub_overflow(d.low, d.range, &diff)) break;
                     d.low = diff;
@@ -848,6 +857,21 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entr
     const uint32_t ones = (1u << ex) - 1;
     if (ex > 0) {
         w += w + uint32_t(!dec_once<5, CHECKED, INLDS>(d, bank, E));
+#if LLMI_ASM_DEC
+        if constexpr (INLDS && !CHECKED) {
+            // The loop gathers the ex - 1 bits at the bottom of `run`, under a marker bit that starts at bit 33 - ex: the
+            // add-with-carry that takes a bit in pushes the marker out as its carry when the last one has come
+            // (dec_rows_asm.hpp); what was gathered before the loop moves up by ex - 1 to make room.
+            const uint32_t m = uint32_t(ex) - 1u;
+            uint32_t run = 0;
+            if (ex > 1) {
+                run = 0x80000000u >> (m - 1u);
+                const uint32_t nx = dec_rows_mantissa_asm(d.low, d.range, d.win, E.e6, run);
+                dec_put_state<6, INLDS>(bank, nx);
+            }
+            w = (w << m) | run;
+        } else
+#endif
         if (ex > 1) {
             entry_t cur = E.e6;
             uint32_t nx;
@@ -896,8 +920,22 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                                                       const uint32_t* __restrict__ slice_len,
                                                       uint64_t* __restrict__ states, int16_t* __restrict__ rec,
                                                       uint32_t* status, const uint64_t gpat) {
-    __shared__ entry_t tab[128];
-    __shared__ uint32_t rowbank[ROWS ? kWideBankWords : 1];
+    constexpr bool ASM = ROWS && LLMI_ASM_DEC != 0;
+    entry_t* tab;
+    uint32_t* rowbank;
+    if constexpr (ASM) {  // the hand-written loop addresses the model table relative to LDS address 0 (see the encoder)
+        tab = reinterpret_cast<entry_t*>(dyn_lds);
+        rowbank = reinterpret_cast<uint32_t*>(dyn_lds + kRowsDecBankOff);
+        if (uint32_t(uintptr_t((lds_u8_ptr)dyn_lds)) != 0) {
+            if (threadIdx.x == 0) atomicOr(status, kStInternal);
+            return;
+        }
+    } else {
+        __shared__ entry_t s_tab[128];
+        __shared__ uint32_t s_rowbank[ROWS ? kWideBankWords : 1];
+        tab = s_tab;
+        rowbank = s_rowbank;
+    }
     clear_lds_states<LDSTAB>();
     load_table(tab);
     const uint32_t lpw = lpw_and_flags & 0xFF;
@@ -1182,7 +1220,7 @@ hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_units, const
             const hipError_t e = allow_big_lds(kernel);
             if (e != hipSuccess) return e;
         }
-        kernel<<<dim3(blocks), dim3(64), T ? kLdsTableBytes : 0, stream>>>(g, arg, d_units, d_slice_len, d_states,
+        kernel<<<dim3(blocks), dim3(64), T ? kLdsTableBytes : (R && LLMI_ASM_DEC ? kRowsDecLdsBytes : 0), stream>>>(g, arg, d_units, d_slice_len, d_states,
                                                                           d_rec, d_status, gpat);
     });
     return hipGetLastError();
