@@ -53,7 +53,9 @@ hipError_t launch_group_sums(const Geometry& g, const uint32_t* d_slice_len, uin
 hipError_t launch_scan_groups(const Geometry& g, uint64_t* d_group_off, uint64_t* d_total, hipStream_t stream);
 // u64[frames]: payload bytes of every frame (sum of its slices' lengths)
 hipError_t launch_frame_bytes(const Geometry& g, const uint32_t* d_slice_len, uint64_t* d_frame_bytes, hipStream_t stream);
-// Slice streams live in STREAM LANE ORDER for the serial kernels: 16-byte units [group][unit][lane], slice_cap/16 units
+// Slice streams live in lane order for the serial kernels.  Behind the ENCODER: 16-byte units [group][unit][lane] (a lane flushes
+// 16 bytes at a time); in front of the DECODER: dwords [group][dword][lane] (a lane reads a dword at a time: a running offset
+// instead of unit arithmetic).  slice_cap/16 units
 // per slice (model_kernels.hip).  pack: that order -> payload (slices back to back, capacity payload_cap);
 // stage: payload -> that order.
 hipError_t launch_pack_payload(const Geometry& g, const uint8_t* d_units, const uint32_t* d_slice_len,
@@ -72,7 +74,7 @@ hipError_t launch_range_sums(const uint32_t* d_vals, const uint64_t* d_start, co
                              uint32_t cap, hipStream_t stream);
 // One lane per slice: range decoder + adaptive states + context model on reconstructed samples.
 // llcomp.hpp:91-127, 219-247, 486-530.  d_rec int16 in LANE ORDER.
-// d_units: the slices' streams in stream lane order (launch_stage_streams).
+// d_units: the slices' streams in dword lane order (launch_stage_streams).
 hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_units, const uint32_t* d_slice_len,
                                 uint64_t* d_states, uint32_t generation, int16_t* d_rec, uint32_t* d_status, hipStream_t stream);
 

@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void k_stage_streams(const Geometry g, const u
     __shared__ GroupStreams gs;
     const uint32_t group = blockIdx.x;
     load_group_streams(g, group, slice_len, off, payload_bytes, status, kStTruncated, gs);
-    const uint32_t cap16 = g.slice_cap >> 4;
+    const uint32_t capdw = g.slice_cap >> 2;
     const uint32_t a = threadIdx.x & 63, b = threadIdx.x >> 6;
     // "+ 4": the dword right behind every stream is staged too (as zeros) -- the decoder clamps its reads to it.
     // All sixteen loads of a thread are in flight before the first is stored, and the loads of the NEXT chunk are issued
@@ -438,11 +438,11 @@ __global__ __launch_bounds__(256) void k_stage_streams(const Geometry g, const u
         }
         __syncthreads();
         if ((c0 + 1) * 256 < gs.max_len + 4) request(c0 + 1);
-        for (uint32_t uu = b; uu < 16; uu += 4) {
-            const uint32_t u = c0 * 16 + uu;
-            if (u < cap16 && a < (1u << g.lane_shift))
-                units[((size_t(group) * cap16 + u) << g.lane_shift) + a] =
-                    make_uint4(tile[a][uu * 4 + 0], tile[a][uu * 4 + 1], tile[a][uu * 4 + 2], tile[a][uu * 4 + 3]);
+        // DWORD lane order for the decoder, [group][dword k][lane]: a wavefront stores one 256-byte row per dword index
+        uint32_t* const dw = reinterpret_cast<uint32_t*>(units);
+        for (uint32_t kk = b; kk < kChunkDwords; kk += 4) {
+            const uint32_t k = c0 * kChunkDwords + kk;
+            if (k < capdw && a < (1u << g.lane_shift)) dw[((size_t(group) * capdw + k) << g.lane_shift) + a] = tile[a][kk];
         }
         __syncthreads();
     }

@@ -131,7 +131,7 @@ struct Bank {
 // consecutive dwords -- conflict-free.  (As [context][lane] 8-byte entries every byte store of a new state was a 2-way
 // bank conflict: 28 of the ~150 LDS cycles of a sample.)  State byte k of a lane: word k / 4, 256 bytes further on.
 constexpr uint32_t kRowBankWords = 3 * 2 * 64;
-__device__ __forceinline__ constexpr uint32_t rowbank_byte(int slot) { return uint32_t(slot >> 2) * 256u + uint32_t(slot & 3); }
+[[maybe_unused]] __device__ __forceinline__ constexpr uint32_t rowbank_byte(int slot) { return uint32_t(slot >> 2) * 256u + uint32_t(slot & 3); }
 // The DECODER's row banks are wide: 16 bits per slot, holding the TABLE OFFSET of the slot's state (8 * state, what the upper
 // half of a half-entry carries anyway) instead of the state byte -- [context][word 0..3][lane] dwords, slot k in half k & 1 of
 // word k / 2.  The address of a slot's entry is then a mask or a right shift by a constant (2-cycle operations) where the
@@ -685,20 +685,22 @@ struct RangeDec {
     uint32_t low, range;
     unsigned long long win; // window, LSB first (next byte = win & 0xFF), sentinel bit above the valid bytes
     uint32_t nxt;           // prefetched dword that follows the window
-    const uint32_t* group;  // WAVE-UNIFORM: first dword of this lane group in the stream lane order array
-    uint32_t lane_dw;       // this lane's dword offset inside a row of units (lane * 4)
-    uint32_t shift;         // lane_shift: dword k sits at group[((k >> 2) << (shift + 2)) + lane_dw + (k & 3)]
-    uint32_t kmax1;         // first dword AFTER the stream; the stager guarantees it (and every byte past the end
-                            // of the stream inside the last dword) reads zero, as llcomp.hpp:475-479 wants
-    uint32_t kn;            // next dword to prefetch
+    // The staged streams are in DWORD lane order, [group][dword k][lane]: dword k of this lane sits `k * step` bytes
+    // behind its first one, so the prefetch walks a running byte offset -- one 2-cycle add and one clamp per dword
+    // (16-byte units as on the encoder's side cost five 4-cycle operations of address arithmetic per top-up).
+    const char* gbase;      // WAVE-UNIFORM: first dword of this lane group in the staged array
+    uint32_t ofs;           // byte offset from there of the next dword to prefetch (lane * 4 + k * step)
+    uint32_t step;          // 4 << lane_shift (a vector value: an add with a scalar operand costs twice as much)
+    uint32_t ofs_end;       // offset of the first dword AFTER the stream; the stager guarantees it (and every byte past the
+                            // end of the stream inside the last dword) reads zero, as llcomp.hpp:475-479 wants
 };
 __device__ __forceinline__ bool window_low(const RangeDec& d) { return uint32_t(d.win >> 32) == 0; }  // <= 3 bytes
 // issues the load of dword k.  UNCONDITIONAL (index clamped to the zero dword behind the stream) so that its result
 // lands directly in the loop-carried register -- a conditional load ends in a register copy and hipcc waits vmcnt(0)
 // for that copy right after the issue; 32-bit offset from a wave-uniform base = one global_load with an SGPR base.
-__device__ __forceinline__ void dec_prefetch(RangeDec& d, uint32_t k) {
-    const uint32_t kc = min(k, d.kmax1);
-    d.nxt = d.group[(((kc >> 2) << d.shift) << 2) + d.lane_dw + (kc & 3)];
+__device__ __forceinline__ void dec_prefetch(RangeDec& d) {
+    d.nxt = *reinterpret_cast<const uint32_t*>(d.gbase + min(d.ofs, d.ofs_end));
+    d.ofs += d.step;
 }
 // Pins the point where a value that was loaded earlier is consumed: the compiler's s_waitcnt for it lands HERE (the
 // load was issued a whole sample ago, so it has long returned) and no later load may be hoisted above it -- otherwise
@@ -713,19 +715,19 @@ __device__ __forceinline__ void dec_append(RangeDec& d) {  // requires window_lo
     const uint32_t sh = 31u - uint32_t(__builtin_clz(uint32_t(d.win)));
     const uint32_t rest = uint32_t(d.win) ^ (1u << sh);  // (the high dword is zero here)
     d.win = ((0x100000000ull | ready) << sh) | rest;
-    dec_prefetch(d, d.kn++);
+    dec_prefetch(d);
 }
-__device__ __forceinline__ void dec_open(RangeDec& d, const uint32_t* group, uint32_t lane_dw, uint32_t shift, uint32_t len) {
-    d.group = group;
-    d.lane_dw = lane_dw;
-    d.shift = shift;
-    d.kmax1 = (len + 3) >> 2;
-    dec_prefetch(d, 0);
+__device__ __forceinline__ void dec_open(RangeDec& d, const uint32_t* group, uint32_t lane, uint32_t shift, uint32_t len) {
+    d.gbase = reinterpret_cast<const char*>(group);
+    d.ofs = lane * 4;
+    d.step = 4u << shift;
+    asm volatile("" : "+v"(d.step));
+    d.ofs_end = lane * 4 + ((len + 3) >> 2) * d.step;
+    dec_prefetch(d);
     const uint32_t first = d.nxt;
-    dec_prefetch(d, 1);
+    dec_prefetch(d);
     const unsigned long long both = first | ((unsigned long long)d.nxt << 32);
-    dec_prefetch(d, 2);
-    d.kn = 3;
+    dec_prefetch(d);
     d.range = 0xFF00;  // llcomp.hpp:93-96: low = first two bytes
     d.low = ((first & 0xFF) << 8) | ((first >> 8) & 0xFF);
     d.win = (both >> 16) | (1ull << 48);  // six bytes left
@@ -945,13 +947,13 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
     if (threadIdx.x >= lpw || id >= g.n_slices) return;
     const SliceRect r = slice_rect(g, id);
     RangeDec d;
-    // streams come staged in stream lane order; lengths beyond the payload were clipped (and reported) by the stager.
+    // streams come staged in dword lane order (RangeDec); lengths beyond the payload were clipped (and reported) by the stager.
     // All lanes of a wavefront belong to one lane group (lanes_per_wave divides the group width): its base is uniform.
     const uint32_t len = min(slice_len[id], g.slice_cap - 16);
     const uint32_t grp = __builtin_amdgcn_readfirstlane(id >> g.lane_shift);
     const uint32_t lane_in_group = id & ((1u << g.lane_shift) - 1);
-    dec_open(d, reinterpret_cast<const uint32_t*>(units) + ((size_t(grp) * (g.slice_cap >> 4)) << (g.lane_shift + 2)),
-             lane_in_group * 4, g.lane_shift, len);
+    dec_open(d, reinterpret_cast<const uint32_t*>(units) + ((size_t(grp) * (g.slice_cap >> 2)) << g.lane_shift), lane_in_group,
+             g.lane_shift, len);
 
     // reconstructed samples in lane order: sample k of this slice is p0[k * GW]
     int16_t* p0 = rec + lane_order_index(g, id, 0);
