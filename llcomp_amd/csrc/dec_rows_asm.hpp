@@ -7,7 +7,8 @@
 // above them, placed so that it leaves the register as the carry of that same add-with-carry when the lane's last bit has
 // come in; the carry is the loop's exit mask.  (The caller merges the run into what it had gathered before, once per sample.)
 //
-// LDS contract: the model table sits at LDS address 0 (the kernel puts its LDS into the dynamic block and checks that).
+// LDS contract: the entries of the model table carry absolute LDS addresses of their successors (load_table in
+// slice_kernels.hip), so the loop needs no base and the table may sit anywhere.
 // Register contract: the window lives in v[46:47] and the current entry in v[48:49] (operands tied to those registers: the
 // block needs their halves by name), v50..v54 and s56..s61 are owned by the block; with hipcc's own needs the kernel stays
 // at 56 VGPRs / 64 SGPRs (eight wavefronts per SIMD with room to spare).
@@ -25,7 +26,8 @@ __device__ __forceinline__ uint32_t dec_rows_mantissa_asm(uint32_t& low, uint32_
                                                           unsigned long long cur, uint32_t& wl) {
     uint32_t nx;
     asm volatile(
-        "s_mov_b64 s[56:57], exec\n"
+        "s_mov_b64 s[56:57], exec\n\t"
+        ".p2align 6\n"
         ".Lm_%=:\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         "v_mul_u32_u24_sdwa v50, v48, %[range] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"

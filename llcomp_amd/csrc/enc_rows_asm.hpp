@@ -211,7 +211,8 @@ __device__ __forceinline__ void enc_rows_sample_asm(uint32_t& low, uint32_t& ran
         LL_UNARY("3", "2", LL_E3L, LL_E3H, "3")
         "s_mov_b64 " LL_SU ", exec\n\t"
         "v_add_u32_e32 " LL_N ", -3, " LL_EX "\n\t"
-        "s_mov_b32 " LL_SI ", 0\n"
+        "s_mov_b32 " LL_SI ", 0\n\t"
+        ".p2align 6\n"  // (the two run loops start on a 64-byte line of the instruction cache)
         ".Ltail_%=:\n\t"
         LL_SPLIT(LL_E4L)
         "v_cmp_lt_u32_e32 vcc, " LL_SI ", " LL_N "\n\t"
@@ -247,6 +248,7 @@ __device__ __forceinline__ void enc_rows_sample_asm(uint32_t& low, uint32_t& ran
         "ds_write_b8 %[bank], " LL_E5H " offset:257\n"
         LL_PATCH_END("5")
         LL_RENORM("6")
+        ".p2align 6\n"
         ".Lman_%=:\n\t"
         "v_cmp_ne_u32_e32 vcc, %[sent], " LL_BITS "\n\t"
         "s_and_b64 exec, exec, vcc\n\t"

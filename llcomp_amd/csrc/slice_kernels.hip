@@ -104,10 +104,20 @@ constexpr EntryTable make_entries() {
 }
 __constant__ EntryTable c_entries = make_entries();
 
+// The copy in LDS carries ABSOLUTE LDS byte addresses in the offset fields of its entries (tables.hpp has them relative to
+// the table): the table's own LDS address is added to both while it is copied in.  Walking from entry to entry is then a
+// right shift and a load with no base to add -- whether the table sits at a fixed address the compiler knows (static LDS) or
+// in the dynamic block, where it only knows a symbol (and would add it with a 4-cycle SDWA add per access).
+using lds_u8_ptr = __attribute__((address_space(3))) uint8_t*;
+using lds_entry_ptr = const __attribute__((address_space(3))) unsigned long long*;
+__device__ __forceinline__ uint32_t lds_address(const void* p) { return uint32_t(uintptr_t((lds_u8_ptr) reinterpret_cast<const uint8_t*>(p))); }
 __device__ __forceinline__ void load_table(entry_t* tab) {
-    for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x) tab[i] = c_entries.v[i];
+    const unsigned long long rebase = (unsigned long long)lds_address(tab) * 0x0001000000010000ull;
+    for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x) tab[i] = c_entries.v[i] + rebase;
     __syncthreads();
 }
+// the entry at an absolute LDS address taken from a half-entry / a wide row bank
+__device__ __forceinline__ entry_t lds_entry(uint32_t address) { return *reinterpret_cast<lds_entry_ptr>(uintptr_t(address)); }
 
 __device__ __forceinline__ uint32_t byte_of(uint32_t w, int k) { return (w >> (8 * k)) & 0xFF; }
 __device__ __forceinline__ uint32_t consume_here(uint32_t v);
@@ -200,10 +210,8 @@ __device__ __forceinline__ void fetch_rest(Entries& E, const uint32_t* bank, con
     E.e7 = tab[slot_state<7>(bank)];
 }
 
-// the entry of the successor that half-entry `nx` names: its byte offset sits pre-scaled in the upper half (tables.hpp)
-__device__ __forceinline__ entry_t entry_at(const entry_t* tab, uint32_t nx) {
-    return *reinterpret_cast<const entry_t*>(reinterpret_cast<const char*>(tab) + (nx >> 16));
-}
+// the entry of the successor that half-entry `nx` names: its LDS address sits in the upper half (load_table)
+__device__ __forceinline__ entry_t entry_at(const entry_t*, uint32_t nx) { return lds_entry(nx >> 16); }
 
 // ================================================ ENCODER ========================================================
 // Range encoder of one lane (llcomp.hpp:33-89).  Output bytes are staged in a per-lane 32-byte LDS area and leave for
@@ -242,7 +250,6 @@ struct RangeEnc {
 // at position -1, i.e. the unused last byte of the neighbouring lane's area (16 bytes of padding in front of lane 0).
 constexpr int kStageBytes = 32;
 constexpr int kStagePad = 16;
-using lds_u8_ptr = __attribute__((address_space(3))) uint8_t*;
 __device__ __forceinline__ int32_t enc_pos(const RangeEnc& e) { return e.flushed + int32_t(e.wp - e.base); }
 // stream lane order: unit u of this lane is (u << lane_shift) units further on
 __device__ __forceinline__ uint8_t* unit_byte(RangeEnc& e, uint32_t k) {
@@ -422,10 +429,10 @@ __device__ __forceinline__ void enc_residual(RangeEnc& e, Bank& bank, const entr
                 // remaining mantissa bits left-aligned, followed by a sentinel 1: the loop needs no counter
                 uint32_t bits = ((a << 1) | 1u) << (32 - ex);
                 do {
-                    nx = enc_step_msb(e, bits, cur);  // successor's table offset
-                    cur = *reinterpret_cast<const entry_t*>(reinterpret_cast<const char*>(tab) + nx);
+                    nx = enc_step_msb(e, bits, cur);  // successor's LDS address
+                    cur = lds_entry(nx);
                 } while (bits != 0x80000000u);
-                put_state<6, INLDS>(bank, nx >> 3);
+                put_state<6, INLDS>(bank, (nx - lds_address(tab)) >> 3);
             }
         }
         enc_once<7, INLDS>(e, bank, E, res < 0);
@@ -449,7 +456,6 @@ extern __shared__ __attribute__((aligned(32))) unsigned char dyn_lds[];
 // checks that and refuses to run otherwise).
 constexpr uint32_t kRowsEncTabOff = 0, kRowsEncStageOff = 1024, kRowsEncBankOff = 1024 + 16 + 32 * 64;
 constexpr uint32_t kRowsEncLdsBytes = kRowsEncBankOff + 3 * 64 * 8;
-constexpr uint32_t kRowsDecBankOff = 1024, kRowsDecLdsBytes = kRowsDecBankOff + 3 * 4 * 64 * 4;  // table, wide row banks
 // rare: a carry that the block could not finish inside the staging area goes on into the bytes already stored to HBM
 __device__ __forceinline__ void enc_carry_back_flushed(RangeEnc& e) {
     for (int32_t k = e.flushed - 1; k >= 0; --k) {
@@ -661,7 +667,7 @@ __device__ __forceinline__ void dec_put_state(Bank& b, uint32_t half) {
 }
 template <int SLOT, bool INLDS>
 __device__ __forceinline__ entry_t dec_entry(const Bank& b, const entry_t* tab) {
-    if constexpr (INLDS) return *reinterpret_cast<const entry_t*>(reinterpret_cast<const char*>(tab) + wide_offset<SLOT>(b.w));
+    if constexpr (INLDS) return lds_entry(wide_offset<SLOT>(b.w));
     else return tab[slot_state<SLOT>(b.w)];
 }
 template <bool INLDS>
@@ -922,22 +928,8 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                                                       const uint32_t* __restrict__ slice_len,
                                                       uint64_t* __restrict__ states, int16_t* __restrict__ rec,
                                                       uint32_t* status, const uint64_t gpat) {
-    constexpr bool ASM = ROWS && LLMI_ASM_DEC != 0;
-    entry_t* tab;
-    uint32_t* rowbank;
-    if constexpr (ASM) {  // the hand-written loop addresses the model table relative to LDS address 0 (see the encoder)
-        tab = reinterpret_cast<entry_t*>(dyn_lds);
-        rowbank = reinterpret_cast<uint32_t*>(dyn_lds + kRowsDecBankOff);
-        if (uint32_t(uintptr_t((lds_u8_ptr)dyn_lds)) != 0) {
-            if (threadIdx.x == 0) atomicOr(status, kStInternal);
-            return;
-        }
-    } else {
-        __shared__ entry_t s_tab[128];
-        __shared__ uint32_t s_rowbank[ROWS ? kWideBankWords : 1];
-        tab = s_tab;
-        rowbank = s_rowbank;
-    }
+    __shared__ entry_t tab[128];  // (entries carry absolute LDS addresses, load_table: the hand-written loop needs no base)
+    __shared__ uint32_t rowbank[ROWS ? kWideBankWords : 1];
     clear_lds_states<LDSTAB>();
     load_table(tab);
     const uint32_t lpw = lpw_and_flags & 0xFF;
@@ -967,7 +959,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
         // one-row slice (llcomp.hpp:494-509 with h == 0): l = left (128 at the start), everything above = l, so
         // hash = 605*quant5(L - l), prediction = l.  The three banks sit in LDS ([context][lane], see the encoder); no
         // state memory in HBM.
-        for (uint32_t k = 0; k < 12; ++k) rowbank[k * 64 + threadIdx.x] = 0;
+        for (uint32_t k = 0; k < 12; ++k) rowbank[k * 64 + threadIdx.x] = lds_address(tab) * 0x00010001u;  // state 0 in every slot
         int l[NCH], L[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) l[k] = L[k] = 128;
@@ -1222,7 +1214,7 @@ hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_units, const
             const hipError_t e = allow_big_lds(kernel);
             if (e != hipSuccess) return e;
         }
-        kernel<<<dim3(blocks), dim3(64), T ? kLdsTableBytes : (R && LLMI_ASM_DEC ? kRowsDecLdsBytes : 0), stream>>>(g, arg, d_units, d_slice_len, d_states,
+        kernel<<<dim3(blocks), dim3(64), T ? kLdsTableBytes : 0, stream>>>(g, arg, d_units, d_slice_len, d_states,
                                                                           d_rec, d_status, gpat);
     });
     return hipGetLastError();
