@@ -50,7 +50,7 @@ typedef enum llcomp_mi_status {
     LLCOMP_MI_BAD_ARGS = 4,        /* null pointers, zero sizes, unsupported channel count, bad opts */
     LLCOMP_MI_OUT_OF_RANGE = 5,    /* legacy format with w or h > 65535, or w*h*c >= 2^31 (reference: silent truncation, D4) */
     LLCOMP_MI_OUTPUT_OVERFLOW = 6, /* caller-provided output capacity too small (reference: heap overflow, D1) */
-    LLCOMP_MI_HIP_ERROR = 7,
+    LLCOMP_MI_HIP_ERROR = 7,       /* a HIP call failed, or a kernel found its own launch assumptions violated and refused to run */
     LLCOMP_MI_NO_DEVICE = 8,
     LLCOMP_MI_NOMEM = 9,
     LLCOMP_MI_BUSY = 10            /* streaming pipeline: every slot is occupied / the oldest job is still in flight */
