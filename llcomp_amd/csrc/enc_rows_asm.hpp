@@ -52,6 +52,9 @@ namespace llcomp_mi {
 #define LL_E7 "v[48:49]"
 #define LL_E7L "v48"
 #define LL_E7H "v49"
+#define LL_LOW "v30"    // RangeEnc::low and ::range live in ONE register pair (an operand tied to it): a renormalisation
+#define LL_RANGE "v31"  // shifts both with one 64-bit shift -- `low` is below 2^25, a carry out of its held byte is
+#define LL_LR "v[30:31]"  // cleared by the subroutine before, so nothing of it reaches `range` -- and masks the old held byte away
 #define LL_R1 "v50"    // range * P >> 8
 #define LL_BITS "v51"  // mantissa bits still to code, left-aligned, sentinel 1 behind them
 #define LL_N "v51"     // ones of the unary tail (ex - 3); the tail is over before the mantissa bits are formed
@@ -84,10 +87,8 @@ namespace llcomp_mi {
 #endif
 #if LLMI_ASM_VAR & 1
 #define LL_C3 "3"
-#define LL_C8 "8"
 #else
 #define LL_C3 "%[c3]"
-#define LL_C8 "%[c8]"
 #endif
 #if LLMI_ASM_VAR & 4
 #define LL_PATCH_SKIP(N)
@@ -102,26 +103,26 @@ namespace llcomp_mi {
 #endif
 // range -= (r1 = range * P(entry) >> 8): the outcome of a 0
 #define LL_SPLIT(EL)                                                                                              \
-    "v_mul_u32_u24_sdwa " LL_R1 ", " EL ", %[range] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t" \
+    "v_mul_u32_u24_sdwa " LL_R1 ", " EL ", " LL_RANGE " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t" \
     "v_lshrrev_b32_e32 " LL_R1 ", 8, " LL_R1 "\n\t"                                                               \
-    "v_sub_u32_e32 %[range], %[range], " LL_R1 "\n\t"
+    "v_sub_u32_e32 " LL_RANGE ", " LL_RANGE ", " LL_R1 "\n\t"
 // the lanes in exec coded a 1 instead
 #define LL_ONE                                          \
-    "v_add_u32_e32 %[low], %[low], %[range]\n\t"        \
-    "v_mov_b32_e32 %[range], " LL_R1 "\n\t"
+    "v_add_u32_e32 " LL_LOW ", " LL_LOW ", " LL_RANGE "\n\t"        \
+    "v_mov_b32_e32 " LL_RANGE ", " LL_R1 "\n\t"
 // Renormalisation site N of the lanes in exec (llcomp.hpp:62-72; one step always suffices).  The byte held in bits 16..23 of
 // `low` goes to the staging area; a carry that reached a held 0xFF (bit 24) is the rare case and a subroutine.
 #define LL_RENORM(N)                                                                                               \
-    "v_cmp_gt_u32_e32 vcc, %[c100], %[range]\n\t"                                                                  \
+    "v_cmp_gt_u32_e32 vcc, %[c100], " LL_RANGE "\n\t"                                                                  \
     "s_and_saveexec_b64 " LL_SW ", vcc\n\t"                                                                        \
     LL_RENORM_SKIP(N)                                                                                              \
-    "ds_write_b8_d16_hi %[wp], %[low]\n\t"                                                                         \
-    "v_cmp_lt_u32_e32 vcc, %[cwrap], %[low]\n\t"                                                                   \
+    "ds_write_b8_d16_hi %[wp], " LL_LOW "\n\t"                                                                         \
+    "v_cmp_lt_u32_e32 vcc, %[cwrap], " LL_LOW "\n\t"                                                                   \
     "s_cbranch_vccnz .Lrare" N "_%=\n"                                                                             \
     ".Lback" N "_%=:\n\t"                                                                                          \
     "v_add_u32_e32 %[wp], 1, %[wp]\n\t"                                                                            \
-    "v_lshlrev_b32_e32 %[range], 8, %[range]\n\t"                                                                  \
-    "v_lshlrev_b32_sdwa %[low], " LL_C8 ", %[low] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n" \
+    "v_lshlrev_b64 " LL_LR ", 8, " LL_LR "\n\t"                                                                     \
+    "v_and_b32_e32 " LL_LOW ", 0xffffff, " LL_LOW "\n"                                                                     \
     ".Lskip" N "_%=:\n\t"                                                                                          \
     "s_mov_b64 exec, " LL_SW "\n\t"
 #define LL_RARE_STUB(N)                     \
@@ -163,10 +164,10 @@ struct EncRowsExtra {
     uint32_t any_pend;  // wave-uniform: some lane set `pend`
 };
 
-// Codes residual `res` in the context whose 8 state bytes sit at LDS address `bank`; low / range / wp as in RangeEnc
-// (slice_kernels.hip; all LDS addresses are byte addresses), `base` = LDS address of the lane's staging area (carries walk
+// Codes residual `res` in the context whose 8 state bytes sit at LDS address `bank`; low_range = RangeEnc::low | ::range << 32,
+// wp as in RangeEnc (slice_kernels.hip; all LDS addresses are byte addresses), `base` = LDS address of the lane's staging area (carries walk
 // back to it).
-__device__ __forceinline__ void enc_rows_sample_asm(uint32_t& low, uint32_t& range, uint32_t& wp, EncRowsExtra& x, uint32_t bank,
+__device__ __forceinline__ void enc_rows_sample_asm(unsigned long long& low_range, uint32_t& wp, EncRowsExtra& x, uint32_t bank,
                                                     int res, uint32_t base) {
     asm volatile(
         "s_mov_b64 " LL_SX ", exec\n\t"
@@ -295,6 +296,7 @@ __device__ __forceinline__ void enc_rows_sample_asm(uint32_t& low, uint32_t& ran
         "s_cbranch_execnz .Lcloop_%=\n"
         ".Lcdone_%=:\n\t"
         "s_mov_b64 exec, " LL_SC "\n\t"
+        "v_and_b32_e32 " LL_LOW ", 0xffffff, " LL_LOW "\n\t"  // the carry is spent (it must not reach `range` in the 64-bit shift)
         "s_add_u32 " LL_SRL ", " LL_SRL ", 4\n\t"
         "s_addc_u32 " LL_SRH ", " LL_SRH ", 0\n\t"
         "s_setpc_b64 " LL_SR "\n"
@@ -324,9 +326,9 @@ __device__ __forceinline__ void enc_rows_sample_asm(uint32_t& low, uint32_t& ran
         "s_cmp_ge_u32 " LL_S1 ", " LL_S2 "\n\t"
         "s_cselect_b32 %[hot], 1, 0\n\t"
         "s_mov_b64 exec, " LL_SX "\n\t"
-        : [low] "+v"(low), [range] "+v"(range), [wp] "+v"(wp), [pend] "+v"(x.pend), [hot] "+s"(x.hot), [anyp] "+s"(x.any_pend)
+        : "+{v[30:31]}"(low_range), [wp] "+v"(wp), [pend] "+v"(x.pend), [hot] "+s"(x.hot), [anyp] "+s"(x.any_pend)
         : [bank] "v"(bank), [res] "v"(res), [base] "v"(base), [c100] "s"(0x100u), [cwrap] "s"(0xFFFFFFu),
-          [sent] "s"(0x80000000u), [c3] "v"(3u), [c8] "v"(8u)
+          [sent] "s"(0x80000000u), [c3] "v"(3u)
         : "vcc", "scc", "memory", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44",
           "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43",
           "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54");

@@ -544,6 +544,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
         asm volatile("" : "+v"(bank_base));
 #if LLMI_ASM_ENC
         EncRowsExtra xs{0u, 0u, 0u};
+        unsigned long long low_range = e.low | ((unsigned long long)e.range << 32);  // (one register pair: enc_rows_asm.hpp)
 #endif
         // one sample: context -> row bank, residual -> bins
         auto code = [&](uint32_t sy) {
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
                 res = int(sy) >> 16;
             }
 #if LLMI_ASM_ENC
-            enc_rows_sample_asm(e.low, e.range, e.wp, xs, bank_base + bofs, res, e.base);
+            enc_rows_sample_asm(low_range, e.wp, xs, bank_base + bofs, res, e.base);
             if (__builtin_expect(xs.any_pend != 0, 0)) {
                 xs.any_pend = 0;
                 if (xs.pend) enc_carry_back_flushed(e);
@@ -598,6 +599,10 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
             s0 = s1;
             s1 = s2;
         }
+#if LLMI_ASM_ENC
+        e.low = uint32_t(low_range);
+        e.range = uint32_t(low_range >> 32);
+#endif
     } else {
         // Everything the coder needs is known up front: the symbol two samples ahead and the state bank one sample
         // ahead are in flight while a sample is coded (forwarded when consecutive samples share a context).
