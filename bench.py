@@ -913,7 +913,7 @@ def main():
                                           **getattr(c4_run, "last_detail", {})}
 
         def leg_contents():  # other contents at the default slicing (4 distinct frames, the rest rotations)
-            for content in ("g2", "mid"):
+            for content in ("g2", "mid", "nat"):  # clean gradient, dithered gradient, photo-like (synth.py)
                 if content != args.content:
                     also[f"{content}_default_slicing"] = brief(measure(make_frames(content, F, 0, distinct=4), args.tile_w, args.tile_h, planar, args.streams, sub, 1, local_rank),
                                                                workload=f"{F} frames 4K {content}, {args.tile_w}x{args.tile_h} planar")

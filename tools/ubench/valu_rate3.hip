@@ -71,6 +71,9 @@ __global__ void k(unsigned* out, int iters, unsigned seed) {
 #define A47(i) asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(r[i]));
 #define A48(i) asm volatile("s_mov_b64 exec, exec");
 #define A49(i) asm volatile("s_or_b64 s[20:21], s[20:21], vcc" ::: "s20", "s21");
+#define A50(i) asm volatile("v_cmp_gt_u64 vcc, %1, %0" : : "v"(q[i & 3]), "s"(sq) : "vcc");
+#define A51(i) asm volatile("v_cmp_eq_u64 vcc, 0, %0" : : "v"(q[i & 3]) : "vcc");
+#define A52(i) asm volatile("v_lshlrev_b64 %0, 8, %0" : "+v"(q[i & 3]));
 #define CASE(N) else if (KIND == N) BODY(A##N)
         if (KIND == 31 || KIND == 33 || KIND == 34) {
             asm volatile("s_mov_b64 s[22:23], exec\n s_mov_b64 exec, 0" ::: "s22", "s23");
@@ -80,7 +83,7 @@ __global__ void k(unsigned* out, int iters, unsigned seed) {
         CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
         CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26) CASE(27) CASE(28)
         CASE(29) CASE(30) CASE(32) CASE(35) CASE(36) CASE(37) CASE(38) CASE(39) CASE(40) CASE(41) CASE(42) CASE(43) CASE(44) CASE(45) CASE(46)
-        CASE(47) CASE(48) CASE(49)
+        CASE(47) CASE(48) CASE(49) CASE(50) CASE(51) CASE(52)
     }
     unsigned s = lds[threadIdx.x];
     for (int i = 0; i < 8; ++i) s ^= r[i];
@@ -113,10 +116,10 @@ double run(int waves_per_simd, int iters) {
         "v_lshrrev 24", "s_nop 0", "s_mov_b64 s,exec", "saveexec+restore (pair)", "v_add exec=0", "ds_write_b8", "ds_write_b8 exec=0", "v_mul_u24 exec=0", \
         "v_cmp+cbranch_vccz+nop (3)", "v_sub_co_u32", "v_subrev_u32", "v_bfe_u32 imm", "v_and sgpr", \
         "v_cndmask_e64 0,1,vcc", "v_cndmask vzero,v,vcc", "v_lshrrev vgpr-amount", "v_lshlrev_b64 vgpr-amount", "v_min_u32", "v_lshl_add_u64 sgpr", "v_cmp_e64 sgpr", \
-        "v_ashrrev 31", "s_mov_b64 exec,exec", "s_or_b64 s,s,vcc"}
+        "v_ashrrev 31", "s_mov_b64 exec,exec", "s_or_b64 s,s,vcc", "v_cmp_gt_u64 sgpr", "v_cmp_eq_u64 0", "v_lshlrev_b64 imm"}
 template <int K0>
 void run_one(int kind, int w, const char* const* names) {
-    if constexpr (K0 < 50) {
+    if constexpr (K0 < 53) {
         if (kind == K0) { printf("  %-28s %.2f\n", names[K0], run<K0>(w, 300)); fflush(stdout); return; }
         run_one<K0 + 1>(kind, w, names);
     }
