@@ -58,4 +58,45 @@ __device__ __forceinline__ uint32_t dec_rows_mantissa_asm(uint32_t& low, uint32_
     return nx;
 }
 
+// The unary run of the exponent on slot 4 (llcomp.hpp:226-235): in: exec = the lanes whose exponent is at least 3; cur = entry
+// of slot 4's state; n = 0.  Every lane takes the outcome of a 0 in place (range = r0, low -= r0: a borrow says the bin IS a 0
+// and the lane leaves; its `low` is put back behind the loop, once per sample -- hipcc's loop keeps the difference apart and
+// copies it in, a move per bin); the lanes that stay take r1 as the range, refill (r1 << 8 is the product with its low byte
+// masked away: no left shift) and walk on to the high half's successor.  out: n = bins of the run (ones + the closing 0), cur =
+// entry whose low half is the new state.  The refill of the closing bin is the caller's (pending, like in the C++ loop); no
+// limit per step: a run fed past the window ends by itself when the window's zeros come.
+__device__ __forceinline__ void dec_rows_unary_asm(uint32_t& low, uint32_t& range, unsigned long long& win, unsigned long long& cur,
+                                                   uint32_t& n) {
+    asm volatile(
+        "s_mov_b64 s[56:57], exec\n\t"
+        ".p2align 6\n"
+        ".Lu_%=:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mul_u32_u24_sdwa v50, v48, %[range] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_e32 v51, 8, v50\n\t"                  // r1
+        "v_sub_u32_e32 %[range], %[range], v51\n\t"          // r0
+        "v_sub_co_u32_e32 %[low], vcc, %[low], %[range]\n\t"
+        "v_add_u32_e32 %[n], 1, %[n]\n\t"
+        "s_andn2_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz .Lu_done_%=\n\t"
+        "v_lshrrev_b32_e32 v53, 16, v49\n\t"
+        "ds_read_b64 v[48:49], v53\n\t"
+        "v_mov_b32_e32 %[range], v51\n\t"
+        "v_cmp_gt_u32_e32 vcc, %[c100], v51\n\t"
+        "s_and_saveexec_b64 s[60:61], vcc\n\t"
+        "s_cbranch_execz .Lur_%=\n\t"
+        "v_and_b32_e32 %[range], 0xffffff00, v50\n\t"
+        "v_perm_b32 %[low], %[low], v46, %[sel]\n\t"
+        "v_lshrrev_b64 v[46:47], 8, v[46:47]\n"
+        ".Lur_%=:\n\t"
+        "s_mov_b64 exec, s[60:61]\n\t"
+        "s_branch .Lu_%=\n"
+        ".Lu_done_%=:\n\t"
+        "s_mov_b64 exec, s[56:57]\n\t"
+        "v_add_u32_e32 %[low], %[low], %[range]\n\t"
+        : [low] "+v"(low), [range] "+v"(range), [n] "+v"(n), "+{v[46:47]}"(win), "+{v[48:49]}"(cur)
+        : [c100] "s"(0x100u), [sel] "s"(0x06050400u)
+        : "vcc", "scc", "memory", "v50", "v51", "v52", "v53", "v54", "s56", "s57", "s58", "s59", "s60", "s61");
+}
+
 }  // namespace llcomp_mi

@@ -839,6 +839,13 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entr
                 // happens once, behind the loop.
                 entry_t cur = E.e4;
                 int n = 0;  // bins of the unary tail: n - 1 ones and the closing zero
+#if LLMI_ASM_DEC
+                if constexpr (INLDS && !CHECKED) {
+                    uint32_t nn = 0;
+                    dec_rows_unary_asm(d.low, d.range, d.win, cur, nn);
+                    n = int(nn);
+                } else
+#endif
                 for (;;) {
                     if (CHECKED && d.win <= 1) dec_append(d);
                     const uint32_t r1 = __umul24(d.range, prob_of(cur)) >> 8;
