@@ -827,6 +827,12 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entr
     if (!ALL) dec_fetch_rest<INLDS>(E, bank, tab);
     int ex = 0;
     bool ok = true;
+#if LLMI_ASM_DEC
+    if constexpr (INLDS && !CHECKED) {  // slots 1..4 as one hand-written block (dec_rows_asm.hpp)
+        ex = int(dec_rows_exponent_asm(d.low, d.range, d.win, lds_address(bank.lds), E.e1, E.e2, E.e3, E.e4));
+        if (ex > 31) ok = false;  // "Invalid exponent" (llcomp.hpp:230-235), confirmed by the checked replay
+    } else
+#endif
     if (dec_once<1, CHECKED, INLDS>(d, bank, E)) {
         ex = 1;
         if (dec_once<2, CHECKED, INLDS>(d, bank, E)) {
@@ -839,13 +845,6 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entr
                 // happens once, behind the loop.
                 entry_t cur = E.e4;
                 int n = 0;  // bins of the unary tail: n - 1 ones and the closing zero
-#if LLMI_ASM_DEC
-                if constexpr (INLDS && !CHECKED) {
-                    uint32_t nn = 0;
-                    dec_rows_unary_asm(d.low, d.range, d.win, cur, nn);
-                    n = int(nn);
-                } else
-#endif
                 for (;;) {
                     if (CHECKED && d.win <= 1) dec_append(d);
                     const uint32_t r1 = __umul24(d.range, prob_of(cur)) >> 8;
