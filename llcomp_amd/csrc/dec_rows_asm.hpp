@@ -1,137 +1,293 @@
-// dec_rows_asm.hpp -- the mantissa run of the decoder for 1-row slices (slot 6 of getSymbol<true,4,6,7>, llcomp.hpp:236-243,
-// over the range decoder, llcomp.hpp:98-121), hand-written for gfx950.  Same bins and arithmetic as the loop around
-// dec_step_acc in slice_kernels.hip (which the checked replay and the other kernel families keep using).
+// dec_rows_asm.hpp -- one sample of the decoder's FAST PATH for 1-row slices (getSymbol<true,4,6,7>, llcomp.hpp:219-247, over
+// the range decoder, llcomp.hpp:98-121), hand-written for gfx950.  Same bins, same order, same arithmetic as
+// dec_residual<*, false, true> in slice_kernels.hip, which documents the scheme and stays in use as the CHECKED replay (the block
+// never looks at the fill level of the window: dec_sample rolls back and replays a sample that emptied it) and for the other
+// kernel families.
 //
-// Why by hand: hipcc's loop ends on a compare of the gathered bits against a per-lane limit -- a 4-cycle operation per bin on
-// top of the add-with-carry that gathers them.  Here the register that gathers the bits (at its bottom) carries a marker bit
-// above them, placed so that it leaves the register as the carry of that same add-with-carry when the lane's last bit has
-// come in; the carry is the loop's exit mask.  (The caller merges the run into what it had gathered before, once per sample.)
+// What the block does that hipcc's structurised code cannot (prices: tools/ubench/valu_rate3):
+//   * the lane sets of the unary exponent are NESTED (the lanes that decode a 1 on slot k are the lanes that decode slot k + 1),
+//     so exec only shrinks until the phase is over; every lane takes the outcome of a 0 IN PLACE (range = r0, low -= r0: a
+//     borrow says the bin is a 0 and the lane drops out; `low` is put back and the refill done once behind the phase), where
+//     the compiler keeps the difference apart and selects or copies per bin;
+//   * a lane that stays has range = r1, and r1 << 8 of its refill is the product with its low byte masked away (no left shift);
+//   * the mantissa run gathers its bits under a MARKER bit that the same add-with-carry pushes out as its carry when the lane's
+//     last bit has come in: the carry is the loop's exit mask, no compare per bin;
+//   * the "most lanes non-zero" flag is three scalar instructions on masks the block has anyway; no copies at merges; the two
+//     run loops start on a 64-byte line of the instruction cache.
 //
-// LDS contract: the entries of the model table carry absolute LDS addresses of their successors (load_table in
-// slice_kernels.hip), so the loop needs no base and the table may sit anywhere.
-// Register contract: the window lives in v[46:47] and the current entry in v[48:49] (operands tied to those registers: the
-// block needs their halves by name), v50..v54 and s56..s61 are owned by the block; with hipcc's own needs the kernel stays
-// at 56 VGPRs / 64 SGPRs (eight wavefronts per SIMD with room to spare).
+// LDS contract: the entries of the model table carry absolute LDS addresses of their successors (load_table); the row bank is
+// the decoder's wide one (16-bit table addresses, [word 0..3][lane] 256 bytes apart, slot k in half k & 1 of word k / 2).
+// Register contract: the window lives in v[46:47] (an operand tied to the pair: the block needs its low half by name), the block
+// owns v32..v45, v48..v52 and s56..s71 for its length; with what hipcc needs around it the kernel stays at 56 VGPRs / 80 SGPRs
+// (eight wavefronts per SIMD with room to spare).  gfx950 hazards the assembler does not handle inside inline asm, checked by
+// hand: a vector instruction that reads VCC follows the vector instruction that wrote it by two wait states (s_nop 1).
 #pragma once
 #include <cstdint>
 
 namespace llcomp_mi {
 
-// in: exec = the lanes with a mantissa run (exponent > 1); low / range as in RangeDec; win = the 64-bit stream window (sentinel
-// scheme of RangeDec); cur = entry of slot 6's state; wl = the marker bit (bit 32 - bins of the run), the run's inverted bits
-// below it on return.  Returns the
-// half-entry that belongs to the last decoded bit (the caller stores the slot's new state from it).  Never looks at the fill
-// level of the window (the unchecked fast path of dec_sample).
-__device__ __forceinline__ uint32_t dec_rows_mantissa_asm(uint32_t& low, uint32_t& range, unsigned long long& win,
-                                                          unsigned long long cur, uint32_t& wl) {
-    uint32_t nx;
-    asm volatile(
-        "s_mov_b64 s[56:57], exec\n\t"
-        ".p2align 6\n"
-        ".Lm_%=:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_mul_u32_u24_sdwa v50, v48, %[range] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-        "v_lshrrev_b32_e32 v50, 8, v50\n\t"                   // r1
-        "v_sub_u32_e32 v51, %[range], v50\n\t"                // r0
-        "v_sub_co_u32_e32 v52, vcc, %[low], v51\n\t"          // borrow: the bit is 0
-        "s_nop 1\n\t"                                         // (VALU wrote VCC, VALU reads VCC: two wait states on gfx950)
-        "v_cndmask_b32_e32 %[range], v50, v51, vcc\n\t"
-        "v_cndmask_b32_e32 %[low], v52, %[low], vcc\n\t"
-        "v_cndmask_b32_e32 %[nx], v49, v48, vcc\n\t"
-        "v_addc_co_u32_e32 %[wl], vcc, %[wl], %[wl], vcc\n\t"  // 2w + borrow (inverted bits); carry out: this was the last bit
-        "s_mov_b64 s[58:59], vcc\n\t"
-        "v_lshrrev_b32_e32 v53, 16, %[nx]\n\t"
-        "ds_read_b64 v[48:49], v53\n\t"                       // successor's entry
-        "v_cmp_gt_u32_e32 vcc, %[c100], %[range]\n\t"         // refill (llcomp.hpp:115-120)
-        "s_and_saveexec_b64 s[60:61], vcc\n\t"
-        "s_cbranch_execz .Lr_%=\n\t"
-        "v_lshlrev_b32_e32 %[range], 8, %[range]\n\t"
-        "v_perm_b32 %[low], %[low], v46, %[sel]\n\t"          // low << 8 | next byte of the window
-        "v_lshrrev_b64 v[46:47], 8, v[46:47]\n"
-        ".Lr_%=:\n\t"
-        "s_andn2_b64 exec, s[60:61], s[58:59]\n\t"            // everybody back, minus the lanes that are done
-        "s_cbranch_execnz .Lm_%=\n\t"
-        "s_mov_b64 exec, s[56:57]\n\t"
-        : [low] "+v"(low), [range] "+v"(range), [wl] "+v"(wl), [nx] "=&v"(nx), "+{v[46:47]}"(win), "+{v[48:49]}"(cur)
-        : [c100] "s"(0x100u), [sel] "s"(0x06050400u)
-        : "vcc", "scc", "memory", "v50", "v51", "v52", "v53", "v54", "s56", "s57", "s58", "s59", "s60", "s61");
-    return nx;
-}
+#define LD_E0L "v32"
+#define LD_E0H "v33"
+#define LD_E0 "v[32:33]"
+#define LD_E5L "v34"
+#define LD_E5H "v35"
+#define LD_E5 "v[34:35]"
+#define LD_E6L "v36"
+#define LD_E6H "v37"
+#define LD_E6 "v[36:37]"
+#define LD_E7L "v38"
+#define LD_E7H "v39"
+#define LD_E7 "v[38:39]"
+#define LD_E1L "v40"
+#define LD_E1H "v41"
+#define LD_E1 "v[40:41]"
+#define LD_E2L "v42"
+#define LD_E2H "v43"
+#define LD_E2 "v[42:43]"
+#define LD_E3L "v44"
+#define LD_E3H "v45"
+#define LD_E3 "v[44:45]"
+#define LD_E4L "v48"
+#define LD_E4H "v49"
+#define LD_E4 "v[48:49]"
+#define LD_WINL "v46"
+#define LD_WIN "v[46:47]"
+#define LD_PROD "v50"  // range * P
+#define LD_R1 "v51"    // range * P >> 8
+#define LD_DIFF "v52"  // low - r0
+#define LD_OFF "v52"   // LDS address of a successor entry / of a fetched slot (never live together with the difference)
+#define LD_RUN "v40"   // mantissa run: marker + inverted bits   (slots 1..3 are over: their entries' registers are free)
+#define LD_NX "v41"    //               half-entry the last bin chose
+#define LD_T "v42"     // short-lived
+#define LD_SX "s[56:57]"  // exec at entry
+#define LD_SA "s[58:59]"  // lanes with a non-zero residual
+#define LD_SW "s[60:61]"  // exec saved around a refill
+#define LD_SP "s[62:63]"  // exec saved around a bit-1 patch
+#define LD_S5 "s[64:65]"  // lanes that finish the sample (non-zero residual, valid exponent)
+#define LD_SU "s[66:67]"  // lanes of the run on slot 4; later: lanes that decode slot 5 (exponent > 0)
+#define LD_SD "s[68:69]"  // mantissa run: lanes whose last bit has just come in
+#define LD_S1 "s70"
+#define LD_S2 "s71"
 
-// The whole unary exponent (llcomp.hpp:226-235: slots 1, 2, 3 once each, then a run on slot 4) of the lanes in exec (those with
-// a non-zero residual).  The lane sets are nested -- the lanes that decode a 1 on slot k are the lanes that decode slot k + 1 -- so
-// exec only shrinks until the phase is over.  Every lane takes the outcome of a 0 IN PLACE (range = r0, low -= r0: a borrow says
-// the bin is a 0 and the lane drops out; its `low` is put back and its refill done once behind the phase -- hipcc's code keeps the
-// difference apart and selects / copies per bin); the lanes that stay take r1 as the range, count the 1, refill (r1 << 8 is the
-// product with its low byte masked away: no left shift) and go on.  New states go to the wide row bank as they are decided (the
-// low half's first, the lanes that stay overwrite it with the high half's).  e1..e3 / cur: entries of slots 1..3 / 4.
-// out: ex = exponent (ones decoded; the caller rejects > 31), low / range / win as after getSymbol's unary part INCLUDING the
-// refill of the closing 0.  No limit per step: a run fed past the window ends by itself when the window's zeros come.
-#define LLD_REFILL_R1(N)                                         \
-    "v_cmp_gt_u32_e32 vcc, %[c100], v51\n\t"                     \
-    "s_and_saveexec_b64 s[60:61], vcc\n\t"                       \
-    "s_cbranch_execz .Lxr" N "_%=\n\t"                           \
-    "v_and_b32_e32 %[range], 0xffffff00, v50\n\t"                \
-    "v_perm_b32 %[low], %[low], v46, %[sel]\n\t"                 \
-    "v_lshrrev_b64 v[46:47], 8, v[46:47]\n"                      \
-    ".Lxr" N "_%=:\n\t"                                          \
-    "s_mov_b64 exec, s[60:61]\n\t"
-#define LLD_UNARY(EL, EH, OFS, N)                                                                                     \
-    "v_mul_u32_u24_sdwa v50, " EL ", %[range] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t" \
-    "v_lshrrev_b32_e32 v51, 8, v50\n\t"                                                                               \
-    "v_sub_u32_e32 %[range], %[range], v51\n\t"                                                                       \
-    "v_sub_co_u32_e32 %[low], vcc, %[low], %[range]\n\t"                                                              \
-    "ds_write_b16_d16_hi %[bank], " EL " offset:" OFS "\n\t"                                                          \
-    "s_andn2_b64 exec, exec, vcc\n\t"                                                                                 \
-    "s_cbranch_execz .Lx_done_%=\n\t"                                                                                 \
-    "ds_write_b16_d16_hi %[bank], " EH " offset:" OFS "\n\t"                                                          \
-    "v_add_u32_e32 %[ex], 1, %[ex]\n\t"                                                                               \
-    "v_mov_b32_e32 %[range], v51\n\t"                                                                                 \
-    LLD_REFILL_R1(N)
-__device__ __forceinline__ uint32_t dec_rows_exponent_asm(uint32_t& low, uint32_t& range, unsigned long long& win, uint32_t bank,
-                                                          unsigned long long e1, unsigned long long e2, unsigned long long e3,
-                                                          unsigned long long cur) {
-    uint32_t ex;
+// r1 = range * P(entry) >> 8, range = r0 = range - r1: the outcome of a 0, in place
+#define LD_SPLIT(EL)                                                                                                       \
+    "v_mul_u32_u24_sdwa " LD_PROD ", " EL ", %[range] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t" \
+    "v_lshrrev_b32_e32 " LD_R1 ", 8, " LD_PROD "\n\t"                                                                      \
+    "v_sub_u32_e32 %[range], %[range], " LD_R1 "\n\t"
+// refill (llcomp.hpp:115-120) of the lanes in exec
+#define LD_REFILL(N)                                         \
+    "v_cmp_gt_u32_e32 vcc, %[c100], %[range]\n\t"            \
+    "s_and_saveexec_b64 " LD_SW ", vcc\n\t"                  \
+    "s_cbranch_execz .Lrf" N "_%=\n\t"                       \
+    "v_lshlrev_b32_e32 %[range], 8, %[range]\n\t"            \
+    "v_perm_b32 %[low], %[low], " LD_WINL ", %[sel]\n\t"     \
+    "v_lshrrev_b64 " LD_WIN ", 8, " LD_WIN "\n"              \
+    ".Lrf" N "_%=:\n\t"                                      \
+    "s_mov_b64 exec, " LD_SW "\n\t"
+// the same for lanes that have just taken r1 as their range: r1 << 8 = the product without its low byte
+#define LD_REFILL_R1(N)                                           \
+    "v_cmp_gt_u32_e32 vcc, %[c100], " LD_R1 "\n\t"                \
+    "s_and_saveexec_b64 " LD_SW ", vcc\n\t"                       \
+    "s_cbranch_execz .Lrf" N "_%=\n\t"                            \
+    "v_and_b32_e32 %[range], 0xffffff00, " LD_PROD "\n\t"         \
+    "v_perm_b32 %[low], %[low], " LD_WINL ", %[sel]\n\t"          \
+    "v_lshrrev_b64 " LD_WIN ", 8, " LD_WIN "\n"                   \
+    ".Lrf" N "_%=:\n\t"                                           \
+    "s_mov_b64 exec, " LD_SW "\n\t"
+// one bin of the nested unary prefix (slots 1..3): a 1 = the lane stays
+#define LD_UNARY(EL, EH, OFS, N)                                            \
+    LD_SPLIT(EL)                                                            \
+    "v_sub_co_u32_e32 %[low], vcc, %[low], %[range]\n\t"                    \
+    "ds_write_b16_d16_hi %[bank], " EL " offset:" OFS "\n\t"                \
+    "s_andn2_b64 exec, exec, vcc\n\t"                                       \
+    "s_cbranch_execz .Lx_done_%=\n\t"                                       \
+    "ds_write_b16_d16_hi %[bank], " EH " offset:" OFS "\n\t"                \
+    "v_add_u32_e32 %[ex], 1, %[ex]\n\t"                                     \
+    "v_mov_b32_e32 %[range], " LD_R1 "\n\t"                                 \
+    LD_REFILL_R1(N)
+// entries of slots 1..7 from the bank words (addresses by mask / constant right shift)
+#define LD_FETCH_REST                                         \
+    "v_lshrrev_b32_e32 " LD_E1L ", 16, %[w0]\n\t"             \
+    "v_and_b32_e32 " LD_E2L ", 0xffff, %[w1]\n\t"             \
+    "v_lshrrev_b32_e32 " LD_E3L ", 16, %[w1]\n\t"             \
+    "v_and_b32_e32 " LD_E4L ", 0xffff, %[w2]\n\t"             \
+    "ds_read_b64 " LD_E1 ", " LD_E1L "\n\t"                   \
+    "ds_read_b64 " LD_E2 ", " LD_E2L "\n\t"                   \
+    "ds_read_b64 " LD_E3 ", " LD_E3L "\n\t"                   \
+    "ds_read_b64 " LD_E4 ", " LD_E4L "\n\t"                   \
+    "v_lshrrev_b32_e32 " LD_E5L ", 16, %[w2]\n\t"             \
+    "v_and_b32_e32 " LD_E6L ", 0xffff, %[w3]\n\t"             \
+    "v_lshrrev_b32_e32 " LD_E7L ", 16, %[w3]\n\t"             \
+    "ds_read_b64 " LD_E5 ", " LD_E5L "\n\t"                   \
+    "ds_read_b64 " LD_E6 ", " LD_E6L "\n\t"                   \
+    "ds_read_b64 " LD_E7 ", " LD_E7L "\n\t"
+
+// in: exec = the lanes of the wavefront's slices; low / range / win as in RangeDec; w0..w3 = the context's wide row bank (read by
+// the caller, who also needs it to roll back), bank = its LDS address; hot = wave-uniform "most lanes had a non-zero residual
+// last time" (in: entries of slots 1..7 are requested up front; out: the new flag).  out: value = the decoded residual's
+// magnitude with the sign bin applied (0 for a zero residual).  A lane whose exponent exceeds 31 ("Invalid exponent",
+// llcomp.hpp:230-235) stops behind the exponent and leaves with an EMPTY window: the caller replays it on the checked path.
+__device__ __forceinline__ void dec_rows_sample_asm(uint32_t& low, uint32_t& range, unsigned long long& win, uint32_t w0, uint32_t w1,
+                                                    uint32_t w2, uint32_t w3, uint32_t bank, uint32_t& hot, uint32_t& value) {
+    uint32_t ex, w;
     asm volatile(
-        "s_mov_b64 s[56:57], exec\n\t"
+        "s_mov_b64 " LD_SX ", exec\n\t"
+        "v_and_b32_e32 " LD_OFF ", 0xffff, %[w0]\n\t"
+        "ds_read_b64 " LD_E0 ", " LD_OFF "\n\t"
+        "v_mov_b32_e32 %[value], 0\n\t"
+        "s_cmp_lg_u32 %[hot], 0\n\t"
+        "s_cbranch_scc0 .Lcold_%=\n\t"
+        LD_FETCH_REST
+        "s_waitcnt lgkmcnt(7)\n\t"
+        "s_branch .Lzero_%=\n"
+        ".Lcold_%=:\n\t"
+        "s_waitcnt lgkmcnt(0)\n"
+        // ---- slot 0: a 1 = the residual is zero (the lane is done), a 0 (borrow) = it goes on
+        ".Lzero_%=:\n\t"
+        LD_SPLIT(LD_E0L)
+        "v_sub_co_u32_e32 " LD_DIFF ", vcc, %[low], %[range]\n\t"
+        "ds_write_b16_d16_hi %[bank], " LD_E0L "\n\t"
+        "s_and_b64 " LD_SA ", exec, vcc\n\t"
+        "s_andn2_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz .Lz1_%=\n\t"
+        "v_mov_b32_e32 %[low], " LD_DIFF "\n\t"
+        "v_mov_b32_e32 %[range], " LD_R1 "\n\t"
+        "ds_write_b16_d16_hi %[bank], " LD_E0H "\n"
+        ".Lz1_%=:\n\t"
+        "s_mov_b64 exec, " LD_SX "\n\t"
+        LD_REFILL("0")
+        "s_and_b64 exec, " LD_SA ", " LD_SA "\n\t"
+        "s_cbranch_execz .Ldone_%=\n\t"
+        "s_cmp_lg_u32 %[hot], 0\n\t"
+        "s_cbranch_scc1 .Lhave_%=\n\t"
+        LD_FETCH_REST
+        ".Lhave_%=:\n\t"
         "v_mov_b32_e32 %[ex], 0\n\t"
-        LLD_UNARY("v40", "v41", "2", "1")
-        LLD_UNARY("v42", "v43", "256", "2")
-        LLD_UNARY("v44", "v45", "258", "3")
-        "s_mov_b64 s[58:59], exec\n\t"  // the lanes of the run on slot 4
+        "v_mov_b32_e32 %[w], 1\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        // ---- unary exponent: slots 1, 2, 3 once each, then a run on slot 4
+        LD_UNARY(LD_E1L, LD_E1H, "2", "1")
+        LD_UNARY(LD_E2L, LD_E2H, "256", "2")
+        LD_UNARY(LD_E3L, LD_E3H, "258", "3")
+        "s_mov_b64 " LD_SU ", exec\n\t"
         ".p2align 6\n"
         ".Lu_%=:\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        "v_mul_u32_u24_sdwa v50, v48, %[range] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-        "v_lshrrev_b32_e32 v51, 8, v50\n\t"            // r1
-        "v_sub_u32_e32 %[range], %[range], v51\n\t"    // r0
+        LD_SPLIT(LD_E4L)
         "v_sub_co_u32_e32 %[low], vcc, %[low], %[range]\n\t"
         "s_andn2_b64 exec, exec, vcc\n\t"
         "s_cbranch_execz .Lu_done_%=\n\t"
-        "v_lshrrev_b32_e32 v53, 16, v49\n\t"
-        "ds_read_b64 v[48:49], v53\n\t"
+        "v_lshrrev_b32_e32 " LD_OFF ", 16, " LD_E4H "\n\t"
+        "ds_read_b64 " LD_E4 ", " LD_OFF "\n\t"
         "v_add_u32_e32 %[ex], 1, %[ex]\n\t"
-        "v_mov_b32_e32 %[range], v51\n\t"
-        LLD_REFILL_R1("4")
+        "v_mov_b32_e32 %[range], " LD_R1 "\n\t"
+        LD_REFILL_R1("4")
         "s_branch .Lu_%=\n"
         ".Lu_done_%=:\n\t"
-        "s_mov_b64 exec, s[58:59]\n\t"
-        "ds_write_b16_d16_hi %[bank], v48 offset:512\n"  // slot 4: the closing 0's successor
+        "s_mov_b64 exec, " LD_SU "\n\t"
+        "ds_write_b16_d16_hi %[bank], " LD_E4L " offset:512\n"  // slot 4: the closing 0's successor
         ".Lx_done_%=:\n\t"
-        "s_mov_b64 exec, s[56:57]\n\t"
-        "v_add_u32_e32 %[low], %[low], %[range]\n\t"     // every lane left by a borrow, with low - r0: put r0 back ...
-        "v_cmp_gt_u32_e32 vcc, %[c100], %[range]\n\t"    // ... and refill behind the closing 0
-        "s_and_saveexec_b64 s[60:61], vcc\n\t"
-        "s_cbranch_execz .Lxr5_%=\n\t"
+        "s_mov_b64 exec, " LD_SA "\n\t"
+        "v_add_u32_e32 %[low], %[low], %[range]\n\t"  // every lane left by a borrow, with low - r0: put r0 back ...
+        LD_REFILL("5")                                // ... and refill behind the closing 0
+        // ---- exponent > 31: "Invalid exponent" -- the lane stops here (rare; the caller replays it)
+        "v_cmp_lt_u32_e32 vcc, 31, %[ex]\n\t"
+        "s_cbranch_vccz .Lexok_%=\n\t"
+        "s_and_saveexec_b64 " LD_SP ", vcc\n\t"
+        "v_mov_b32_e32 " LD_WINL ", 0\n\t"  // an empty window (not even the sentinel) is what makes the caller replay a sample
+        "v_mov_b32_e32 v47, 0\n\t"
+        "s_andn2_b64 exec, " LD_SP ", exec\n\t"
+        "s_cbranch_execz .Ldone_%=\n"
+        ".Lexok_%=:\n\t"
+        "s_mov_b64 " LD_S5 ", exec\n\t"  // (the lanes that finish the sample: value and sign below)
+        // ---- slot 5: the mantissa bit below the leading one (exponent > 0); w = 2 + inverted bit
+        "v_cmp_lt_u32_e32 vcc, 0, %[ex]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz .Lvalue_%=\n\t"
+        "s_mov_b64 " LD_SU ", exec\n\t"
+        LD_SPLIT(LD_E5L)
+        "v_sub_co_u32_e32 " LD_DIFF ", vcc, %[low], %[range]\n\t"
+        "ds_write_b16_d16_hi %[bank], " LD_E5L " offset:514\n\t"
+        "s_andn2_b64 " LD_SP ", exec, vcc\n\t"                 // the lanes that decoded a 1
+        "v_addc_co_u32_e32 %[w], vcc, %[w], %[w], vcc\n\t"    // 1 + 1 + borrow
+        "v_mov_b32_e32 " LD_RUN ", 0\n\t"
+        "s_and_b64 exec, " LD_SP ", " LD_SP "\n\t"
+        "s_cbranch_execz .Lp5_%=\n\t"
+        "v_mov_b32_e32 %[low], " LD_DIFF "\n\t"
+        "v_mov_b32_e32 %[range], " LD_R1 "\n\t"
+        "ds_write_b16_d16_hi %[bank], " LD_E5H " offset:514\n"
+        ".Lp5_%=:\n\t"
+        "s_mov_b64 exec, " LD_SU "\n\t"
+        LD_REFILL("6")
+        // ---- the rest of the mantissa as a run on slot 6 (exponent > 1): bits gathered under a marker that leaves as a carry
+        "v_add_u32_e32 " LD_T ", -1, %[ex]\n\t"  // m = bins of the run
+        "v_cmp_lt_u32_e32 vcc, 1, %[ex]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz .Lm_skip_%=\n\t"
+        "s_mov_b64 " LD_SP ", exec\n\t"
+        "v_add_u32_e32 " LD_NX ", -2, %[ex]\n\t"
+        "v_lshrrev_b32_e32 " LD_RUN ", " LD_NX ", %[sentv]\n\t"  // marker at bit 32 - m
+        ".p2align 6\n"
+        ".Lm_%=:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        LD_SPLIT(LD_E6L)
+        "v_sub_co_u32_e32 " LD_DIFF ", vcc, %[low], %[range]\n\t"
+        "s_nop 1\n\t"  // (VALU wrote VCC, VALU reads VCC: two wait states on gfx950)
+        "v_cndmask_b32_e32 %[range], " LD_R1 ", %[range], vcc\n\t"
+        "v_cndmask_b32_e32 %[low], " LD_DIFF ", %[low], vcc\n\t"
+        "v_cndmask_b32_e32 " LD_NX ", " LD_E6H ", " LD_E6L ", vcc\n\t"
+        "v_addc_co_u32_e32 " LD_RUN ", vcc, " LD_RUN ", " LD_RUN ", vcc\n\t"  // 2 run + borrow (inverted bits); carry out: this was the last bit
+        "s_mov_b64 " LD_SD ", vcc\n\t"
+        "v_lshrrev_b32_e32 " LD_OFF ", 16, " LD_NX "\n\t"
+        "ds_read_b64 " LD_E6 ", " LD_OFF "\n\t"
+        "v_cmp_gt_u32_e32 vcc, %[c100], %[range]\n\t"
+        "s_and_saveexec_b64 " LD_SW ", vcc\n\t"
+        "s_cbranch_execz .Lmr_%=\n\t"
         "v_lshlrev_b32_e32 %[range], 8, %[range]\n\t"
-        "v_perm_b32 %[low], %[low], v46, %[sel]\n\t"
-        "v_lshrrev_b64 v[46:47], 8, v[46:47]\n"
-        ".Lxr5_%=:\n\t"
-        "s_mov_b64 exec, s[60:61]\n\t"
-        : [low] "+v"(low), [range] "+v"(range), [ex] "=&v"(ex), "+{v[46:47]}"(win), "+{v[48:49]}"(cur)
-        : [c100] "s"(0x100u), [sel] "s"(0x06050400u), [bank] "v"(bank), "{v[40:41]}"(e1), "{v[42:43]}"(e2), "{v[44:45]}"(e3)
-        : "vcc", "scc", "memory", "v50", "v51", "v52", "v53", "v54", "s56", "s57", "s58", "s59", "s60", "s61");
-    return ex;
+        "v_perm_b32 %[low], %[low], " LD_WINL ", %[sel]\n\t"
+        "v_lshrrev_b64 " LD_WIN ", 8, " LD_WIN "\n"
+        ".Lmr_%=:\n\t"
+        "s_andn2_b64 exec, " LD_SW ", " LD_SD "\n\t"  // everybody back, minus the lanes that are done
+        "s_cbranch_execnz .Lm_%=\n\t"
+        "s_mov_b64 exec, " LD_SP "\n\t"
+        "ds_write_b16_d16_hi %[bank], " LD_NX " offset:768\n"  // slot 6: the successor the last bin chose
+        ".Lm_skip_%=:\n\t"
+        "s_mov_b64 exec, " LD_SU "\n\t"
+        "v_lshlrev_b32_e32 %[w], " LD_T ", %[w]\n\t"  // what was gathered before the run moves up to make room for it
+        "v_or_b32_e32 %[w], %[w], " LD_RUN "\n"
+        // ---- the value: w with the bits below its leading one inverted back (w == 1 for exponent 0)
+        ".Lvalue_%=:\n\t"
+        "s_mov_b64 exec, " LD_S5 "\n\t"
+        "v_lshlrev_b32_e64 " LD_T ", %[ex], 1\n\t"
+        "v_add_u32_e32 " LD_T ", -1, " LD_T "\n\t"
+        "v_xor_b32_e32 %[value], %[w], " LD_T "\n\t"
+        // ---- slot 7: the sign (a 1 = negative)
+        LD_SPLIT(LD_E7L)
+        "v_sub_co_u32_e32 " LD_DIFF ", vcc, %[low], %[range]\n\t"
+        "ds_write_b16_d16_hi %[bank], " LD_E7L " offset:770\n\t"
+        "s_andn2_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz .Lp7_%=\n\t"
+        "v_mov_b32_e32 %[low], " LD_DIFF "\n\t"
+        "v_mov_b32_e32 %[range], " LD_R1 "\n\t"
+        "ds_write_b16_d16_hi %[bank], " LD_E7H " offset:770\n\t"
+        "v_sub_u32_e32 %[value], 0, %[value]\n"
+        ".Lp7_%=:\n\t"
+        "s_mov_b64 exec, " LD_S5 "\n\t"
+        LD_REFILL("7")
+        ".Ldone_%=:\n\t"
+        "s_bcnt1_i32_b64 " LD_S1 ", " LD_SA "\n\t"
+        "s_bcnt1_i32_b64 " LD_S2 ", " LD_SX "\n\t"
+        "s_lshl_b32 " LD_S1 ", " LD_S1 ", 1\n\t"
+        "s_cmp_ge_u32 " LD_S1 ", " LD_S2 "\n\t"
+        "s_cselect_b32 %[hot], 1, 0\n\t"
+        "s_mov_b64 exec, " LD_SX "\n\t"
+        : [low] "+v"(low), [range] "+v"(range), "+{v[46:47]}"(win), [hot] "+s"(hot), [value] "=&v"(value),
+          [ex] "=&v"(ex), [w] "=&v"(w)
+        : [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [bank] "v"(bank), [c100] "s"(0x100u), [sel] "s"(0x06050400u),
+          [sentv] "v"(0x80000000u)
+        : "vcc", "scc", "memory", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45",
+          "v48", "v49", "v50", "v51", "v52", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66",
+          "s67", "s68", "s69", "s70", "s71");
 }
 
 }  // namespace llcomp_mi

@@ -827,12 +827,6 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entr
     if (!ALL) dec_fetch_rest<INLDS>(E, bank, tab);
     int ex = 0;
     bool ok = true;
-#if LLMI_ASM_DEC
-    if constexpr (INLDS && !CHECKED) {  // slots 1..4 as one hand-written block (dec_rows_asm.hpp)
-        ex = int(dec_rows_exponent_asm(d.low, d.range, d.win, lds_address(bank.lds), E.e1, E.e2, E.e3, E.e4));
-        if (ex > 31) ok = false;  // "Invalid exponent" (llcomp.hpp:230-235), confirmed by the checked replay
-    } else
-#endif
     if (dec_once<1, CHECKED, INLDS>(d, bank, E)) {
         ex = 1;
         if (dec_once<2, CHECKED, INLDS>(d, bank, E)) {
@@ -876,21 +870,6 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entr
     const uint32_t ones = (1u << ex) - 1;
     if (ex > 0) {
         w += w + uint32_t(!dec_once<5, CHECKED, INLDS>(d, bank, E));
-#if LLMI_ASM_DEC
-        if constexpr (INLDS && !CHECKED) {
-            // The loop gathers the ex - 1 bits at the bottom of `run`, under a marker bit that starts at bit 33 - ex: the
-            // add-with-carry that takes a bit in pushes the marker out as its carry when the last one has come
-            // (dec_rows_asm.hpp); what was gathered before the loop moves up by ex - 1 to make room.
-            const uint32_t m = uint32_t(ex) - 1u;
-            uint32_t run = 0;
-            if (ex > 1) {
-                run = 0x80000000u >> (m - 1u);
-                const uint32_t nx = dec_rows_mantissa_asm(d.low, d.range, d.win, E.e6, run);
-                dec_put_state<6, INLDS>(bank, nx);
-            }
-            w = (w << m) | run;
-        } else
-#endif
         if (ex > 1) {
             entry_t cur = E.e6;
             uint32_t nx;
@@ -912,12 +891,23 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entr
 }
 
 // One sample: fast path first, checked replay when the window ran dry (or the fast path saw nonsense because of it).
+// `hot` (wave-uniform, in / out): most lanes had a non-zero residual last time -- the entries of slots 1..7 are requested up front.
 template <bool INLDS>
-__device__ __forceinline__ bool dec_sample(RangeDec& d, Bank& bank, const entry_t* tab, bool hot, bool replay_always,
+__device__ __forceinline__ bool dec_sample(RangeDec& d, Bank& bank, const entry_t* tab, uint32_t& hot, bool replay_always,
                                            uint32_t& v) {
     const uint32_t s_low = d.low, s_range = d.range, s_b0 = bank.w[0], s_b1 = bank.w[1], s_b2 = bank.w[2], s_b3 = bank.w[3];
     const unsigned long long s_win = d.win;
-    bool ok = hot ? dec_residual<true, false, INLDS>(d, bank, tab, v) : dec_residual<false, false, INLDS>(d, bank, tab, v);
+    bool ok;
+#if LLMI_ASM_DEC
+    if constexpr (INLDS) {  // the fast path of the 1-row-slice kernels is one hand-written block (dec_rows_asm.hpp)
+        dec_rows_sample_asm(d.low, d.range, d.win, bank.w[0], bank.w[1], bank.w[2], bank.w[3], lds_address(bank.lds), hot, v);
+        ok = true;  // (an invalid exponent leaves with an empty window: replayed below, where the verdict is formed)
+    } else
+#endif
+    {
+        ok = hot ? dec_residual<true, false, INLDS>(d, bank, tab, v) : dec_residual<false, false, INLDS>(d, bank, tab, v);
+        hot = 2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true));  // (ballots are wave-uniform: scalar arithmetic)
+    }
     if (__builtin_expect(!ok || d.win == 0 || replay_always, 0)) {
         d.low = s_low; d.range = s_range; d.win = s_win;
         bank.w[0] = s_b0; bank.w[1] = s_b1;
@@ -963,7 +953,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
     const ptrdiff_t GW = ptrdiff_t(1) << g.lane_shift;  // distance between consecutive samples of this slice
     // the same through a wave-uniform base + 32-bit element offset (one store instruction, no 64-bit address math)
     int16_t* const gbase = rec + ((size_t(grp) * g.slice_samples) << g.lane_shift);
-    bool hot = false;
+    uint32_t hot = 0;  // wave-uniform: most lanes had a non-zero residual last time (dec_sample)
     LLMI_PROBE_START();
 
     if constexpr (ROWS) {
@@ -1009,7 +999,6 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 Bank bank{{bp[0], bp[64], bp[128], bp[192]}, reinterpret_cast<uint8_t*>(bp)};
                 uint32_t v = 0;
                 if (!dec_sample<true>(d, bank, tab, hot, replay_always, v)) bad = true;
-                hot = 2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true));  // (ballots are wave-uniform: scalar arithmetic)
                 v = (v ^ uint32_t(sg)) - uint32_t(sg);
                 const int val = int(int16_t(uint32_t(lv) + v));
                 held_val = val;
@@ -1062,8 +1051,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                             atomicOr(status, kStBadExponent);
                             return;
                         }
-                        hot = 2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true));  // (ballots are wave-uniform: scalar arithmetic)
-                        banks[size_t(ctx) << bsh] = bank_tagged<LDSTAB>(uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32), gpat);
+                                banks[size_t(ctx) << bsh] = bank_tagged<LDSTAB>(uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32), gpat);
                         if (neg) v = 0u - v;
                         *q = int16_t(uint32_t(predict(n)) + v);
                     }
@@ -1111,8 +1099,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                         atomicOr(status, kStBadExponent);
                         return;  // this lane's slice is unusable; the whole call reports the error
                     }
-                    hot = 2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true));  // (ballots are wave-uniform: scalar arithmetic)
-                    held_bank = uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32);
+                        held_bank = uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32);
                     banks[size_t(ctx) << bsh] = bank_tagged<LDSTAB>(held_bank, gpat);
                     if (neg) v = 0u - v;
                     const int val = int(int16_t(uint32_t(predict(n)) + v));
