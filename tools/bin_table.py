@@ -94,9 +94,9 @@ def show(title, bl, idxs, skip_deeper=True):
     print("   => " + "  ".join(f"{k}: {v}" for k, v in sorted(tot.items())))
 
 
-def asm_loops(lines):
-    """the loops of the hand-written encoder block: .Ltail_N / .Lman_N up to the branch back to the label"""
-    for name, kind in ((".Ltail_", "unary tail: one iteration = one bin on slot 4"), (".Lman_", "mantissa tail: one iteration = one bin on slot 6")):
+def asm_loops(lines, names):
+    """the loops of a hand-written block: from its label up to the branch back to the label"""
+    for name, kind in names:
         for i, l in enumerate(lines):
             m = re.match(r"^\s*(" + re.escape(name) + r"\d+):", l)
             if not m:
@@ -104,23 +104,23 @@ def asm_loops(lines):
             body = []
             for t in lines[i + 1:]:
                 t = t.split(";")[0].strip()
-                if not t or t.endswith(":") and not t.startswith(".Lback") and not t.startswith(".Lskip") and not t.startswith(".Lpatch"):
-                    if t.endswith(":"):
-                        break
+                if not t or t.startswith(".p2align"):
                     continue
                 if t.endswith(":"):
-                    continue
-                body.append(t)
-                if t == "s_branch " + m.group(1):
+                    if re.match(r"^\.L(back|skip|patch|rf|mr|xr)", t):
+                        continue
                     break
-            print(f"\n-- hand-written loop {m.group(1)}  ({kind}; the carry subroutine, called once in ~1000 renormalisations, is out of line)")
+                body.append(t)
+                if re.match(r"^s_(branch|cbranch_\w+) " + re.escape(m.group(1)) + r"$", t):
+                    break
+            print(f"\n-- hand-written loop {m.group(1)}  ({kind}; rare paths are out of line)")
             tot = {}
             for t in body:
                 k = klass(t)
                 tot[k] = tot.get(k, 0) + 1
                 print(f"   {k:2s}  {t}")
             print("   => " + "  ".join(f"{k}: {v}" for k, v in sorted(tot.items())))
-            break  # (the block is instantiated twice, bulk loop and tail loop: identical text)
+            break  # (the block is instantiated more than once: identical text)
 
 
 def main():
@@ -138,7 +138,12 @@ def main():
                 n_all[k] = n_all.get(k, 0) + 1
         print("static instruction count of the whole kernel: " + "  ".join(f"{k}: {v}" for k, v in sorted(n_all.items())))
         if "k_encode" in key:
-            asm_loops(kernel_lines(text, key))
+            asm_loops(kernel_lines(text, key), ((".Ltail_", "encoder unary tail: one iteration = one bin on slot 4"),
+                                                (".Lman_", "encoder mantissa tail: one iteration = one bin on slot 6")))
+        else:
+            asm_loops(kernel_lines(text, key), ((".Lu_", "decoder unary tail: one iteration = one bin on slot 4"),
+                                                (".Lm_", "decoder mantissa tail: one iteration = one bin on slot 6")))
+            print("\n(the compiler's loops below belong to the CHECKED replay path, entered for well under 1 % of the samples)")
         for lab, body in ls:
             # the rare carry-propagation loops of the encoder live at depth 3 below these; classify by content
             ops = " ".join(t for j in body for t in bl[j][2])
