@@ -8,14 +8,19 @@
 //     from a 64-bit register window inside one exec-masked region and tops the window up once per sample, the
 //     encoder renormalises in 6 instructions with eager carry propagation, its output bytes go to a per-lane LDS
 //     staging area that is filled linearly and flushed 16 bytes at a time;
-//   * the model table lives in LDS as 8-byte entries {next0, P, 8*next0 | next1, P, 8*next1}: the 8 entries of a
-//     context are requested together when the context is known; a run of bins on one slot walks from entry to entry
-//     through the pre-scaled offsets (one shift by a constant per bin), and the encoder (whose bins are known in
-//     advance) requests a successor before it codes the bin that leads there;
+//   * the model table lives in LDS as 8-byte entries {next0, P, address of next0's entry | next1, P, address of next1's
+//     entry} (absolute LDS addresses, added while the table is copied in): the 8 entries of a context are requested
+//     together when the context is known; a run of bins on one slot walks from entry to entry with one right shift by a
+//     constant per bin and no base to add, and the encoder (whose bins are known in advance) requests a successor before
+//     it codes the bin that leads there;
 //   * 1-row slices (tile_h == 1) can only ever reach 3 contexts (llcomp.hpp:417-429 with h == 0: hash =
 //     605*quant5(L-l)), so their 24 state bytes stay in LDS and the kernel touches no state memory in HBM at all;
 //     taller slices keep a private 63 KB table (u64 per context) in HBM, fetched one context per sample -- or in
-//     LDS when a wavefront carries a single slice (LDSTAB).
+//     LDS when a wavefront carries a single slice (LDSTAB);
+//   * for the 1-row-slice kernels (the headline path) the per-sample coding is hand-written gfx950 assembly
+//     (enc_rows_asm.hpp, dec_rows_asm.hpp: nested lane sets, outcomes taken in place, carry-out loop exits); the C++
+//     below states the same algorithm, serves every other kernel family and the decoder's checked replay, and is what
+//     the blocks are A/B-tested against (LLMI_ASM_ENC / LLMI_ASM_DEC = 0).
 #include <algorithm>
 
 #include "device_common.hpp"
@@ -28,7 +33,7 @@
 #if LLMI_ASM_ENC
 #include "enc_rows_asm.hpp"
 #endif
-// The decoder's mantissa run of the 1-row-slice kernels as a hand-written loop (dec_rows_asm.hpp); 0 = hipcc's loop.
+// The decoder's fast path of a sample of the 1-row-slice kernels as one hand-written block (dec_rows_asm.hpp); 0 = hipcc's code.
 #ifndef LLMI_ASM_DEC
 #define LLMI_ASM_DEC 1
 #endif
