@@ -66,6 +66,8 @@ namespace llcomp_mi {
 #define LD_S5 "s[64:65]"  // lanes that finish the sample (non-zero residual, valid exponent)
 #define LD_SU "s[66:67]"  // lanes of the run on slot 4; later: lanes that decode slot 5 (exponent > 0)
 #define LD_SD "s[68:69]"  // mantissa run: lanes whose last bit has just come in
+#define LD_S1L "s[68:69]"  // lanes with an exponent > 0 (the lanes that stayed behind slot 1); shares LD_SD: read before the run
+#define LD_SM "s[70:71]"   // lanes with an exponent > 1; shares LD_S1 / LD_S2: read before the end
 #define LD_S1 "s70"
 #define LD_S2 "s71"
 
@@ -95,11 +97,12 @@ namespace llcomp_mi {
     ".Lrf" N "_%=:\n\t"                                           \
     "s_mov_b64 exec, " LD_SW "\n\t"
 // one bin of the nested unary prefix (slots 1..3): a 1 = the lane stays
-#define LD_UNARY(EL, EH, OFS, N)                                            \
+#define LD_UNARY(EL, EH, OFS, N, SAVE)                                      \
     LD_SPLIT(EL)                                                            \
     "v_sub_co_u32_e32 %[low], vcc, %[low], %[range]\n\t"                    \
     "ds_write_b16_d16_hi %[bank], " EL " offset:" OFS "\n\t"                \
     "s_andn2_b64 exec, exec, vcc\n\t"                                       \
+    SAVE                                                                    \
     "s_cbranch_execz .Lx_done_%=\n\t"                                       \
     "ds_write_b16_d16_hi %[bank], " EH " offset:" OFS "\n\t"                \
     "v_add_u32_e32 %[ex], 1, %[ex]\n\t"                                     \
@@ -166,9 +169,11 @@ __device__ __forceinline__ void dec_rows_sample_asm(uint32_t& low, uint32_t& ran
         "v_mov_b32_e32 %[w], 1\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         // ---- unary exponent: slots 1, 2, 3 once each, then a run on slot 4
-        LD_UNARY(LD_E1L, LD_E1H, "2", "1")
-        LD_UNARY(LD_E2L, LD_E2H, "256", "2")
-        LD_UNARY(LD_E3L, LD_E3H, "258", "3")
+        // (the lanes that stay behind slots 1 and 2 are the lanes of slot 5 and of the mantissa run: kept, not compared for again)
+        "s_mov_b64 " LD_SM ", 0\n\t"
+        LD_UNARY(LD_E1L, LD_E1H, "2", "1", "s_mov_b64 " LD_S1L ", exec\n\t")
+        LD_UNARY(LD_E2L, LD_E2H, "256", "2", "s_mov_b64 " LD_SM ", exec\n\t")
+        LD_UNARY(LD_E3L, LD_E3H, "258", "3", "")
         "s_mov_b64 " LD_SU ", exec\n\t"
         ".p2align 6\n"
         ".Lu_%=:\n\t"
@@ -201,8 +206,7 @@ __device__ __forceinline__ void dec_rows_sample_asm(uint32_t& low, uint32_t& ran
         ".Lexok_%=:\n\t"
         "s_mov_b64 " LD_S5 ", exec\n\t"  // (the lanes that finish the sample: value and sign below)
         // ---- slot 5: the mantissa bit below the leading one (exponent > 0); w = 2 + inverted bit
-        "v_cmp_lt_u32_e32 vcc, 0, %[ex]\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"
+        "s_and_b64 exec, exec, " LD_S1L "\n\t"  // exponent > 0
         "s_cbranch_execz .Lvalue_%=\n\t"
         "s_mov_b64 " LD_SU ", exec\n\t"
         LD_SPLIT(LD_E5L)
@@ -221,8 +225,7 @@ __device__ __forceinline__ void dec_rows_sample_asm(uint32_t& low, uint32_t& ran
         LD_REFILL("6")
         // ---- the rest of the mantissa as a run on slot 6 (exponent > 1): bits gathered under a marker that leaves as a carry
         "v_add_u32_e32 " LD_T ", -1, %[ex]\n\t"  // m = bins of the run
-        "v_cmp_lt_u32_e32 vcc, 1, %[ex]\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"
+        "s_and_b64 exec, exec, " LD_SM "\n\t"  // exponent > 1
         "s_cbranch_execz .Lm_skip_%=\n\t"
         "s_mov_b64 " LD_SP ", exec\n\t"
         "v_add_u32_e32 " LD_NX ", -2, %[ex]\n\t"

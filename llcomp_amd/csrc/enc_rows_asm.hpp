@@ -70,6 +70,7 @@ namespace llcomp_mi {
 #define LL_SW "s[42:43]"  // exec saved around a renormalisation
 #define LL_SB "s[44:45]"  // lanes that code slot 5 (ex > 0)
 #define LL_SU "s[46:47]"  // lanes that entered the unary tail (ex > 2)
+#define LL_SM "s[56:57]"  // lanes with a mantissa run (ex > 1)
 #define LL_SC "s[40:41]"  // carry subroutine (no patch is open during a renormalisation)
 #define LL_SD "s[48:49]"
 #define LL_SE "s[50:51]"
@@ -131,11 +132,12 @@ namespace llcomp_mi {
     "s_branch .Lcarry_%=\n\t"               \
     "s_branch .Lback" N "_%=\n"
 // one bin of the nested unary prefix on slot K (1..3): the lanes in exec code "ex > K-1"; those with a 1 stay
-#define LL_UNARY(K, KM1, EL, EH, N)                        \
+#define LL_UNARY(K, KM1, EL, EH, N, SAVE)                  \
     LL_SPLIT(EL)                                           \
     "ds_write_b8 %[bank], " EL " offset:" K "\n\t"         \
     "v_cmp_lt_u32_e32 vcc, " KM1 ", " LL_EX "\n\t"         \
     "s_and_b64 exec, exec, vcc\n\t"                        \
+    SAVE                                                   \
     "s_cbranch_execz .Lunary_done_%=\n\t"                  \
     LL_ONE                                                 \
     "ds_write_b8 %[bank], " EH " offset:" K "\n\t"         \
@@ -187,16 +189,17 @@ __device__ __forceinline__ void enc_rows_sample_asm(unsigned long long& low_rang
         LL_SPLIT(LL_E0L)
         "ds_write_b8 %[bank], " LL_E0L "\n\t"
         "v_cmp_eq_u32_e32 vcc, 0, %[res]\n\t"
+        "s_andn2_b64 " LL_SA ", exec, vcc\n\t"  // the lanes with a non-zero residual
         "s_and_saveexec_b64 " LL_ST ", vcc\n\t"
         LL_PATCH_SKIP("0")
         LL_ONE
         "ds_write_b8 %[bank], " LL_E0H "\n"
         LL_PATCH_END("0")
         LL_RENORM("0")
-        "v_cmp_ne_u32_e32 vcc, 0, %[res]\n\t"
-        "s_and_b64 " LL_SA ", exec, vcc\n\t"
-        "s_cbranch_scc0 .Ldone_%=\n\t"
-        "s_mov_b64 exec, " LL_SA "\n\t"
+        "s_and_b64 exec, " LL_SA ", " LL_SA "\n\t"
+        "s_cbranch_execz .Ldone_%=\n\t"
+        "s_mov_b64 " LL_SB ", 0\n\t"  // (slot 1 may not be reached by anybody: nobody codes slot 5 then)
+        "s_mov_b64 " LL_SM ", 0\n\t"
         "s_cmp_lg_u32 %[hot], 0\n\t"
         "s_cbranch_scc1 .Lhave_%=\n\t"
         LL_FETCH_REST
@@ -207,9 +210,10 @@ __device__ __forceinline__ void enc_rows_sample_asm(unsigned long long& low_rang
         "v_sub_u32_e32 " LL_EX ", 31, " LL_EX "\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         // ---- unary exponent: slots 1, 2, 3 once each, then a run on slot 4; exec only shrinks until .Lunary_done
-        LL_UNARY("1", "0", LL_E1L, LL_E1H, "1")
-        LL_UNARY("2", "1", LL_E2L, LL_E2H, "2")
-        LL_UNARY("3", "2", LL_E3L, LL_E3H, "3")
+        // (the lane sets of slots 2 and 3 are the lane sets of slot 5 and of the mantissa run: kept, not compared for again)
+        LL_UNARY("1", "0", LL_E1L, LL_E1H, "1", "s_mov_b64 " LL_SB ", exec\n\t")
+        LL_UNARY("2", "1", LL_E2L, LL_E2H, "2", "s_mov_b64 " LL_SM ", exec\n\t")
+        LL_UNARY("3", "2", LL_E3L, LL_E3H, "3", "")
         "s_mov_b64 " LL_SU ", exec\n\t"
         "v_add_u32_e32 " LL_N ", -3, " LL_EX "\n\t"
         "s_mov_b32 " LL_SI ", 0\n\t"
@@ -233,10 +237,8 @@ __device__ __forceinline__ void enc_rows_sample_asm(unsigned long long& low_rang
         "s_mov_b64 exec, " LL_SA "\n\t"
         LL_RENORM("5")  // of the lanes whose last unary bin was the closing zero
         // ---- slot 5: the mantissa bit below the leading one, then the rest of the mantissa as a run on slot 6
-        "v_cmp_lt_u32_e32 vcc, 0, " LL_EX "\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"
+        "s_and_b64 exec, " LL_SB ", " LL_SB "\n\t"  // the lanes with an exponent > 0
         "s_cbranch_execz .Lsign_%=\n\t"
-        "s_mov_b64 " LL_SB ", exec\n\t"
         LL_SPLIT(LL_E5L)
         "ds_write_b8 %[bank], " LL_E5L " offset:257\n\t"
         "v_lshl_or_b32 " LL_BITS ", " LL_A ", 1, 1\n\t"
@@ -302,9 +304,7 @@ __device__ __forceinline__ void enc_rows_sample_asm(unsigned long long& low_rang
         "s_setpc_b64 " LL_SR "\n"
         // ---- back in line
         ".Lman_done_%=:\n\t"
-        "s_mov_b64 exec, " LL_SB "\n\t"
-        "v_cmp_lt_u32_e32 vcc, 1, " LL_EX "\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"
+        "s_mov_b64 exec, " LL_SM "\n\t"  // the lanes with an exponent > 1: those that ran
         "v_lshrrev_b32_e32 " LL_T ", 3, " LL_OFF "\n\t"
         "ds_write_b8 %[bank], " LL_T " offset:258\n"
         // ---- slot 7: the sign
@@ -331,7 +331,7 @@ __device__ __forceinline__ void enc_rows_sample_asm(unsigned long long& low_rang
           [sent] "s"(0x80000000u), [c3] "v"(3u)
         : "vcc", "scc", "memory", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44",
           "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43",
-          "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54");
+          "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s56", "s57");
 }
 
 }  // namespace llcomp_mi
