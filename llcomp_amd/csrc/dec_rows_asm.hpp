@@ -56,6 +56,8 @@ namespace llcomp_mi {
 #define LD_R1 "v51"    // range * P >> 8
 #define LD_DIFF "v52"  // low - r0
 #define LD_OFF "v52"   // LDS address of a successor entry / of a fetched slot (never live together with the difference)
+#define LD_EX "v32"    // exponent                         (slot 0 is over: its entry's registers are free)
+#define LD_W "v33"     // mantissa bits gathered so far, inverted, under their leading one
 #define LD_RUN "v40"   // mantissa run: marker + inverted bits   (slots 1..3 are over: their entries' registers are free)
 #define LD_NX "v41"    //               half-entry the last bin chose
 #define LD_T "v42"     // short-lived
@@ -82,8 +84,8 @@ namespace llcomp_mi {
     "s_and_saveexec_b64 " LD_SW ", vcc\n\t"                  \
     "s_cbranch_execz .Lrf" N "_%=\n\t"                       \
     "v_lshlrev_b32_e32 %[range], 8, %[range]\n\t"            \
-    "v_perm_b32 %[low], %[low], " LD_WINL ", %[sel]\n\t"     \
-    "v_lshrrev_b64 " LD_WIN ", 8, " LD_WIN "\n"              \
+    "v_perm_b32 %[low], %[low], %[w32], %[sel]\n\t"          \
+    "v_lshrrev_b32_e32 %[w32], 8, %[w32]\n"                   \
     ".Lrf" N "_%=:\n\t"                                      \
     "s_mov_b64 exec, " LD_SW "\n\t"
 // the same for lanes that have just taken r1 as their range: r1 << 8 = the product without its low byte
@@ -92,8 +94,8 @@ namespace llcomp_mi {
     "s_and_saveexec_b64 " LD_SW ", vcc\n\t"                       \
     "s_cbranch_execz .Lrf" N "_%=\n\t"                            \
     "v_and_b32_e32 %[range], 0xffffff00, " LD_PROD "\n\t"         \
-    "v_perm_b32 %[low], %[low], " LD_WINL ", %[sel]\n\t"          \
-    "v_lshrrev_b64 " LD_WIN ", 8, " LD_WIN "\n"                   \
+    "v_perm_b32 %[low], %[low], %[w32], %[sel]\n\t"               \
+    "v_lshrrev_b32_e32 %[w32], 8, %[w32]\n"                        \
     ".Lrf" N "_%=:\n\t"                                           \
     "s_mov_b64 exec, " LD_SW "\n\t"
 // one bin of the nested unary prefix (slots 1..3): a 1 = the lane stays
@@ -105,7 +107,7 @@ namespace llcomp_mi {
     SAVE                                                                    \
     "s_cbranch_execz .Lx_done_%=\n\t"                                       \
     "ds_write_b16_d16_hi %[bank], " EH " offset:" OFS "\n\t"                \
-    "v_add_u32_e32 %[ex], 1, %[ex]\n\t"                                     \
+    "v_add_u32_e32 " LD_EX ", 1, " LD_EX "\n\t"                                     \
     "v_mov_b32_e32 %[range], " LD_R1 "\n\t"                                 \
     LD_REFILL_R1(N)
 // entries of slots 1..7 from the bank words (addresses by mask / constant right shift)
@@ -128,13 +130,16 @@ namespace llcomp_mi {
 // in: exec = the lanes of the wavefront's slices; low / range / win as in RangeDec; w0..w3 = the context's wide row bank (read by
 // the caller, who also needs it to roll back), bank = its LDS address; hot = wave-uniform "most lanes had a non-zero residual
 // last time" (in: entries of slots 1..7 are requested up front; out: the new flag).  out: value = the decoded residual's
-// magnitude with the sign bin applied (0 for a zero residual).  A lane whose exponent exceeds 31 ("Invalid exponent",
-// llcomp.hpp:230-235) stops behind the exponent and leaves with an EMPTY window: the caller replays it on the checked path.
+// magnitude with the sign bin applied (0 for a zero residual); w32 = what is left of the sample's private copy of the window's
+// next three bytes (refills take their byte from it and shift it down by a 2-cycle 32-bit shift; the 64-bit window moves once,
+// behind the sample, by the bytes that went): 0 = the sample wanted more than the three, or its exponent exceeded 31 ("Invalid
+// exponent", llcomp.hpp:230-235: the lane stops behind the exponent) -- the caller replays that lane on the checked path.
 __device__ __forceinline__ void dec_rows_sample_asm(uint32_t& low, uint32_t& range, unsigned long long& win, uint32_t w0, uint32_t w1,
-                                                    uint32_t w2, uint32_t w3, uint32_t bank, uint32_t& hot, uint32_t& value) {
-    uint32_t ex, w;
+                                                    uint32_t w2, uint32_t w3, uint32_t bank, uint32_t& hot, uint32_t& value, uint32_t& w32) {
     asm volatile(
         "s_mov_b64 " LD_SX ", exec\n\t"
+        "v_and_b32_e32 %[w32], 0xffffff, " LD_WINL "\n\t"  // the sample's bytes: the window's next three under a sentinel 1
+        "v_or_b32_e32 %[w32], 0x1000000, %[w32]\n\t"
         "v_and_b32_e32 " LD_OFF ", 0xffff, %[w0]\n\t"
         "ds_read_b64 " LD_E0 ", " LD_OFF "\n\t"
         "v_mov_b32_e32 %[value], 0\n\t"
@@ -165,8 +170,8 @@ __device__ __forceinline__ void dec_rows_sample_asm(uint32_t& low, uint32_t& ran
         "s_cbranch_scc1 .Lhave_%=\n\t"
         LD_FETCH_REST
         ".Lhave_%=:\n\t"
-        "v_mov_b32_e32 %[ex], 0\n\t"
-        "v_mov_b32_e32 %[w], 1\n\t"
+        "v_mov_b32_e32 " LD_EX ", 0\n\t"
+        "v_mov_b32_e32 " LD_W ", 1\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         // ---- unary exponent: slots 1, 2, 3 once each, then a run on slot 4
         // (the lanes that stay behind slots 1 and 2 are the lanes of slot 5 and of the mantissa run: kept, not compared for again)
@@ -184,7 +189,7 @@ __device__ __forceinline__ void dec_rows_sample_asm(uint32_t& low, uint32_t& ran
         "s_cbranch_execz .Lu_done_%=\n\t"
         "v_lshrrev_b32_e32 " LD_OFF ", 16, " LD_E4H "\n\t"
         "ds_read_b64 " LD_E4 ", " LD_OFF "\n\t"
-        "v_add_u32_e32 %[ex], 1, %[ex]\n\t"
+        "v_add_u32_e32 " LD_EX ", 1, " LD_EX "\n\t"
         "v_mov_b32_e32 %[range], " LD_R1 "\n\t"
         LD_REFILL_R1("4")
         "s_branch .Lu_%=\n"
@@ -196,11 +201,10 @@ __device__ __forceinline__ void dec_rows_sample_asm(uint32_t& low, uint32_t& ran
         "v_add_u32_e32 %[low], %[low], %[range]\n\t"  // every lane left by a borrow, with low - r0: put r0 back ...
         LD_REFILL("5")                                // ... and refill behind the closing 0
         // ---- exponent > 31: "Invalid exponent" -- the lane stops here (rare; the caller replays it)
-        "v_cmp_lt_u32_e32 vcc, 31, %[ex]\n\t"
+        "v_cmp_lt_u32_e32 vcc, 31, " LD_EX "\n\t"
         "s_cbranch_vccz .Lexok_%=\n\t"
         "s_and_saveexec_b64 " LD_SP ", vcc\n\t"
-        "v_mov_b32_e32 " LD_WINL ", 0\n\t"  // an empty window (not even the sentinel) is what makes the caller replay a sample
-        "v_mov_b32_e32 v47, 0\n\t"
+        "v_mov_b32_e32 %[w32], 0\n\t"  // used-up bytes (not even the sentinel left) are what makes the caller replay a sample
         "s_andn2_b64 exec, " LD_SP ", exec\n\t"
         "s_cbranch_execz .Ldone_%=\n"
         ".Lexok_%=:\n\t"
@@ -213,7 +217,7 @@ __device__ __forceinline__ void dec_rows_sample_asm(uint32_t& low, uint32_t& ran
         "v_sub_co_u32_e32 " LD_DIFF ", vcc, %[low], %[range]\n\t"
         "ds_write_b16_d16_hi %[bank], " LD_E5L " offset:514\n\t"
         "s_andn2_b64 " LD_SP ", exec, vcc\n\t"                 // the lanes that decoded a 1
-        "v_addc_co_u32_e32 %[w], vcc, %[w], %[w], vcc\n\t"    // 1 + 1 + borrow
+        "v_addc_co_u32_e32 " LD_W ", vcc, " LD_W ", " LD_W ", vcc\n\t"    // 1 + 1 + borrow
         "v_mov_b32_e32 " LD_RUN ", 0\n\t"
         "s_and_b64 exec, " LD_SP ", " LD_SP "\n\t"
         "s_cbranch_execz .Lp5_%=\n\t"
@@ -224,11 +228,11 @@ __device__ __forceinline__ void dec_rows_sample_asm(uint32_t& low, uint32_t& ran
         "s_mov_b64 exec, " LD_SU "\n\t"
         LD_REFILL("6")
         // ---- the rest of the mantissa as a run on slot 6 (exponent > 1): bits gathered under a marker that leaves as a carry
-        "v_add_u32_e32 " LD_T ", -1, %[ex]\n\t"  // m = bins of the run
+        "v_add_u32_e32 " LD_T ", -1, " LD_EX "\n\t"  // m = bins of the run
         "s_and_b64 exec, exec, " LD_SM "\n\t"  // exponent > 1
         "s_cbranch_execz .Lm_skip_%=\n\t"
         "s_mov_b64 " LD_SP ", exec\n\t"
-        "v_add_u32_e32 " LD_NX ", -2, %[ex]\n\t"
+        "v_add_u32_e32 " LD_NX ", -2, " LD_EX "\n\t"
         "v_lshrrev_b32_e32 " LD_RUN ", " LD_NX ", %[sentv]\n\t"  // marker at bit 32 - m
         ".p2align 6\n"
         ".Lm_%=:\n\t"
@@ -247,8 +251,8 @@ __device__ __forceinline__ void dec_rows_sample_asm(uint32_t& low, uint32_t& ran
         "s_and_saveexec_b64 " LD_SW ", vcc\n\t"
         "s_cbranch_execz .Lmr_%=\n\t"
         "v_lshlrev_b32_e32 %[range], 8, %[range]\n\t"
-        "v_perm_b32 %[low], %[low], " LD_WINL ", %[sel]\n\t"
-        "v_lshrrev_b64 " LD_WIN ", 8, " LD_WIN "\n"
+        "v_perm_b32 %[low], %[low], %[w32], %[sel]\n\t"
+        "v_lshrrev_b32_e32 %[w32], 8, %[w32]\n"
         ".Lmr_%=:\n\t"
         "s_andn2_b64 exec, " LD_SW ", " LD_SD "\n\t"  // everybody back, minus the lanes that are done
         "s_cbranch_execnz .Lm_%=\n\t"
@@ -256,14 +260,14 @@ __device__ __forceinline__ void dec_rows_sample_asm(uint32_t& low, uint32_t& ran
         "ds_write_b16_d16_hi %[bank], " LD_NX " offset:768\n"  // slot 6: the successor the last bin chose
         ".Lm_skip_%=:\n\t"
         "s_mov_b64 exec, " LD_SU "\n\t"
-        "v_lshlrev_b32_e32 %[w], " LD_T ", %[w]\n\t"  // what was gathered before the run moves up to make room for it
-        "v_or_b32_e32 %[w], %[w], " LD_RUN "\n"
+        "v_lshlrev_b32_e32 " LD_W ", " LD_T ", " LD_W "\n\t"  // what was gathered before the run moves up to make room for it
+        "v_or_b32_e32 " LD_W ", " LD_W ", " LD_RUN "\n"
         // ---- the value: w with the bits below its leading one inverted back (w == 1 for exponent 0)
         ".Lvalue_%=:\n\t"
         "s_mov_b64 exec, " LD_S5 "\n\t"
-        "v_lshlrev_b32_e64 " LD_T ", %[ex], 1\n\t"
+        "v_lshlrev_b32_e64 " LD_T ", " LD_EX ", 1\n\t"
         "v_add_u32_e32 " LD_T ", -1, " LD_T "\n\t"
-        "v_xor_b32_e32 %[value], %[w], " LD_T "\n\t"
+        "v_xor_b32_e32 %[value], " LD_W ", " LD_T "\n\t"
         // ---- slot 7: the sign (a 1 = negative)
         LD_SPLIT(LD_E7L)
         "v_sub_co_u32_e32 " LD_DIFF ", vcc, %[low], %[range]\n\t"
@@ -278,14 +282,17 @@ __device__ __forceinline__ void dec_rows_sample_asm(uint32_t& low, uint32_t& ran
         "s_mov_b64 exec, " LD_S5 "\n\t"
         LD_REFILL("7")
         ".Ldone_%=:\n\t"
+        "s_mov_b64 exec, " LD_SX "\n\t"
+        "v_ffbh_u32_e32 " LD_DIFF ", %[w32]\n\t"          // the sentinel has moved down by 8 bits per byte consumed:
+        "v_add_u32_e32 " LD_DIFF ", -7, " LD_DIFF "\n\t"  // clz - 7 bits  (a copy that is used up gives nonsense: that lane is replayed)
+        "v_lshrrev_b64 " LD_WIN ", " LD_DIFF ", " LD_WIN "\n\t"
         "s_bcnt1_i32_b64 " LD_S1 ", " LD_SA "\n\t"
         "s_bcnt1_i32_b64 " LD_S2 ", " LD_SX "\n\t"
         "s_lshl_b32 " LD_S1 ", " LD_S1 ", 1\n\t"
         "s_cmp_ge_u32 " LD_S1 ", " LD_S2 "\n\t"
         "s_cselect_b32 %[hot], 1, 0\n\t"
         "s_mov_b64 exec, " LD_SX "\n\t"
-        : [low] "+v"(low), [range] "+v"(range), "+{v[46:47]}"(win), [hot] "+s"(hot), [value] "=&v"(value),
-          [ex] "=&v"(ex), [w] "=&v"(w)
+        : [low] "+v"(low), [range] "+v"(range), "+{v[46:47]}"(win), [hot] "+s"(hot), [value] "=&v"(value), [w32] "=&v"(w32)
         : [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [bank] "v"(bank), [c100] "s"(0x100u), [sel] "s"(0x06050400u),
           [sentv] "v"(0x80000000u)
         : "vcc", "scc", "memory", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45",

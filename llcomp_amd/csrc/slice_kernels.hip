@@ -905,15 +905,18 @@ __device__ __forceinline__ bool dec_sample(RangeDec& d, Bank& bank, const entry_
     bool ok;
 #if LLMI_ASM_DEC
     if constexpr (INLDS) {  // the fast path of the 1-row-slice kernels is one hand-written block (dec_rows_asm.hpp)
-        dec_rows_sample_asm(d.low, d.range, d.win, bank.w[0], bank.w[1], bank.w[2], bank.w[3], lds_address(bank.lds), hot, v);
-        ok = true;  // (an invalid exponent leaves with an empty window: replayed below, where the verdict is formed)
+        uint32_t left;
+        dec_rows_sample_asm(d.low, d.range, d.win, bank.w[0], bank.w[1], bank.w[2], bank.w[3], lds_address(bank.lds), hot, v, left);
+        ok = left != 0;  // (more than three bytes wanted, or an invalid exponent: replayed below, where the verdict is formed)
     } else
 #endif
     {
         ok = hot ? dec_residual<true, false, INLDS>(d, bank, tab, v) : dec_residual<false, false, INLDS>(d, bank, tab, v);
         hot = 2 * __popcll(__ballot(v != 0)) >= __popcll(__ballot(true));  // (ballots are wave-uniform: scalar arithmetic)
     }
-    if (__builtin_expect(!ok || d.win == 0 || replay_always, 0)) {
+    // (hipcc's fast path signals a sample that ran out of window bytes by an empty window; the block signals it through `ok`)
+    const bool ran_dry = (INLDS && LLMI_ASM_DEC != 0) ? false : d.win == 0;
+    if (__builtin_expect(!ok || ran_dry || replay_always, 0)) {
         d.low = s_low; d.range = s_range; d.win = s_win;
         bank.w[0] = s_b0; bank.w[1] = s_b1;
         if constexpr (INLDS) {  // the fast path has already stored new states: put the old ones back
