@@ -16,6 +16,7 @@
 #include "container.hpp"
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "snapshot.hpp"
 #include "tables.hpp"
 
 using namespace llcomp_mi;
@@ -128,6 +129,9 @@ void codec_release(llcomp_mi_codec* k) {
     dev_free(k->d_scratch, k->done);
     dev_free(k->d_group_off, k->done);
     dev_free(k->d_total_tmp, k->done);
+    dev_free(k->d_snap_sorted, k->done);
+    dev_free(k->d_snap_banks, k->done);
+    dev_free(k->d_snap_res, k->done);
     for (auto& sp : k->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     delete k;
 }
@@ -198,13 +202,20 @@ int llcomp_mi_codec_create_ex(llcomp_mi_codec** out, int32_t device, uint32_t fr
     const bool fused = model_is_fused(g);
     const uint64_t b_sym = fused ? 8 : samples * 4, b_states = k->need_states ? (uint64_t(lane_groups(g)) * kContexts << g.lane_shift) * 8 : 8,
                    b_scratch = (uint64_t(lane_groups(g)) << g.lane_shift) * g.slice_cap, b_off = (uint64_t(lane_groups(g)) + 1) * 8;
-    const uint64_t b_lanes = (uint64_t(lane_groups(g)) * slice_capacity_samples(g) << g.lane_shift) * (fused ? 2 : 4);
-    k->workspace_bytes = b_sym + b_lanes + b_states + b_scratch + b_off + 8;
+    // the 2-D encoder's snapshot pass: sorted entries (u32, they take the place of the lane-order symbols), banks in sorted and
+    // in stream order (u64 each), residuals (i16) -- piece layout, snapshot.hpp
+    const bool snap = snapshot_mode(g);
+    const uint64_t snap_el = snap ? snapshot_elems(g) : 0;
+    const uint64_t b_lanes = std::max((uint64_t(lane_groups(g)) * slice_capacity_samples(g) << g.lane_shift) * (fused ? 2 : 4), snap_el * 4);
+    k->workspace_bytes = b_sym + b_lanes + b_states + b_scratch + b_off + 8 + snap_el * 18;
     bool ok = dev_alloc(&k->d_sym_or_rec, b_sym) == hipSuccess && dev_alloc(&k->d_lane_order, b_lanes) == hipSuccess &&
               dev_alloc(reinterpret_cast<void**>(&k->d_states), b_states) == hipSuccess &&
               dev_alloc(reinterpret_cast<void**>(&k->d_scratch), b_scratch) == hipSuccess &&
               dev_alloc(reinterpret_cast<void**>(&k->d_group_off), b_off) == hipSuccess &&
               dev_alloc(reinterpret_cast<void**>(&k->d_total_tmp), 8) == hipSuccess;
+    if (ok && snap)
+        ok = dev_alloc(&k->d_snap_sorted, snap_el * 8) == hipSuccess && dev_alloc(&k->d_snap_banks, snap_el * 8) == hipSuccess &&
+             dev_alloc(&k->d_snap_res, snap_el * 2) == hipSuccess;
     if (!ok) {
         llcomp_mi_codec_destroy(k);
         return LLCOMP_MI_NOMEM;
@@ -243,7 +254,7 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Geometry& g = k->g;
     HIP_TRY(hipMemsetAsync(d_status, 0, 4, s));
-    {
+    if (!snapshot_mode(g)) {  // (the snapshot encoder never touches the state tables: they are the decoder's alone)
         Timed t(k, s, 0);
         if (int rc = next_state_generation(k, s)) return rc;
     }
@@ -253,13 +264,20 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
             HIP_TRY(launch_model_rows_fwd(g, static_cast<const uint8_t*>(d_px), static_cast<uint16_t*>(k->d_lane_order), s));
         } else {
             HIP_TRY(launch_model_fwd(g, static_cast<const uint8_t*>(d_px), static_cast<uint32_t*>(k->d_sym_or_rec), s));
-            HIP_TRY(launch_to_lane_order_u32(g, static_cast<const uint32_t*>(k->d_sym_or_rec),
-                                             static_cast<uint32_t*>(k->d_lane_order), s));
+            if (snapshot_mode(g)) {  // states replayed ahead of the coder: it reads banks + residuals front to back, no table
+                HIP_TRY(launch_snapshot(g, static_cast<const uint32_t*>(k->d_sym_or_rec), k->d_lane_order, k->d_snap_sorted,
+                                        k->d_snap_banks, k->d_snap_res, s));
+            } else {
+                HIP_TRY(launch_to_lane_order_u32(g, static_cast<const uint32_t*>(k->d_sym_or_rec),
+                                                 static_cast<uint32_t*>(k->d_lane_order), s));
+            }
         }
     }
     {
         Timed t(k, s, 2);
-        HIP_TRY(launch_encode_slices(g, k->d_lane_order, k->d_states, k->state_generation, k->d_scratch, static_cast<uint32_t*>(d_slice_len),
+        const bool snap = snapshot_mode(g);
+        HIP_TRY(launch_encode_slices(g, snap ? k->d_snap_res : k->d_lane_order, snap ? static_cast<uint64_t*>(k->d_snap_banks) : k->d_states,
+                                     k->state_generation, k->d_scratch, static_cast<uint32_t*>(d_slice_len),
                                      k->d_group_off, static_cast<uint32_t*>(d_status), s));
     }
     {

@@ -29,6 +29,9 @@ struct llcomp_mi_codec {
     uint8_t* d_scratch = nullptr;    // slice streams in stream lane order: 16-byte units [group][unit][lane]
     uint64_t* d_group_off = nullptr; // u64[lane groups + 1]: payload offset of every lane group's first slice
     uint64_t* d_total_tmp = nullptr;
+    void* d_snap_sorted = nullptr;   // snapshot pass of the 2-D encoder (snapshot.hpp): banks in context-sorted order,
+    void* d_snap_banks = nullptr;    // banks in stream order, residuals in stream order; null unless snapshot_mode(g)
+    void* d_snap_res = nullptr;
     uint64_t workspace_bytes = 0;
     bool need_states = true;  // false when the states live in LDS (1-row slices; one slice per wavefront)
     uint32_t state_generation = 0;  // tag of the last call that used d_states (kernels.hpp); 0 = the table has not been cleared yet

@@ -36,7 +36,10 @@ enum : uint32_t {
     kGeoLdsTable = 2u,     // one slice per wavefront: its 63 KB state table lives in LDS
     kGeoForceReplay = 4u,  // test hook: every decoded sample also goes through rollback + checked replay
     kGeoSmallModel = 8u,   // bitstream variant: the reference built with LargeModel = false (llcomp.hpp:21, 26-32, 427-429)
+    kGeoSnapshot = 16u,    // 2-D slices of at most kSnapMaxSamples samples: the ENCODER streams state snapshots (snapshot_kernels.hip)
+                           // instead of read-modify-writing a 63 KB table per slice in HBM; the decoder still needs that table
 };
+constexpr uint32_t kSnapMaxSamples = 4096;  // a slice's samples are sorted by context inside one workgroup's LDS
 
 // Test / tuning hooks.  They are read from the environment ONCE per process (codec.hip: current_tuning; a test that
 // changes them calls llcomp_mi_reload_tuning), they select the kernel family when a codec object is created, and none
@@ -47,6 +50,7 @@ struct Tuning {
     bool norows = false;       // LLCOMP_MI_NOROWS=1: 1-row slices through the general table-per-slice kernels
     bool noldstab = false;     // LLCOMP_MI_NOLDSTAB=1: single-slice launches keep their table in HBM
     bool force_replay = false; // LLCOMP_MI_FORCE_REPLAY=1
+    bool nosnap = false;       // LLCOMP_MI_NOSNAP=1: the 2-D encoder keeps its state tables in HBM (the path before round 4)
 };
 inline Tuning tuning_from_env() {
     Tuning t;
@@ -62,6 +66,7 @@ inline Tuning tuning_from_env() {
     t.norows = flag("LLCOMP_MI_NOROWS");
     t.noldstab = flag("LLCOMP_MI_NOLDSTAB");
     t.force_replay = flag("LLCOMP_MI_FORCE_REPLAY");
+    t.nosnap = flag("LLCOMP_MI_NOSNAP");
     return t;
 }
 
@@ -136,6 +141,7 @@ inline bool make_geometry(Geometry& g, uint32_t frames, uint32_t w, uint32_t h, 
     g.flags = 0;
     if (g.tile_h == 1 && !tune.norows && g.nch <= 4) g.flags |= kGeoRows;  // (the register-resident row kernels exist for 1..4 channels)
     else if (g.lpw == 1 && !tune.noldstab) g.flags |= kGeoLdsTable;
+    else if (g.slice_samples <= kSnapMaxSamples && !tune.nosnap) g.flags |= kGeoSnapshot;
     if (tune.force_replay) g.flags |= kGeoForceReplay;
     if (small_model) g.flags |= kGeoSmallModel;
     return true;

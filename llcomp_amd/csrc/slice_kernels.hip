@@ -478,12 +478,16 @@ __device__ __forceinline__ void clear_lds_states() {
         for (uint32_t i = threadIdx.x; i < uint32_t(kContexts); i += blockDim.x) t[i] = 0;
     }
 }
-template <int NCH, bool ROWS, typename SYM, bool LDSTAB = false>
+// SNAP: slices of several rows whose states were replayed ahead of the coder (snapshot_kernels.hip): `sym` is then the array of
+// folded residuals (i16) and `states` the array of state banks as they stand BEFORE each sample (u64), both in stream order
+// and in the piece layout [lane group][piece][lane][32 bytes] -- the kernel reads them front to back and touches no table.
+template <int NCH, bool ROWS, typename SYM, bool LDSTAB = false, bool SNAP = false>
 __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const uint32_t lpw,
                                                       const SYM* __restrict__ sym, uint64_t* __restrict__ states,
                                                       uint8_t* __restrict__ scratch, uint32_t* __restrict__ slice_len,
                                                       uint64_t* __restrict__ group_sum, uint32_t* status, const uint64_t gpat) {
-    constexpr bool ASM = ROWS && LLMI_ASM_ENC != 0;
+    static_assert(!(SNAP && (ROWS || LDSTAB)), "one kernel family at a time");
+    constexpr bool ASM = (ROWS || SNAP) && LLMI_ASM_ENC != 0;
     entry_t* tab;
     uint8_t* stage;
     uint32_t* rowbank;
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     } else {
         __shared__ entry_t s_tab[128];
         __shared__ __attribute__((aligned(32))) uint8_t s_stage[kStagePad + kStageBytes * 64];
-        __shared__ uint32_t s_rowbank[ROWS ? kRowBankWords : 1];
+        __shared__ uint32_t s_rowbank[ROWS ? kRowBankWords : 1];  // (SNAP without the hand-written block keeps its bank in registers)
         tab = s_tab;
         stage = s_stage;
         rowbank = s_rowbank;
@@ -530,7 +534,85 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     bool hot = false;  // wave-uniform: most lanes had a non-zero residual last time
     LLMI_PROBE_START();
 
-    if constexpr (ROWS) {
+    if constexpr (SNAP) {
+        // One bank and one residual per sample, front to back.  The sample index is wave-uniform (lock-step), so the piece
+        // address is a scalar base plus the lane's fixed offset.
+        const uint32_t cap = (g.slice_samples + 15u) & ~15u;  // snapshot_cap()
+        const uint32_t grp = __builtin_amdgcn_readfirstlane(id >> g.lane_shift);
+        const char* const gres = reinterpret_cast<const char*>(sym) + ((size_t(grp) * cap * 2) << g.lane_shift);
+        const char* const gbank = reinterpret_cast<const char*>(states) + ((size_t(grp) * cap * 8) << g.lane_shift);
+        const uint32_t row = 32u << g.lane_shift;
+        uint32_t lofs = (id & ((1u << g.lane_shift) - 1)) * 32u;
+        asm volatile("" : "+v"(lofs));
+        auto load_res = [&](uint32_t i) -> int {
+            i = min(i, cap - 1);
+            return *reinterpret_cast<const int16_t*>(gres + size_t(i >> 4) * row + ((i & 15u) << 1) + lofs);
+        };
+        auto load_bank = [&](uint32_t i) -> uint2 {
+            i = min(i, cap - 1);
+            return *reinterpret_cast<const uint2*>(gbank + size_t(i >> 3) * (2 * row) + ((i & 7u) << 3) + 2 * lofs);  // 64-byte pieces
+        };
+#if LLMI_ASM_ENC
+        // the hand-written sample in its snapshot form (enc_sample_asm.inc, LL_SNAP): the bank arrives in two registers and no
+        // state is written back anywhere
+        EncRowsExtra xs{0u, 0u, 0u};
+        unsigned long long low_range = e.low | ((unsigned long long)e.range << 32);
+#endif
+        auto code = [&](int res, uint2 bk) {
+#if LLMI_ASM_ENC
+            enc_snap_sample_asm(low_range, e.wp, xs, bk.x, bk.y, res, e.base);
+            if (__builtin_expect(xs.any_pend != 0, 0)) {
+                xs.any_pend = 0;
+                if (xs.pend) enc_carry_back_flushed(e);
+                xs.pend = 0;
+            }
+#else
+            Bank bank{{bk.x, bk.y}, nullptr};
+            if (hot) enc_residual<true, false>(e, bank, tab, res); else enc_residual<false, false>(e, bank, tab, res);
+            hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(res != 0)) >= __popcll(__ballot(true)));
+#endif
+        };
+        // A wavefront that runs alone on its SIMD (a few thousand slices of 4096 samples do not fill the GPU) codes a sample
+        // in well under a microsecond, an HBM round trip under load takes two: bank and residual are requested FOUR samples
+        // ahead, through four register slots that the 4x unrolled bulk loop rotates statically.  The bulk runs under a scalar
+        // counter when all slices of the wavefront are equally long; what is left takes the loop with the per-lane test.
+        const uint32_t total0 = __builtin_amdgcn_readfirstlane(total);
+        const bool same = __builtin_amdgcn_ballot_w64(total != total0) == 0;
+        const uint32_t n_bulk = same ? total0 & ~3u : 0;
+        int r0 = load_res(0), r1 = load_res(1), r2 = load_res(2), r3 = load_res(3);
+        uint2 b0 = load_bank(0), b1 = load_bank(1), b2 = load_bank(2), b3 = load_bank(3);
+        uint32_t i = 0;
+#define LLMI_SNAP_SAMPLE(R, B, AHEAD)                          \
+        {                                                          \
+            const int rc = int(consume_here(uint32_t(R)));        \
+            uint2 bc = B;                                          \
+            bc.x = consume_here(bc.x);                             \
+            R = load_res(i + AHEAD);                               \
+            B = load_bank(i + AHEAD);                              \
+            if (e.wp >= e.base + 16) enc_flush16(e);               \
+            code(rc, bc);                                          \
+        }
+        for (; i < n_bulk; i += 4) {
+            LLMI_SNAP_SAMPLE(r0, b0, 4)
+            LLMI_SNAP_SAMPLE(r1, b1, 5)
+            LLMI_SNAP_SAMPLE(r2, b2, 6)
+            LLMI_SNAP_SAMPLE(r3, b3, 7)
+        }
+        for (; i < total; ++i) {  // (slot 0 always holds sample i here: the slots move down by one)
+            LLMI_SNAP_SAMPLE(r0, b0, 4)
+            {
+                const int tr = r0;
+                const uint2 tb = b0;
+                r0 = r1; r1 = r2; r2 = r3; r3 = tr;
+                b0 = b1; b1 = b2; b2 = b3; b3 = tb;
+            }
+        }
+#undef LLMI_SNAP_SAMPLE
+#if LLMI_ASM_ENC
+        e.low = uint32_t(low_range);
+        e.range = uint32_t(low_range >> 32);
+#endif
+    } else if constexpr (ROWS) {
         // contexts 0 / 605 / 1210 only: their state bytes sit in LDS, [context][lane] (a read + a write per sample
         // instead of selecting among / writing back to three register pairs: twelve v_cndmask)
         for (uint32_t k = 0; k < 6; ++k) rowbank[k * 64 + threadIdx.x] = 0;
@@ -1192,6 +1274,11 @@ hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* 
     if (model_is_fused(g)) {  // planar 1-row slices: 16-bit symbols, always the ROWS kernel
         k_encode_slices<1, true, uint16_t><<<dim3(blocks), dim3(64), LLMI_ASM_ENC ? kRowsEncLdsBytes : 0, stream>>>(
             g, lpw, static_cast<const uint16_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status, gpat);
+        return hipGetLastError();
+    }
+    if (g.flags & kGeoSnapshot) {  // d_sym: residuals, d_states: banks before each sample (launch_snapshot), both in piece layout
+        k_encode_slices<0, false, uint32_t, false, true><<<dim3(blocks), dim3(64), LLMI_ASM_ENC ? kRowsEncLdsBytes : 0, stream>>>(
+            g, lpw, static_cast<const uint32_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status, 0);
         return hipGetLastError();
     }
     const bool lds = states_in_lds(g);

@@ -1,0 +1,369 @@
+// snapshot_kernels.hip -- the STATE SNAPSHOT pass of the 2-D encoder (tile_h > 1, several slices per wavefront).
+//
+// The reference codes one sample after the other and lets every bin read and update states[hash*8 + slot]
+// (llcomp.hpp:385, 439-444).  With one LANE per slice that table is 63 KB per lane: it lives in HBM, and every sample costs
+// a random 8-byte read-modify-write that moves a 128-byte line both ways (131 B per sample measured for 3 algorithmic).
+// But the ENCODER knows every (context, residual) of a slice before it codes anything, and the states do not depend on the
+// range coder at all: the eight states a sample will find in its context are a function of the earlier samples OF THAT
+// CONTEXT only.  So the table is replaced by three streaming steps, all of them coalesced:
+//   k_snap_sort    one workgroup per slice: a stable LSD radix sort of the slice's samples by context in LDS (13-bit key, at most
+//                  4096 samples) -> entries {residual, stream position, "first sample of its context"} in context-major order;
+//   k_snap_walk    one lane per slice (64 slices per wavefront, like the coder): walks its slice's entries in that order with the
+//                  eight states of the current context in REGISTERS -- a context's samples are consecutive now, a new context
+//                  starts from zeros -- and leaves the bank as it stood BEFORE every sample; a sample's effect on the eight
+//                  states is nine table look-ups (walk_tables.hpp), no range arithmetic, no divergence;
+//   k_snap_unperm  one workgroup per slice: puts the banks back into stream order through LDS.
+// The coder (slice_kernels.hip, k_encode_slices<..., SNAP>) then reads one 8-byte bank and one residual per sample, in order.
+// Every lane-per-slice <-> workgroup-per-slice hand-over uses the PIECE layout below, so that both sides move whole 32-byte
+// pieces and nothing is transposed in a pass of its own.
+//
+// Piece layout of an array: [lane group][piece][lane][P bytes], P = 32 for the entries (eight u32) and the residuals (sixteen
+// i16), P = 64 for the banks (eight u64).  A wavefront of the lane-per-slice kernels reads element e of its 64 lanes from one
+// run of 64 * P bytes (re-used by the samples that share the piece) and writes whole pieces; a workgroup that owns one slice moves
+// pieces 64 * P bytes apart, and the workgroups of the lanes that share a 128-byte line run on the same XCD at about the same
+// time (block -> slice mapping below), so the line meets in one L2.  (tools/ubench/piece_access.hip: 32-byte pieces move at
+// 2.8 / 4.0 TB/s write / read with that mapping, 0.8 / 1.4 without; a slice's contiguous 32 KB at 5.8 / 6.2.)
+#include <hip/hip_runtime.h>
+
+#include "device_common.hpp"
+#include "kernels.hpp"
+#include "snapshot.hpp"
+#include "walk_tables.hpp"
+
+namespace llcomp_mi {
+
+namespace {
+
+__constant__ WalkTables c_walk = make_walk_tables();
+
+constexpr uint32_t kSortThreads = 256;
+constexpr uint32_t kOwn = kSnapMaxSamples / kSortThreads;  // 16 consecutive sort positions per thread
+constexpr uint32_t kRowPad = kSortThreads + 1;             // position p lives at (p % 16) * 257 + p / 16: a thread's own 16
+                                                           // positions and 64 consecutive positions both spread over the banks
+__device__ __forceinline__ uint32_t phys(uint32_t p) { return (p & (kOwn - 1)) * kRowPad + (p >> 4); }
+static_assert(kOwn == 16, "phys()");
+
+// workgroup -> slice, XCD-aware (workgroup i runs on XCD i % 8): the slices of one lane group go to ONE XCD, neighbouring lanes
+// to neighbouring slots, so the 32-byte pieces that share a cache line are moved through the same L2 at about the same time
+__device__ __forceinline__ bool block_slice(const Geometry& g, uint32_t& id, uint32_t& group, uint32_t& lane) {
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    group = ((slot >> g.lane_shift) << 3) + xcd;
+    lane = slot & ((1u << g.lane_shift) - 1);
+    id = (group << g.lane_shift) + lane;
+    return id < g.n_slices;
+}
+
+struct Span {
+    size_t origin;   // index of the slice's first sample in the image-order symbol array
+    uint32_t n_row;  // samples per slice row (contiguous)
+    uint32_t n;      // samples in the slice
+};
+__device__ __forceinline__ Span slice_span(const Geometry& g, uint32_t id) {
+    const SliceRect r = slice_rect(g, id);
+    Span s;
+    s.origin = slice_origin(g, r);
+    s.n_row = r.sw * g.nch;
+    s.n = s.n_row * r.sh;
+    return s;
+}
+
+// inclusive prefix sum over the 64 lanes of a wavefront (DPP: four shifts inside the rows of 16, two row broadcasts)
+__device__ __forceinline__ uint32_t wave_scan(uint32_t x) {
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x111, 0xF, 0xF, false));  // row_shr:1
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x112, 0xF, 0xF, false));  // row_shr:2
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x114, 0xF, 0xF, false));  // row_shr:4
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x118, 0xF, 0xF, false));  // row_shr:8
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1, 3
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
+// One stable counting pass of the radix sort on key bits [SH, SH + BITS).  Thread t owns positions 16t .. 16t+15 of `src` (in
+// order) and counts its digits in PRIVATE counters cnt[digit / 2][t] (two 16-bit counters per word: all sums stay below 2^16).
+// The counters become start positions in (digit, thread) order -- every wavefront scans whole rows cnt[j][0..255], four
+// threads' counters per lane -- and every thread scatters its keys in order.
+template <int SH, int BITS>
+__device__ __forceinline__ void sort_pass(const uint32_t* src, uint32_t* dst, uint32_t* cnt, uint32_t* tot) {
+    constexpr uint32_t ND2 = (1u << BITS) / 2;  // packed counters per thread = rows
+    static_assert(ND2 == 4 || ND2 == 8, "rows per wavefront");
+    constexpr uint32_t RPW = ND2 / 4;           // rows each of the four wavefronts scans
+    const uint32_t t = threadIdx.x, wave = t >> 6, l = t & 63;
+#pragma unroll
+    for (uint32_t j = 0; j < ND2; ++j) cnt[j * kSortThreads + t] = 0;
+    uint32_t keys[kOwn], slot[kOwn], inc[kOwn];
+#pragma unroll
+    for (uint32_t i = 0; i < kOwn; ++i) keys[i] = src[i * kRowPad + t];
+#pragma unroll
+    for (uint32_t i = 0; i < kOwn; ++i) {
+        slot[i] = ((keys[i] >> (SH + 1)) & (ND2 - 1)) * kSortThreads + t;
+        inc[i] = 1u + ((keys[i] >> SH) & 1u) * 0xFFFFu;  // +1 in the low or in the high half
+        atomicAdd(&cnt[slot[i]], inc[i]);                // (private counter: ds_add without return)
+    }
+    __syncthreads();
+    uint4 c[RPW];
+    uint32_t excl[RPW];
+#pragma unroll
+    for (uint32_t u = 0; u < RPW; ++u) {
+        const uint32_t j = wave + 4 * u;
+        c[u] = *reinterpret_cast<const uint4*>(&cnt[j * kSortThreads + 4 * l]);
+        const uint32_t sum = c[u].x + c[u].y + c[u].z + c[u].w;
+        const uint32_t incl = wave_scan(sum);
+        excl[u] = incl - sum;
+        if (l == 63) tot[j] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < RPW; ++u) {
+        const uint32_t j = wave + 4 * u;
+        uint32_t run = 0;  // keys with a smaller digit than 2j
+#pragma unroll
+        for (uint32_t jj = 0; jj < ND2; ++jj) {
+            const uint32_t tj = tot[jj];
+            run += jj < j ? (tj & 0xFFFFu) + (tj >> 16) : 0u;
+        }
+        const uint32_t mine = tot[j];
+        uint4 o;
+        o.x = excl[u] + (run | ((run + (mine & 0xFFFFu)) << 16));  // digit 2j starts at `run`, digit 2j+1 behind it
+        o.y = o.x + c[u].x;
+        o.z = o.y + c[u].y;
+        o.w = o.z + c[u].z;
+        *reinterpret_cast<uint4*>(&cnt[j * kSortThreads + 4 * l]) = o;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < kOwn; ++i) {
+        const uint32_t old = atomicAdd(&cnt[slot[i]], inc[i]);
+        const uint32_t pos = (old >> (((keys[i] >> SH) & 1u) * 16)) & 0xFFFFu;
+        dst[phys(pos)] = keys[i];
+    }
+    __syncthreads();
+}
+
+// entry of the sorted list: residual (10 bits, two's complement) | stream position << 10 | first-of-its-context << 22
+constexpr uint32_t kEntryPosShift = 10, kEntryFirstBit = 22;
+
+__global__ __launch_bounds__(kSortThreads) void k_snap_sort(const Geometry g, const uint32_t cap, const uint32_t* __restrict__ sym,
+                                                           uint8_t* __restrict__ entries) {
+    __shared__ uint32_t key_a[kOwn * kRowPad], key_b[kOwn * kRowPad];
+    __shared__ uint32_t cnt[8 * kSortThreads];
+    __shared__ uint32_t tot[8];
+    __shared__ int16_t res_of[kSnapMaxSamples];
+    uint32_t id, group, lane;
+    if (!block_slice(g, id, group, lane)) return;
+    const Span sp = slice_span(g, id);
+    const size_t rs = slice_row_stride(g);
+    const uint32_t t = threadIdx.x;
+    // keys: context << 12 | stream position (the low 12 bits ride along; positions beyond the slice sort to the end)
+    {
+        uint32_t v[kOwn];
+        // sample k = i * 256 + t sits in slice row k / n_row: one division per thread, then steps of 256 (32-bit offsets from
+        // the slice's first sample)
+        const uint32_t rs32 = uint32_t(rs), dy = kSortThreads / sp.n_row, dx = kSortThreads - dy * sp.n_row;
+        const uint32_t step_off = dy * rs32 + dx, wrap_off = rs32 - sp.n_row;
+        const uint32_t* const base = sym + sp.origin;
+        const uint32_t y0 = t / sp.n_row;
+        uint32_t x = t - y0 * sp.n_row, off = y0 * rs32 + x;
+#pragma unroll
+        for (uint32_t i = 0; i < kOwn; ++i) {
+            v[i] = i * kSortThreads + t < sp.n ? base[off] : 0x1FFFu;
+            x += dx;
+            off += step_off;
+            if (x >= sp.n_row) {
+                x -= sp.n_row;
+                off += wrap_off;
+            }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < kOwn; ++i) {
+            const uint32_t k = i * kSortThreads + t;
+            key_a[phys(k)] = ((v[i] & 0xFFFFu) << 12) | k;
+            res_of[k] = int16_t(v[i] >> 16);
+        }
+    }
+    __syncthreads();
+    sort_pass<12, 4>(key_a, key_b, cnt, tot);
+    sort_pass<16, 3>(key_b, key_a, cnt, tot);
+    sort_pass<19, 3>(key_a, key_b, cnt, tot);
+    sort_pass<22, 3>(key_b, key_a, cnt, tot);
+    // sorted: key_a.  Entries leave as 32-byte pieces of eight.
+    uint8_t* const out = entries + size_t(group) * (size_t(cap) * 4 << g.lane_shift) + lane * 32u;
+    // Four entries (16 bytes) per thread and turn, neighbouring threads the neighbouring chunks of a piece: a store instruction
+    // then covers whole 32-byte sectors.  (Stores reach HBM per instruction, as 32-byte sectors: a lone 16-byte store costs 32 --
+    // WRITE_SIZE of this kernel read 2x its bytes while one thread wrote both halves of a piece in two instructions.)
+    for (uint32_t c = t; c * 4 < sp.n; c += kSortThreads) {
+        uint32_t e[4];
+        uint32_t prev = c ? key_a[phys(c * 4 - 1)] >> 12 : ~0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t key = key_a[phys(c * 4 + j)];
+            const uint32_t k = key & 0xFFFu, ctx = key >> 12;
+            e[j] = (uint32_t(res_of[k]) & 0x3FFu) | (k << kEntryPosShift) | (uint32_t(ctx != prev) << kEntryFirstBit);
+            prev = ctx;
+        }
+        *reinterpret_cast<uint4*>(out + (size_t(c >> 1) << (g.lane_shift + 5)) + ((c & 1u) << 4)) = make_uint4(e[0], e[1], e[2], e[3]);
+    }
+}
+
+// ---- the walk ----------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kWalkThreads = 256;
+
+// (Measured and dropped, round 4: cutting a slice's sorted list at context boundaries into four parts walked by four wavefronts.
+// The walk is bound by the CU's vector + LDS throughput -- ten byte look-ups with random bank conflicts per step -- not by the
+// length of one lane's chain: four times the wavefronts over ranges that start at different places in every lane took 4.2 ms
+// where one wavefront per 64 slices takes 2.3.)
+__global__ __launch_bounds__(kWalkThreads) void k_snap_walk(const Geometry g, const uint32_t lpw, const uint32_t cap,
+                                                           const uint8_t* __restrict__ entries, uint8_t* __restrict__ sorted_banks) {
+    __shared__ WalkTables tab;
+    // a wavefront's eight banks per lane and round (64 lanes x 64 bytes) on their way out: written lane by lane, read back as the
+    // 4 KB they are in HBM, so that every store instruction covers 1 KB of contiguous memory (whole sectors)
+    __shared__ __attribute__((aligned(16))) uint4 outbuf[kWalkThreads / 64][4 * 64];
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_walk);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&tab);
+        for (uint32_t i = threadIdx.x; i < sizeof(WalkTables) / 4; i += kWalkThreads) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const uint32_t first = (blockIdx.x * (kWalkThreads / 64) + wave) * lpw, id = first + l;
+    if (first >= g.n_slices) return;
+    const bool active = l < lpw && id < g.n_slices;
+    const uint32_t n = active ? slice_span(g, id).n : 0;
+    // (all lanes of a wavefront belong to one lane group: lpw divides the group width)
+    const uint32_t grp = first >> g.lane_shift;
+    const uint32_t lane_in_group = (first & ((1u << g.lane_shift) - 1)) + l;
+    const uint8_t* const ebase = entries + size_t(grp) * (size_t(cap) * 4 << g.lane_shift);
+    uint8_t* const bbase = sorted_banks + size_t(grp) * (size_t(cap) * 8 << g.lane_shift);
+    const uint32_t first_in_group = first & ((1u << g.lane_shift) - 1);
+    // (idle lanes of a narrow or ragged wavefront walk along on the first lane's entries -- their addresses stay inside the
+    // arrays -- and help with the stores below)
+    const uint32_t lofs = (active ? lane_in_group : first_in_group) * 32u;
+    const uint32_t row = 32u << g.lane_shift;  // bytes from one 32-byte piece of a lane to its next
+    uint32_t n_max = 0;
+    for (unsigned long long m = __ballot(active); m; m &= m - 1)
+        n_max = max(n_max, uint32_t(__builtin_amdgcn_readlane(int(n), __builtin_ctzll(m))));
+    const uint32_t lanes_here = min(lpw, g.n_slices - first);  // lanes of this wavefront that own a slice
+
+    // Eight entries (one 32-byte piece per lane) per round, requested TWO ROUNDS ahead.  Banks leave as whole 64-byte pieces.
+    // Entries and banks beyond a slice's last sample are never looked at by anybody (the capacity is a multiple of 16: every
+    // address stays inside the arrays).
+    const uint32_t rounds = (n_max + 7) >> 3, cap_rounds = cap >> 3;
+    auto load_piece = [&](uint32_t r, uint4& a, uint4& b) {  // (r is wave-uniform: scalar base + the lane's offset)
+        const uint4* p = reinterpret_cast<const uint4*>(ebase + size_t(min(r, cap_rounds - 1)) * row + lofs);
+        a = p[0];
+        b = p[1];
+    };
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;  // the eight states of the context being walked
+    auto step = [&](uint32_t e, uint32_t& lo, uint32_t& hi) {
+        const uint32_t codes = tab.codes[e & 0x3FFu];
+        const uint32_t keep = ((e >> kEntryFirstBit) & 1u) - 1u;  // a new context starts from zeros (llcomp.hpp:385)
+        s0 &= keep; s1 &= keep; s2 &= keep; s3 &= keep; s4 &= keep; s5 &= keep; s6 &= keep; s7 &= keep;
+        lo = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
+        hi = s4 | (s5 << 8) | (s6 << 16) | (s7 << 24);
+        s0 = tab.once[s0 * kWalkOnceStride + (codes & 3u)];
+        s1 = tab.once[s1 * kWalkOnceStride + ((codes >> 2) & 3u)];
+        s2 = tab.once[s2 * kWalkOnceStride + ((codes >> 4) & 3u)];
+        s3 = tab.once[s3 * kWalkOnceStride + ((codes >> 6) & 3u)];
+        s4 = tab.unary[s4 * kWalkUnaryStride + ((codes >> 8) & 7u)];
+        s5 = tab.once[s5 * kWalkOnceStride + ((codes >> 11) & 3u)];
+        s6 = tab.bits[s6 * kWalkBitsStride + ((codes >> 13) & 31u)];
+        s7 = tab.once[s7 * kWalkOnceStride + ((codes >> 23) & 3u)];
+        s6 = tab.bits[s6 * kWalkBitsStride + ((codes >> 18) & 31u)];
+    };
+    uint4 a0, b0, a1, b1;
+    load_piece(0, a0, b0);
+    load_piece(1, a1, b1);
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint4 ea = a0, eb = b0;
+        a0 = a1;
+        b0 = b1;
+        load_piece(r + 2, a1, b1);
+        uint4 o0, o1, o2, o3;
+        step(ea.x, o0.x, o0.y);
+        step(ea.y, o0.z, o0.w);
+        step(ea.z, o1.x, o1.y);
+        step(ea.w, o1.z, o1.w);
+        step(eb.x, o2.x, o2.y);
+        step(eb.y, o2.z, o2.w);
+        step(eb.z, o3.x, o3.y);
+        step(eb.w, o3.z, o3.w);
+        // lane l's piece = chunks 4l .. 4l+3 of the wavefront's 4 KB; store instruction j takes chunks 64j .. 64j+63.  (Chunk
+        // c sits at [c % 4][c / 4]: the lane-wise writes and the chunk-wise reads both spread over the LDS banks.)
+        uint4* const ob = outbuf[wave];
+        ob[0 * 64 + l] = o0;
+        ob[1 * 64 + l] = o1;
+        ob[2 * 64 + l] = o2;
+        ob[3 * 64 + l] = o3;
+        uint4* const q = reinterpret_cast<uint4*>(bbase + size_t(r) * (2 * row) + first_in_group * 64u) + l;  // the wavefront's first piece, chunk l
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t c = j * 64 + l;  // chunk c of the 4 KB belongs to lane c / 4, part c % 4
+            if ((c >> 2) < lanes_here) q[j * 64] = ob[(c & 3u) * 64 + (c >> 2)];
+        }
+    }
+}
+
+// ---- back into stream order --------------------------------------------------------------------------------------------------
+constexpr uint32_t kUnpermThreads = kSnapMaxSamples / 8;  // a thread moves eight entries and their eight banks
+__global__ __launch_bounds__(kUnpermThreads) void k_snap_unperm(const Geometry g, const uint32_t cap, const uint8_t* __restrict__ entries,
+                                                               const uint8_t* __restrict__ sorted_banks, uint8_t* __restrict__ banks,
+                                                               uint8_t* __restrict__ residuals) {
+    __shared__ __attribute__((aligned(16))) uint2 bank_of[kSnapMaxSamples];
+    __shared__ __attribute__((aligned(16))) int16_t res_of[kSnapMaxSamples];
+    uint32_t id, group, lane;
+    if (!block_slice(g, id, group, lane)) return;
+    const uint32_t n = slice_span(g, id).n;
+    const uint32_t q = threadIdx.x;
+    const size_t row = size_t(32) << g.lane_shift;
+    const uint8_t* const ein = entries + size_t(group) * (size_t(cap) * 4 << g.lane_shift) + lane * 32u;
+    const uint8_t* const bin = sorted_banks + size_t(group) * (size_t(cap) * 8 << g.lane_shift) + lane * 64u;
+    if (q * 8 < n) {  // one piece of eight entries, one piece of their eight banks: six loads in flight, then the scatter
+        const uint4* ep = reinterpret_cast<const uint4*>(ein + q * row);
+        const uint4* bp = reinterpret_cast<const uint4*>(bin + q * (2 * row));
+        const uint4 ea = ep[0], eb = ep[1], b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+        const uint32_t e[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+        const uint32_t bx[8] = {b0.x, b0.z, b1.x, b1.z, b2.x, b2.z, b3.x, b3.z};
+        const uint32_t by[8] = {b0.y, b0.w, b1.y, b1.w, b2.y, b2.w, b3.y, b3.w};
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            if (q * 8 + j < n) {
+                const uint32_t k = (e[j] >> kEntryPosShift) & 0xFFFu;
+                bank_of[k] = make_uint2(bx[j], by[j]);
+                res_of[k] = int16_t(int32_t(e[j] << 22) >> 22);
+            }
+        }
+    }
+    __syncthreads();
+    uint8_t* const bout = banks + size_t(group) * (size_t(cap) * 8 << g.lane_shift) + lane * 64u;
+    uint8_t* const rout = residuals + size_t(group) * (size_t(cap) * 2 << g.lane_shift) + lane * 32u;
+    // out: 16-byte chunks, neighbouring threads the neighbouring chunks of a piece (whole sectors per store instruction, see
+    // k_snap_sort)
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t c = q + kUnpermThreads * u;  // two banks
+        if (c * 2 < n) *reinterpret_cast<uint4*>(bout + size_t(c >> 2) * (2 * row) + ((c & 3u) << 4)) = *reinterpret_cast<const uint4*>(&bank_of[c * 2]);
+    }
+    if (q * 8 < n) *reinterpret_cast<uint4*>(rout + size_t(q >> 1) * row + ((q & 1u) << 4)) = *reinterpret_cast<const uint4*>(&res_of[q * 8]);
+}
+
+}  // namespace
+
+bool snapshot_mode(const Geometry& g) { return (g.flags & kGeoSnapshot) != 0; }
+uint32_t snapshot_cap(const Geometry& g) { return (g.slice_samples + 15u) & ~15u; }
+uint64_t snapshot_elems(const Geometry& g) { return (uint64_t(lane_groups(g)) * snapshot_cap(g)) << g.lane_shift; }
+
+hipError_t launch_snapshot(const Geometry& g, const uint32_t* d_sym, void* d_entries, void* d_sorted, void* d_banks, void* d_residuals,
+                           hipStream_t stream) {
+    const uint32_t cap = snapshot_cap(g);
+    const uint32_t groups = lane_groups(g);
+    const uint32_t blocks = (((groups + 7u) >> 3) << 3) << g.lane_shift;  // whole rounds of eight lane groups (one per XCD)
+    k_snap_sort<<<dim3(blocks), dim3(kSortThreads), 0, stream>>>(g, cap, d_sym, static_cast<uint8_t*>(d_entries));
+    const uint32_t waves = (g.n_slices + g.lpw - 1) / g.lpw;
+    k_snap_walk<<<dim3((waves + kWalkThreads / 64 - 1) / (kWalkThreads / 64)), dim3(kWalkThreads), 0, stream>>>(
+        g, g.lpw, cap, static_cast<const uint8_t*>(d_entries), static_cast<uint8_t*>(d_sorted));
+    k_snap_unperm<<<dim3(blocks), dim3(kUnpermThreads), 0, stream>>>(g, cap, static_cast<const uint8_t*>(d_entries),
+                                                         static_cast<const uint8_t*>(d_sorted), static_cast<uint8_t*>(d_banks),
+                                                         static_cast<uint8_t*>(d_residuals));
+    return hipGetLastError();
+}
+
+}  // namespace llcomp_mi
