@@ -676,8 +676,9 @@ class quiet_stdout:
 
 class Watchdog:
     """The secondary legs of the N > 1 line run behind this: if they have not finished `seconds` after arm(), rank 0 prints
-    the line with what it has (the headline is complete by then) and every rank leaves with exit code 0 -- a leg that hangs
-    in a collective, or a rank that died in one, costs that leg, not the run."""
+    the line with what it has (the headline is complete by then; `lost_legs` names what is missing) and every rank leaves with
+    EXIT CODE 3 -- a leg that hangs in a collective, or a rank that died in one, costs that leg, and a harness that looks at the
+    exit code alone does not take the run for a clean one."""
 
     def __init__(self, rank, res):
         import threading
@@ -686,7 +687,7 @@ class Watchdog:
         self.timer = None
 
     def bail(self, what, why):
-        """give up on the remaining legs NOW: rank 0 prints the line as it stands, the process leaves with exit code 0"""
+        """give up on the remaining legs NOW: rank 0 prints the line as it stands, the process leaves with exit code 3"""
         with self.lock:
             if self.done:
                 return
@@ -697,7 +698,7 @@ class Watchdog:
                 print(json.dumps(self.res), flush=True)
         sys.stdout.flush()
         time.sleep(0 if self.rank == 0 else 3.0)
-        os._exit(0)
+        os._exit(3)
 
     def arm(self, seconds, what):
         import threading
@@ -786,6 +787,9 @@ def main():
         m = measure(make_frames(args.content, F, rank, distinct=min(F, 8)), args.tile_w, args.tile_h, planar, args.streams, args.steps, args.warmup,
                     local_rank, barrier=barrier)
         t = torch.tensor([m["dt"]], dtype=torch.float64, device="cuda")
+        every = torch.zeros(world, dtype=torch.float64, device="cuda")
+        every[rank] = m["dt"]
+        dist.all_reduce(every)  # every rank's own time for the same K steps (the line's value uses the slowest)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_all = float(t.item())
         res = None
@@ -793,6 +797,15 @@ def main():
             res = headline(args, dict(m, dt=dt_all, mpix=world * m["F"] * W4K * H4K * m["steps"] / dt_all / 1e6), world, planar)
             res["ranks_seen"] = dist.get_world_size()
             res["per_gpu_value"] = round(res["value"] / world, 2)
+            # what each rank did on its own GPU in the same timed region (MPix/s): the spread says whether one GPU held the others up
+            res["per_rank_one_gpu_value"] = [round(m["F"] * W4K * H4K * m["steps"] / float(e) / 1e6, 1) for e in every.tolist()]
+            try:
+                res["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:  # noqa: BLE001
+                res["rccl_version"] = f"unknown ({type(e).__name__})"
+            res["collective_backend"] = dist.get_backend()
+        if dist.get_world_size() != args.gpus:  # (cannot happen behind the check above; a line from fewer ranks must not look green)
+            raise SystemExit(4)
         dog = Watchdog(rank, res)
         dog.arm(args.legs_timeout, "c4_sharded + c5_replica_pcie")
         # ---- BASELINE config 4: strong scaling of sharded 8192^2 images, gather + scatter inside the timed region -------

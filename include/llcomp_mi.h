@@ -129,7 +129,9 @@ uint32_t llcomp_mi_slice_count(uint32_t w, uint32_t h, uint32_t c, uint32_t tile
  * trades a little compression (fresh models per slice) for it.  Returns 0 for nonsense arguments. */
 uint32_t llcomp_mi_suggest_tile_w(uint32_t frames, uint32_t w, uint32_t h, uint32_t c, uint32_t planar);
 /* FNV-1a-64 of a byte range (the checksum tests/golden records containers in); seed 0 starts a hash, a previous result
- * continues it over the next piece (header, slice table and payload of a container that lies in three buffers). */
+ * continues it over the next piece (header, slice table and payload of a container that lies in three buffers).  A running
+ * hash that happens to be 0 (probability 2^-64 per piece) cannot be told from "start" and would restart: good enough for a
+ * checksum of test vectors, not a keyed or adversarial hash. */
 uint64_t llcomp_mi_fnv1a64(const uint8_t* data, size_t len, uint64_t seed);
 /* Concatenator for multi-GPU sharding: `bands` are SLICED containers of consecutive horizontal bands of one
  * image (same width/channels/tile/planar; every band but the last a multiple of tile_h rows, because slices
@@ -150,6 +152,10 @@ int llcomp_mi_codec_create(llcomp_mi_codec** codec, int32_t device, uint32_t fra
 /* flags: LLCOMP_MI_FLAG_SMALL_MODEL */
 int llcomp_mi_codec_create_ex(llcomp_mi_codec** codec, int32_t device, uint32_t frames, uint32_t w, uint32_t h,
                               uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar, uint32_t flags);
+/* Does not wait for the device: the workspace is parked behind an event recorded on the stream of the codec's LAST encode /
+ * decode (whether that call succeeded or not) and is handed out again only after it.  That stream should outlive the work
+ * queued on it; if it is destroyed earlier (legal HIP: hipStreamDestroy drains it in the background) the library notices the
+ * dead event when the blocks are taken out again and drains the whole device instead. */
 void llcomp_mi_codec_destroy(llcomp_mi_codec* codec);
 uint32_t llcomp_mi_codec_slices(const llcomp_mi_codec* codec);        /* total = frames * slices per frame */
 uint64_t llcomp_mi_codec_workspace_bytes(const llcomp_mi_codec* codec);
@@ -228,7 +234,9 @@ int llcomp_mi_stream_submit_decode(llcomp_mi_stream* stream, const uint8_t* data
 int llcomp_mi_stream_pending(llcomp_mi_stream* stream); /* jobs submitted and not yet returned by wait */
 /* LLCOMP_MI_OK when llcomp_mi_stream_wait would not block (or nothing is pending), LLCOMP_MI_BUSY otherwise. */
 int llcomp_mi_stream_poll(llcomp_mi_stream* stream);
-/* Blocks until the OLDEST pending job has finished and describes it; BAD_ARGS when nothing is pending. */
+/* Blocks until the OLDEST pending job has finished and describes it; BAD_ARGS when nothing is pending.  Single consumer:
+ * wait / release / destroy of one pipeline object come from one thread (submits may come from another); the object's lock
+ * is released while wait blocks. */
 int llcomp_mi_stream_wait(llcomp_mi_stream* stream, llcomp_mi_stream_result* result);
 int llcomp_mi_stream_release(llcomp_mi_stream* stream, uint32_t slot);
 

@@ -106,6 +106,13 @@ void mark_done(llcomp_mi_codec* k, hipStream_t s) {
     if (!k->done) k->done = llcomp_mi::make_done_event();
     if (k->done && k->done->ev && hipEventRecord(k->done->ev, s) != hipSuccess) (void)hipGetLastError();
 }
+// ... from a scope guard, so that a call which fails AFTER it has launched kernels leaves the event behind them too (its
+// blocks must not be reused while those kernels still run)
+struct DoneGuard {
+    llcomp_mi_codec* k;
+    hipStream_t s;
+    ~DoneGuard() { mark_done(k, s); }
+};
 
 }  // namespace
 
@@ -253,6 +260,7 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
     if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Geometry& g = k->g;
+    DoneGuard done_guard{k, s};
     HIP_TRY(hipMemsetAsync(d_status, 0, 4, s));
     if (!snapshot_mode(g)) {  // (the snapshot encoder never touches the state tables: they are the decoder's alone)
         Timed t(k, s, 0);
@@ -288,7 +296,6 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
                                     static_cast<uint8_t*>(d_payload), payload_cap, static_cast<uint32_t*>(d_status), s));
     }
     ++k->n_encode;
-    mark_done(k, s);
     return LLCOMP_MI_OK;
 }
 
@@ -299,6 +306,7 @@ int llcomp_mi_codec_decode(llcomp_mi_codec* k, const void* d_payload, uint64_t p
     if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Geometry& g = k->g;
+    DoneGuard done_guard{k, s};
     HIP_TRY(hipMemsetAsync(d_status, 0, 4, s));
     {
         Timed t(k, s, 7);
@@ -331,7 +339,6 @@ int llcomp_mi_codec_decode(llcomp_mi_codec* k, const void* d_payload, uint64_t p
         }
     }
     ++k->n_decode;
-    mark_done(k, s);
     return LLCOMP_MI_OK;
 }
 

@@ -43,7 +43,7 @@ uint64_t llcomp_mi_fnv1a64(const uint8_t* data, size_t len, uint64_t seed) {
 // the GPU about four wavefronts per SIMD (1024 SIMDs x 64 lanes x 4 = 262 144 slices), never narrower than 64 pixels
 // (narrow slices cost compression: every slice starts with fresh models) and never wider than 480 (the throughput
 // default of bench.py).  Few-frame calls are latency-bound with wide slices: one 4K frame in 480x1 planes is 51 840
-// slices = 0.8 wavefronts per SIMD (2.1 ms); the width this returns, 96, gives 4 per SIMD.
+// slices = 0.8 wavefronts per SIMD (2.1 ms); the width this returns, 80, gives 4 per SIMD.
 uint32_t llcomp_mi_suggest_tile_w(uint32_t frames, uint32_t w, uint32_t h, uint32_t c, uint32_t planar) {
     if (!frames || !w || !h || !c) return 0;
     const uint64_t target = 262144;

@@ -147,7 +147,13 @@ hipError_t dev_alloc(void** p, uint64_t bytes) {
     }
     // the block's previous user may still have work in flight on some stream: wait for its completion event (outside
     // the lock; normally the event completed long ago and this returns at once)
-    if (wait_for && wait_for->ev) (void)hipEventSynchronize(wait_for->ev);
+    // If that wait FAILS -- the caller destroyed the stream the event was recorded on while work was pending (legal HIP),
+    // and the runtime answers with a sticky hipErrorCapturedEvent / invalid handle -- the event can say nothing any more:
+    // the error is cleared and the whole device is drained instead, so the block is never handed out on an unproven wait.
+    if (wait_for && wait_for->ev && hipEventSynchronize(wait_for->ev) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+    }
     return hipSuccess;
 }
 

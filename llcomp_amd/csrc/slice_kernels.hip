@@ -462,7 +462,7 @@ extern __shared__ __attribute__((aligned(32))) unsigned char dyn_lds[];
 constexpr uint32_t kRowsEncTabOff = 0, kRowsEncStageOff = 1024, kRowsEncBankOff = 1024 + 16 + 32 * 64;
 constexpr uint32_t kRowsEncLdsBytes = kRowsEncBankOff + 3 * 64 * 8;
 // rare: a carry that the block could not finish inside the staging area goes on into the bytes already stored to HBM
-__device__ __forceinline__ void enc_carry_back_flushed(RangeEnc& e) {
+[[maybe_unused]] __device__ __forceinline__ void enc_carry_back_flushed(RangeEnc& e) {
     for (int32_t k = e.flushed - 1; k >= 0; --k) {
         if (k >= e.cap) break;  // beyond the scratch capacity: the slice is reported as overflowed anyway
         uint8_t* g = unit_byte(e, uint32_t(k));
@@ -493,6 +493,10 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     uint32_t* rowbank;
     if constexpr (ASM) {
         static_assert(kStagePad == 16 && kStageBytes == 32, "kRowsEncBankOff");
+#ifdef LLMI_TEST_LDS_OFFSET  // guard build only (make guards): static LDS in front of the dynamic block -- the check below must fire
+        __shared__ uint32_t s_displace[4];
+        if (threadIdx.x < 4) reinterpret_cast<volatile uint32_t*>(s_displace)[threadIdx.x] = gpat != 0;
+#endif
         tab = reinterpret_cast<entry_t*>(dyn_lds + kRowsEncTabOff);
         stage = dyn_lds + kRowsEncStageOff;
         rowbank = reinterpret_cast<uint32_t*>(dyn_lds + kRowsEncBankOff);

@@ -347,22 +347,29 @@ int llcomp_mi_stream_wait(llcomp_mi_stream* s, llcomp_mi_stream_result* r) {
     // the size mailboxes of younger encode jobs keep arriving, and their container copies have to be queued when they do
     // or the D2H link idles.  Jobs run in submission order on lanes of equal speed, so the next event is the mailbox of
     // the oldest job that still lacks one, else the oldest job's final copy.  The mutex is released while blocked.
+    // One consumer: wait / release / destroy of one pipeline object come from ONE thread (include/llcomp_mi.h) -- the oldest
+    // job cannot change under this loop while the mutex is released.
     for (;;) {
         pump(s);
         if (sl.state == kFailed) break;
         hipEvent_t next = nullptr;
-        for (uint32_t j : s->fifo)
-            if (s->slots[j].state == kEncSizing) { next = s->slots[j].e1; break; }
-        if (!next) {
+        Slot* owner = &sl;  // the job whose event `next` is: a failed wait is charged to IT
+        if (sl.state == kCopying) {  // the oldest job's last copy is queued: a finished result goes out at once
             const hipError_t q = hipEventQuery(sl.e2);
             if (q == hipSuccess) break;
             if (q != hipErrorNotReady) { fail_job(sl, LLCOMP_MI_HIP_ERROR); break; }
-            next = sl.e2;
         }
+        for (uint32_t j : s->fifo)
+            if (s->slots[j].state == kEncSizing) { next = s->slots[j].e1; owner = &s->slots[j]; break; }
+        if (!next) next = sl.e2;
         lock.unlock();
         const hipError_t e = hipEventSynchronize(next);
         lock.lock();
-        if (e != hipSuccess) { fail_job(sl, LLCOMP_MI_HIP_ERROR); break; }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            fail_job(*owner, LLCOMP_MI_HIP_ERROR);
+            if (owner == &sl) break;
+        }
     }
     if (sl.state == kCopying && sl.kind == LLCOMP_MI_JOB_DECODE) sl.status = status_from_bits(uint32_t(sl.lane->h_meta[1]));
     s->fifo.pop_front();

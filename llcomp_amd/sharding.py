@@ -147,7 +147,8 @@ class ShardedCodec:
         self.per_row = self.ntx * (c if self.planar else 1)  # slices per tile row
         # no slice stream is longer than this (geometry.hpp: 13 bytes per sample + slack); lengths read from a container
         # are clamped to it before anything is sized or copied by them
-        self.slice_cap = (13 * self.tile_w * self.tile_h * (1 if self.planar else c) + 32 + 15) // 16 * 16
+        # (with geometry.hpp's ceiling: it goes to the device as a u32, and make_geometry caps a slice's capacity the same way)
+        self.slice_cap = min((13 * self.tile_w * self.tile_h * (1 if self.planar else c) + 32 + 15) // 16 * 16, 0x7FFFFFF0)
         self.nty = (h + self.tile_h - 1) // self.tile_h
         self.spf = self.per_row * self.nty                  # slices of one full image
         self.rows = [(t0 * self.tile_h, min(h, t1 * self.tile_h)) for t0, t1, o in self.chunks if o == self.rank]

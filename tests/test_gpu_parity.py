@@ -565,6 +565,29 @@ def test_one_row_slices_through_both_kernel_families(mi, orc, set_hook):
             assert np.array_equal(mi.decompress_image(s).pixels, img)
 
 
+def test_2d_encoder_snapshot_pass_or_state_tables_same_bytes(mi, orc, set_hook):
+    """Slices of several rows and at most 4096 samples are encoded through the state snapshot pass (context sort, walk,
+    unpermute: snapshot_kernels.hip); LLCOMP_MI_NOSNAP=1 keeps the per-slice state tables in HBM (the round-3 encoder, still
+    used for bigger slices).  Same bytes either way: ragged tiles, every channel count, interleaved and planar, both model
+    sizes, a slice of exactly 4096 samples, slices narrower than a lane group."""
+    cases = [(200, 150, 3, 64, 64, True), (200, 150, 3, 32, 32, False), (130, 67, 1, 64, 64, True), (97, 41, 2, 50, 21, False),
+             (300, 20, 4, 128, 8, True), (64, 64, 3, 64, 64, True), (37, 29, 4, 16, 16, False), (500, 9, 3, 480, 2, True)]
+    for i, (w, h, c, tw, th, planar) in enumerate(cases):
+        img = make_image("g3", w, h, c)
+        img[:, w // 2:] = make_image("nat" if i & 1 else "mid", w - w // 2, h, c)
+        for small in (False, True):
+            orc.set_small_model(small)
+            try:
+                want = orc.compress_sliced(img, tw, th, planar)
+            finally:
+                orc.set_small_model(False)
+            for nosnap in ("0", "1"):
+                set_hook("LLCOMP_MI_NOSNAP", nosnap)
+                s = mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar, small_model=small)
+                assert s == want, (w, h, c, tw, th, planar, small, nosnap)
+                assert np.array_equal(mi.decompress_image(s).pixels, img)
+
+
 def test_state_table_in_lds_or_hbm_same_bytes(mi, orc, set_hook):
     """With one slice per wavefront (a lone legacy stream, a few big tiles) the 63 KB state table of the slice lives in
     LDS; LLCOMP_MI_NOLDSTAB=1 keeps it in HBM like every multi-lane launch.  Same bytes either way, all channel counts."""

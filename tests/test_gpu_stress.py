@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 import pytest  # noqa: E402
 
-HOOKS = ("LLCOMP_MI_LANE_SHIFT", "LLCOMP_MI_NOROWS", "LLCOMP_MI_NOLDSTAB", "LLCOMP_MI_FORCE_REPLAY")
+HOOKS = ("LLCOMP_MI_LANE_SHIFT", "LLCOMP_MI_NOROWS", "LLCOMP_MI_NOLDSTAB", "LLCOMP_MI_FORCE_REPLAY", "LLCOMP_MI_NOSNAP")
 
 
 def make(rng, w, h, c, kind):
@@ -65,6 +65,8 @@ def run_case(mi, orc, seed, check_legacy):
         env["LLCOMP_MI_NOLDSTAB"] = "1"
     if rng.random() < 0.1:
         env["LLCOMP_MI_FORCE_REPLAY"] = "1"
+    if extra.random() < 0.3:  # the 2-D encoder with its state tables in HBM instead of the snapshot pass (same bytes)
+        env["LLCOMP_MI_NOSNAP"] = "1"
     for k in HOOKS:
         os.environ.pop(k, None)
     os.environ.update(env)
