@@ -41,8 +41,13 @@ VALU_PEAK = 1024 * 2.4e9 / 2  # wave-instructions/s: 256 CUs x 4 SIMDs, one VALU
 RMW_UBENCH = 24.06e9       # uniformly random dependent 8-byte read-modify-writes/s into 12.4 GB of per-lane tables at the wavefront count
                            # of the 2-D tile legs (3060): tools/ubench/rand_table.hip, profiles/r03_rand_table.txt.  NOT a ceiling for
                            # the kernels: their contexts are not uniformly random (lanes share lines, the decoder skips unchanged banks)
-TILE_HBM_BYTES_PER_SAMPLE = {"g3": 141.0, "nat": 156.0}  # (2 x FETCH_SIZE + WRITE_SIZE) of k_encode_slices + k_decode_slices / (2 x samples), the guide's gfx950
-                                                         # correction applied: profiles/r03_tiles64_f16_{g3,nat}_pmc_summary.txt (g3: 131 encode, 151 decode; nat: 147, 165)
+# HBM bytes per sample of the 2-D tile legs' kernels, (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction) / samples, from the
+# committed PMC passes of 16 frames / one pipeline (tools/prof_2d.sh).  encode_all_kernels = stage A 5.4 + k_snap_sort 8.0 + k_snap_walk
+# 12.0 + k_snap_unperm 22.0 + k_encode_slices + k_pack_payload; decode_all_kernels = k_stage_streams + k_decode_slices + k_from_lane_order
+# 4.0 + inverse stage A (3, not in the pass).  Round 3's encoder (state tables in HBM) moved 131 (g3) / 147 (nat) in k_encode_slices alone.
+TILE_HBM_SOURCE = "profiles/r04_tiles64_f16_{g3,nat}_pmc_summary.txt"
+TILE_HBM_BYTES_PER_SAMPLE = {"g3": {"k_encode_slices": 12.9, "encode_all_kernels": 63.6, "k_decode_slices": 152.5, "decode_all_kernels": 162.9},
+                             "nat": {"k_encode_slices": 10.7, "encode_all_kernels": 58.9, "k_decode_slices": 164.4, "decode_all_kernels": 172.3}}
 
 
 def make_frames(content, frames, rank, w=W4K, h=H4K, c=C4K, distinct=None):
@@ -931,20 +936,30 @@ def main():
                     also[f"{content}_default_slicing"] = brief(measure(make_frames(content, F, 0, distinct=4), args.tile_w, args.tile_h, planar, args.streams, sub, 1, local_rank),
                                                                workload=f"{F} frames 4K {content}, {args.tile_w}x{args.tile_h} planar")
 
-        def leg_tiles():  # 2-D tiles keep vertical prediction (and the reference's ratio); bound by random state-bank accesses in HBM
+        def leg_tiles():  # 2-D tiles keep vertical prediction (and the reference's ratio): the mode that runs llcomp's full context model
+            def sides(m):  # per launch (one pipeline's frames), summed over the kernels of a direction, from the library's own events
+                p, ne, nd = m["prof"], max(1, m["n_enc"]), max(1, m["n_dec"])
+                enc = {"stage_a": p["k_model_fwd"] / ne, "state_snapshot_pass": p["clear_states_enc"] / ne, "k_encode_slices": p["k_encode_slices"] / ne, "scan+pack": p["scan+pack"] / ne}
+                dec = {"scan+stage": p["k_scan_lengths_dec"] / nd, "k_decode_slices": p["k_decode_slices"] / nd, "stage_a_inverse": (p["k_model_inv"] + p["clear_states_dec"]) / nd}
+                return {"encode_ms_per_launch": {k_: round(v_, 3) for k_, v_ in enc.items()}, "encode_ms_per_launch_sum": round(sum(enc.values()), 3),
+                        "decode_ms_per_launch": {k_: round(v_, 3) for k_, v_ in dec.items()}, "decode_ms_per_launch_sum": round(sum(dec.values()), 3)}
+
             for content in ("nat", "mid", "g3"):
-                fr = frames_np[:16] if content == args.content else make_frames(content, 16, 0, distinct=4)
-                m2 = measure(fr, 64, 64, True, 2, sub, 1, local_rank)
-                samples = 2 * 16 * W4K * H4K * C4K * m2["steps"]  # at most one state-bank read-modify-write per sample and direction
-                extra = {}
-                if content in TILE_HBM_BYTES_PER_SAMPLE:  # HBM-side traffic of the slice kernels from the committed PMC passes of this leg's configuration
-                    gbs = TILE_HBM_BYTES_PER_SAMPLE[content] * samples / m2["dt"] / 1e9
-                    extra = {"hbm_bytes_per_sample": TILE_HBM_BYTES_PER_SAMPLE[content], "hbm_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 3)}
-                also[f"{content}_tiles64x64_16frames"] = brief(m2, workload=f"16 frames 4K {content}, 64x64 planar tiles, state tables in HBM (tagged with the call's generation, not cleared per call)",
-                                                               samples_per_s=round(samples / m2["dt"] / 1e9, 2), uniform_random_rmw_ubench=RMW_UBENCH / 1e9,
-                                                               ratio_to_uniform_random_rmw=round(samples / m2["dt"] / RMW_UBENCH, 3), **extra,
-                                                               note="bound by random state-bank transactions (one 128-byte line fill + partial write-back per sample), not by bytes: "
-                                                                    "ratio_to_uniform_random_rmw compares with a microbenchmark that does nothing else, at the same wavefront count and table size")
+                for frames, streams in ((16, 2), (48, 3)):  # round 3's leg (8 frames per pipeline: latency-bound) and the throughput configuration
+                    fr = frames_np[:frames] if content == args.content and frames <= len(frames_np) else make_frames(content, frames, 0, distinct=4)
+                    m2 = measure(fr, 64, 64, True, streams, sub, 1, local_rank)
+                    samples = 2 * frames * W4K * H4K * C4K * m2["steps"]
+                    extra = {}
+                    if content in TILE_HBM_BYTES_PER_SAMPLE:  # HBM-side traffic from the committed PMC passes of this configuration (one pipeline of 16 frames)
+                        t = TILE_HBM_BYTES_PER_SAMPLE[content]
+                        gbs = (t["encode_all_kernels"] + t["decode_all_kernels"]) / 2 * samples / m2["dt"] / 1e9
+                        extra = {"hbm_bytes_per_sample": t, "hbm_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 3), "hbm_source": TILE_HBM_SOURCE}
+                    also[f"{content}_tiles64x64_{frames}frames"] = brief(
+                        m2, workload=f"{frames} frames 4K {content}, 64x64 planar tiles, {streams} pipelines; encoder: state snapshot pass + sequential coder (no state "
+                                     f"table), decoder: per-slice state tables in HBM (generation-tagged)",
+                        samples_per_s=round(samples / m2["dt"] / 1e9, 2), **sides(m2), **extra,
+                        note="the decoder stays bound by random state-bank transactions (one 128-byte line fill + partial write-back per sample: the next context "
+                             "needs the sample just decoded); the encoder knows every context in advance and streams its states")
 
         def leg_latency():  # latency of ONE frame: at the throughput slicing, and at the width the library suggests for one frame per call
             m1 = measure(frames_np[:1], args.tile_w, args.tile_h, planar, 1, 20, 2, local_rank)

@@ -190,7 +190,9 @@ int llcomp_mi_device_range_sums(const void* d_vals, const void* d_start, const v
 uint32_t llcomp_mi_status_from_bits(uint32_t bits);
 /* Per-kernel timing with hipEvents recorded on the caller's stream around each launch (bench.py's roofline leg).
  * get_profile drains the stream, adds up the milliseconds since the last call and resets:
- *   ms[0] state-table clear  ms[1] stage A (k_model_*)  ms[2] k_encode_slices  ms[3] k_scan_groups + k_pack_payload
+ *   ms[0] state-table clear -- or, where the 2-D encoder replays its states ahead of the coder (slices of several rows and
+ *         at most 4096 samples), the state snapshot pass that replaces the tables: k_snap_sort + _walk + _unperm
+ *   ms[1] stage A (k_model_*)  ms[2] k_encode_slices  ms[3] k_scan_groups + k_pack_payload
  *   ms[4] k_group_sums + k_scan_groups + k_stage_streams (decode)  ms[5] k_decode_slices  ms[6] stage A inverse
  *   ms[7] state-table clear (decode) */
 int llcomp_mi_codec_set_profiling(llcomp_mi_codec* codec, int enable);

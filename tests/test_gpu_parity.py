@@ -551,6 +551,34 @@ def test_cli_roundtrip_matches_reference_behaviour(mi, orc, tmp_path):
     assert r.returncode == 1 and "Invalid magic number" in r.stderr
 
 
+def test_cli_config1_gradient_pgm_equals_reference_stream(mi, orc, tmp_path):
+    """BASELINE config 1 proper, through the tool: the 256x256 single-channel G2 gradient as a PGM file -> tools/llcompc ->
+    <file>.llcomp must be, byte for byte, what the REAL reference's compressImage gives for the same pixels (llcompc.cpp:25-41;
+    kat_streams.json g2-256-256-1: 1277 bytes, hex recorded) -- and tools/llcompd takes it back to the same pixels (the
+    reference's own decoder cannot: SURVEY D2, c < 3)."""
+    import os
+    import subprocess
+
+    from conftest import ROOT
+
+    exe_c, exe_d = os.path.join(ROOT, "tools", "llcompc"), os.path.join(ROOT, "tools", "llcompd")
+    if not (os.path.exists(exe_c) and os.path.exists(exe_d)):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")])
+    v = [x for x in KAT if (x["gen"], x["w"], x["h"], x["c"]) == ("g2", 256, 256, 1)][0]
+    img = make_image("g2", 256, 256, 1)
+    pgm = tmp_path / "c1.pgm"
+    pgm.write_bytes(b"P5\n256 256\n255\n" + img.tobytes())
+    assert subprocess.run([exe_c, str(pgm)]).returncode == 0
+    stream = (tmp_path / "c1.pgm.llcomp").read_bytes()  # llcompc.cpp:34: <path> + ".llcomp"
+    assert len(stream) == v["len"] == 1277 and fnv_hex(orc, stream) == v["fnv1a64"]
+    if "hex" in v:
+        assert stream.hex() == v["hex"]
+    assert subprocess.run([exe_d, str(tmp_path / "c1.pgm.llcomp")]).returncode == 0
+    from test_cli_image_io import decode_png_py
+
+    assert np.array_equal(decode_png_py((tmp_path / "c1.pgm.llcomp.png").read_bytes())[0], img)
+
+
 def test_one_row_slices_through_both_kernel_families(mi, orc, set_hook):
     """tile_h == 1 normally runs the register-resident kernels (+ the fused 16-bit-symbol stage A when planar);
     LLCOMP_MI_NOROWS=1 forces the same slicing through the general table-in-HBM kernels.  Same bytes either way."""
