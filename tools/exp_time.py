@@ -13,7 +13,8 @@ sys.path.insert(0, ROOT)
 lib = sys.argv[1] if len(sys.argv) > 1 else "product"
 if lib != "product":
     os.environ["LLCOMP_MI_LIB"] = os.path.abspath(lib)
-    os.environ["LLCOMP_BENCH_NOCHECK"] = "1"
+    if not os.environ.get("EXP_CHECK"):  # (diagnostic builds with wrong bytes on purpose; EXP_CHECK=1: this build must round-trip)
+        os.environ["LLCOMP_BENCH_NOCHECK"] = "1"
 import bench  # noqa: E402
 
 content = os.environ.get("EXP_CONTENT", "g3")
