@@ -25,6 +25,8 @@
 // 2.8 / 4.0 TB/s write / read with that mapping, 0.8 / 1.4 without; a slice's contiguous 32 KB at 5.8 / 6.2.)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device_common.hpp"
 #include "kernels.hpp"
 #include "snapshot.hpp"
@@ -37,11 +39,16 @@ namespace {
 __constant__ WalkTables c_walk = make_walk_tables();
 
 constexpr uint32_t kSortThreads = 256;
-constexpr uint32_t kOwn = kSnapMaxSamples / kSortThreads;  // 16 consecutive sort positions per thread
-constexpr uint32_t kRowPad = kSortThreads + 1;             // position p lives at (p % 16) * 257 + p / 16: a thread's own 16
-                                                           // positions and 64 consecutive positions both spread over the banks
-__device__ __forceinline__ uint32_t phys(uint32_t p) { return (p & (kOwn - 1)) * kRowPad + (p >> 4); }
-static_assert(kOwn == 16, "phys()");
+// A thread owns OWN consecutive sort positions: 16 for slices of up to 4096 samples, 8 / 4 for up to 2048 / 1024 (the passes cost
+// by the capacity, not by the slice: a 480x2 slice does not pay for 4096 keys).
+constexpr uint32_t kMaxOwn = kSnapMaxSamples / kSortThreads;
+constexpr uint32_t kRowPad = kSortThreads + 1;  // position p lives at (p % OWN) * 257 + p / OWN: a thread's own positions and 64
+                                                // consecutive positions both spread over the LDS banks
+template <uint32_t OWN>
+__device__ __forceinline__ uint32_t phys(uint32_t p) {
+    static_assert((OWN == 4 || OWN == 8 || OWN == 16) && OWN <= kMaxOwn, "a power of two");
+    return (p & (OWN - 1)) * kRowPad + p / OWN;
+}
 
 // workgroup -> slice, XCD-aware (workgroup i runs on XCD i % 8): the slices of one lane group go to ONE XCD, neighbouring lanes
 // to neighbouring slots, so the 32-byte pieces that share a cache line are moved through the same L2 at about the same time
@@ -82,7 +89,7 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t x) {
 // order) and counts its digits in PRIVATE counters cnt[digit / 2][t] (two 16-bit counters per word: all sums stay below 2^16).
 // The counters become start positions in (digit, thread) order -- every wavefront scans whole rows cnt[j][0..255], four
 // threads' counters per lane -- and every thread scatters its keys in order.
-template <int SH, int BITS>
+template <uint32_t kOwn, int SH, int BITS>
 __device__ __forceinline__ void sort_pass(const uint32_t* src, uint32_t* dst, uint32_t* cnt, uint32_t* tot) {
     constexpr uint32_t ND2 = (1u << BITS) / 2;  // packed counters per thread = rows
     static_assert(ND2 == 4 || ND2 == 8, "rows per wavefront");
@@ -134,7 +141,7 @@ __device__ __forceinline__ void sort_pass(const uint32_t* src, uint32_t* dst, ui
     for (uint32_t i = 0; i < kOwn; ++i) {
         const uint32_t old = atomicAdd(&cnt[slot[i]], inc[i]);
         const uint32_t pos = (old >> (((keys[i] >> SH) & 1u) * 16)) & 0xFFFFu;
-        dst[phys(pos)] = keys[i];
+        dst[phys<kOwn>(pos)] = keys[i];
     }
     __syncthreads();
 }
@@ -142,12 +149,13 @@ __device__ __forceinline__ void sort_pass(const uint32_t* src, uint32_t* dst, ui
 // entry of the sorted list: residual (10 bits, two's complement) | stream position << 10 | first-of-its-context << 22
 constexpr uint32_t kEntryPosShift = 10, kEntryFirstBit = 22;
 
+template <uint32_t kOwn>
 __global__ __launch_bounds__(kSortThreads) void k_snap_sort(const Geometry g, const uint32_t cap, const uint32_t* __restrict__ sym,
                                                            uint8_t* __restrict__ entries) {
     __shared__ uint32_t key_a[kOwn * kRowPad], key_b[kOwn * kRowPad];
     __shared__ uint32_t cnt[8 * kSortThreads];
     __shared__ uint32_t tot[8];
-    __shared__ int16_t res_of[kSnapMaxSamples];
+    __shared__ int16_t res_of[kOwn * kSortThreads];
     uint32_t id, group, lane;
     if (!block_slice(g, id, group, lane)) return;
     const Span sp = slice_span(g, id);
@@ -176,15 +184,15 @@ __global__ __launch_bounds__(kSortThreads) void k_snap_sort(const Geometry g, co
 #pragma unroll
         for (uint32_t i = 0; i < kOwn; ++i) {
             const uint32_t k = i * kSortThreads + t;
-            key_a[phys(k)] = ((v[i] & 0xFFFFu) << 12) | k;
+            key_a[phys<kOwn>(k)] = ((v[i] & 0xFFFFu) << 12) | k;
             res_of[k] = int16_t(v[i] >> 16);
         }
     }
     __syncthreads();
-    sort_pass<12, 4>(key_a, key_b, cnt, tot);
-    sort_pass<16, 3>(key_b, key_a, cnt, tot);
-    sort_pass<19, 3>(key_a, key_b, cnt, tot);
-    sort_pass<22, 3>(key_b, key_a, cnt, tot);
+    sort_pass<kOwn, 12, 4>(key_a, key_b, cnt, tot);
+    sort_pass<kOwn, 16, 3>(key_b, key_a, cnt, tot);
+    sort_pass<kOwn, 19, 3>(key_a, key_b, cnt, tot);
+    sort_pass<kOwn, 22, 3>(key_b, key_a, cnt, tot);
     // sorted: key_a.  Entries leave as 32-byte pieces of eight.
     uint8_t* const out = entries + size_t(group) * (size_t(cap) * 4 << g.lane_shift) + lane * 32u;
     // Four entries (16 bytes) per thread and turn, neighbouring threads the neighbouring chunks of a piece: a store instruction
@@ -192,10 +200,10 @@ __global__ __launch_bounds__(kSortThreads) void k_snap_sort(const Geometry g, co
     // WRITE_SIZE of this kernel read 2x its bytes while one thread wrote both halves of a piece in two instructions.)
     for (uint32_t c = t; c * 4 < sp.n; c += kSortThreads) {
         uint32_t e[4];
-        uint32_t prev = c ? key_a[phys(c * 4 - 1)] >> 12 : ~0u;
+        uint32_t prev = c ? key_a[phys<kOwn>(c * 4 - 1)] >> 12 : ~0u;
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
-            const uint32_t key = key_a[phys(c * 4 + j)];
+            const uint32_t key = key_a[phys<kOwn>(c * 4 + j)];
             const uint32_t k = key & 0xFFFu, ctx = key >> 12;
             e[j] = (uint32_t(res_of[k]) & 0x3FFu) | (k << kEntryPosShift) | (uint32_t(ctx != prev) << kEntryFirstBit);
             prev = ctx;
@@ -337,9 +345,8 @@ __global__ __launch_bounds__(kUnpermThreads) void k_snap_unperm(const Geometry g
     uint8_t* const rout = residuals + size_t(group) * (size_t(cap) * 2 << g.lane_shift) + lane * 32u;
     // out: 16-byte chunks, neighbouring threads the neighbouring chunks of a piece (whole sectors per store instruction, see
     // k_snap_sort)
-#pragma unroll
-    for (uint32_t u = 0; u < 4; ++u) {
-        const uint32_t c = q + kUnpermThreads * u;  // two banks
+    for (uint32_t u = 0; u < 4; ++u) {  // (the workgroup has a thread per eight samples of the capacity: four chunks of two banks each)
+        const uint32_t c = q + blockDim.x * u;
         if (c * 2 < n) *reinterpret_cast<uint4*>(bout + size_t(c >> 2) * (2 * row) + ((c & 3u) << 4)) = *reinterpret_cast<const uint4*>(&bank_of[c * 2]);
     }
     if (q * 8 < n) *reinterpret_cast<uint4*>(rout + size_t(q >> 1) * row + ((q & 1u) << 4)) = *reinterpret_cast<const uint4*>(&res_of[q * 8]);
@@ -356,11 +363,14 @@ hipError_t launch_snapshot(const Geometry& g, const uint32_t* d_sym, void* d_ent
     const uint32_t cap = snapshot_cap(g);
     const uint32_t groups = lane_groups(g);
     const uint32_t blocks = (((groups + 7u) >> 3) << 3) << g.lane_shift;  // whole rounds of eight lane groups (one per XCD)
-    k_snap_sort<<<dim3(blocks), dim3(kSortThreads), 0, stream>>>(g, cap, d_sym, static_cast<uint8_t*>(d_entries));
+    if (cap <= 4 * kSortThreads) k_snap_sort<4><<<dim3(blocks), dim3(kSortThreads), 0, stream>>>(g, cap, d_sym, static_cast<uint8_t*>(d_entries));
+    else if (cap <= 8 * kSortThreads) k_snap_sort<8><<<dim3(blocks), dim3(kSortThreads), 0, stream>>>(g, cap, d_sym, static_cast<uint8_t*>(d_entries));
+    else k_snap_sort<16><<<dim3(blocks), dim3(kSortThreads), 0, stream>>>(g, cap, d_sym, static_cast<uint8_t*>(d_entries));
     const uint32_t waves = (g.n_slices + g.lpw - 1) / g.lpw;
     k_snap_walk<<<dim3((waves + kWalkThreads / 64 - 1) / (kWalkThreads / 64)), dim3(kWalkThreads), 0, stream>>>(
         g, g.lpw, cap, static_cast<const uint8_t*>(d_entries), static_cast<uint8_t*>(d_sorted));
-    k_snap_unperm<<<dim3(blocks), dim3(kUnpermThreads), 0, stream>>>(g, cap, static_cast<const uint8_t*>(d_entries),
+    const uint32_t unperm_threads = std::min(kUnpermThreads, ((cap / 8 + 63u) / 64u) * 64u);  // a thread per eight samples of the capacity
+    k_snap_unperm<<<dim3(blocks), dim3(unperm_threads), 0, stream>>>(g, cap, static_cast<const uint8_t*>(d_entries),
                                                          static_cast<const uint8_t*>(d_sorted), static_cast<uint8_t*>(d_banks),
                                                          static_cast<uint8_t*>(d_residuals));
     return hipGetLastError();
