@@ -265,15 +265,16 @@ def brief(m, **extra):
 def profile_numbers(F, tile_w, tile_h, planar, content, S, dom):
     """HBM-side bytes and VALU instructions per launch of kernel `dom` from the committed rocprofv3 PMC passes of THIS
     configuration (profiles/*_traffic.json); (None, None, None) when no committed profile matches."""
-    for name in ("r03_default_traffic.json", "r03_single_stream_traffic.json", "r02_default_traffic.json", "r02_single_stream_traffic.json",
-                 "r01_default_traffic.json", "r01_single_stream_traffic.json"):
+    for name in ("r04_default_traffic.json", "r04_single_stream_traffic.json", "r03_default_traffic.json", "r03_single_stream_traffic.json",
+                 "r02_default_traffic.json", "r02_single_stream_traffic.json", "r01_default_traffic.json", "r01_single_stream_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
             same = all(tj["config"].get(k) == v for k, v in (("frames_per_step_per_gpu", F), ("tile_w", tile_w), ("tile_h", tile_h),
                                                             ("planar", planar), ("content", content), ("streams", S)))
             if same:
                 k = tj["per_launch"][dom]
-                return k.get("hbm_bytes_corrected"), k.get("valu_insts"), "profiles/" + name
+                # (the commit the profiled tree was at: the passes have to be re-run whenever the dominant kernel's source changes)
+                return k.get("hbm_bytes_corrected"), k.get("valu_insts"), "profiles/" + name + (" @ " + tj["profiled_at_commit"] if tj.get("profiled_at_commit") else "")
         except (OSError, KeyError, ValueError):
             pass
     return None, None, None

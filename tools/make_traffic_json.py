@@ -39,7 +39,15 @@ for (k, c), v in fetch.items():
     if (k, "SQ_INSTS_VALU") in sq1:  # VALU wave-instructions per launch (bench.py: roofline.valu_issue)
         out[short]["valu_insts"] = int(sq1[(k, "SQ_INSTS_VALU")])
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-doc = {"config": bench["config"], "bench_value": bench["value"], "kernel_ms_per_step": bench["kernel_ms_per_step"], "per_launch": out,
+try:  # the tree the passes ran on (run this script right behind the GPU call, before anything else is committed)
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    commit = subprocess.check_output(["git", "-C", here, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+    dirty = bool(subprocess.check_output(["git", "-C", here, "status", "--porcelain", "--", "llcomp_amd/csrc"], text=True).strip())
+    commit += "+uncommitted kernel sources" if dirty else ""
+except Exception:  # noqa: BLE001
+    commit = None
+doc = {"profiled_at_commit": commit, "config": bench["config"], "bench_value": bench["value"], "kernel_ms_per_step": bench["kernel_ms_per_step"], "per_launch": out,
        "correction": "bytes = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes); FETCH_SIZE = 1/2 of known read volume on this access pattern"}
 json.dump(doc, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
