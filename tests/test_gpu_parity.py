@@ -270,13 +270,13 @@ def test_model_kernel_matches_oracle_symbols(mi, orc, shape):
 
 
 # ---- device-resident batch codec --------------------------------------------------------------------------------
-def _batch_roundtrip(mi, orc, frames, w, h, c, tw, th, planar, gens):
+def _batch_roundtrip(mi, orc, frames, w, h, c, tw, th, planar, gens, small_model=False):
     import torch
 
     imgs = np.stack([make_image(gens[i % len(gens)], w, h, c) for i in range(frames)])
     for i in range(frames):
         imgs[i] = np.roll(imgs[i], i * 7, axis=1)
-    codec = mi.Codec(frames, w, h, c, tw, th, planar)
+    codec = mi.Codec(frames, w, h, c, tw, th, planar, small_model=small_model) if small_model else mi.Codec(frames, w, h, c, tw, th, planar)
     st = torch.cuda.current_stream().cuda_stream
     d_px = torch.from_numpy(imgs).cuda()
     cap = min(codec.max_payload_bytes, 2 * imgs.size + 64 * codec.n_slices + 4096)
@@ -614,6 +614,25 @@ def test_2d_encoder_snapshot_pass_or_state_tables_same_bytes(mi, orc, set_hook):
                 s = mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar, small_model=small)
                 assert s == want, (w, h, c, tw, th, planar, small, nosnap)
                 assert np.array_equal(mi.decompress_image(s).pixels, img)
+
+
+@pytest.mark.parametrize("tile", [(32, 32, True), (33, 31, True), (32, 33, True), (64, 32, True), (64, 33, True), (65, 63, True), (64, 64, True),
+                                  (1365, 3, True), (16, 21, False), (26, 26, False), (37, 37, False), (4, 2, True)],
+                         ids=lambda t: "%dx%d%s" % (t[0], t[1], "p" if t[2] else "i"))
+def test_snapshot_pass_capacity_classes(mi, orc, tile):
+    """The snapshot pass sorts a slice's samples in one of three capacity classes (1024 / 2048 / 4096 keys) and moves its arrays
+    in pieces of 8 / 16 samples: slices of exactly, one below and one above every boundary (planar: tile_w x tile_h samples;
+    interleaved RGB: x 3), a batch of three frames so that the slice count is no multiple of a lane group, ragged last tiles."""
+    tw, th, planar = tile
+    w, h = min(2 * tw + 5, 1400), 2 * th + 3
+    total = 0
+    for small in (False, True):
+        orc.set_small_model(small)
+        try:
+            total += _batch_roundtrip(mi, orc, 3, w, h, 3, tw, th, planar, ["g3", "nat", "mid"], small_model=small)
+        finally:
+            orc.set_small_model(False)
+    assert total > 0
 
 
 def test_state_table_in_lds_or_hbm_same_bytes(mi, orc, set_hook):
