@@ -198,6 +198,53 @@ def test_rows_path_edges(chunk):
         run_rows_case(mi, orc, 5000 + chunk * 25 + i)
 
 
+def run_tiles_case(mi, orc, seed):
+    """The 2-D encoder's snapshot pass (slices of several rows and at most 4096 samples) on images big enough for many lane
+    groups: random tile shapes around the capacity classes, 1..4 channels, planar and interleaved, contents from noise to
+    saturated checkerboards, either 2-D encoder."""
+    rng = np.random.default_rng(seed)
+    c = int(rng.integers(1, 5))
+    planar = bool(rng.integers(0, 2))
+    per = 1 if planar else c
+    target = int(rng.choice((60, 500, 1024, 1500, 2048, 3000, 4096))) // per  # pixels per tile
+    th = int(rng.integers(2, 70))
+    tw = max(1, min(target // th, 1400))
+    if tw * th * per > 4096:
+        tw = max(1, 4096 // (th * per))
+    w, h = int(rng.integers(tw, 4 * tw + 40)), int(rng.integers(th, 6 * th + 9))
+    w, h = min(w, 1500), min(h, 700)
+    img = make(rng, w, h, c, int(rng.integers(0, 5)))
+    env = {"LLCOMP_MI_NOSNAP": "1"} if rng.random() < 0.2 else {}
+    if rng.random() < 0.2:
+        env["LLCOMP_MI_LANE_SHIFT"] = str(int(rng.integers(0, 7)))
+    for k in HOOKS:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    mi.reload_tuning()
+    try:
+        want = orc.compress_sliced(img, tw, th, planar)
+        got = mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar)
+        assert got == want, f"tiles case {seed}: container differs ({w}x{h}x{c} tile {tw}x{th} planar={planar} env={env})"
+        assert np.array_equal(mi.decompress_image(got).pixels, img), f"tiles case {seed}: round trip"
+    finally:
+        for k in HOOKS:
+            os.environ.pop(k, None)
+        mi.reload_tuning()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", range(3))
+def test_tiles_snapshot_path(chunk):
+    """36 random cases per run on the 2-D tile path, byte-exact against the oracle and lossless."""
+    import llcomp_amd as mi
+    import orc as orc_mod
+
+    assert mi.device_count() >= 1, "GPU tests need a HIP device"
+    orc = orc_mod.Orc()
+    for i in range(12):
+        run_tiles_case(mi, orc, 7000 + chunk * 12 + i)
+
+
 def main():
     import llcomp_amd as mi
     import orc as orc_mod
@@ -208,6 +255,8 @@ def main():
     for i in range(cases):
         run_case(mi, orc, seed0 + i, check_legacy=(i % 7 == 0))
         run_rows_case(mi, orc, seed0 + i)
+        if i % 3 == 0:
+            run_tiles_case(mi, orc, seed0 + i)
         if i % 25 == 24:
             print(f"{i + 1} cases ok", flush=True)
     print(f"stress parity: {cases} cases ok (+ as many on the one-row path)")
