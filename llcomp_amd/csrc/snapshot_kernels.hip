@@ -2,7 +2,7 @@
 //
 // The reference codes one sample after the other and lets every bin read and update states[hash*8 + slot]
 // (llcomp.hpp:385, 439-444).  With one LANE per slice that table is 63 KB per lane: it lives in HBM, and every sample costs
-// a random 8-byte read-modify-write that moves a 128-byte line both ways (131 B per sample measured for 3 algorithmic).
+// a random 8-byte read-modify-write (131 B of HBM traffic per sample measured for 3 algorithmic).
 // But the ENCODER knows every (context, residual) of a slice before it codes anything, and the states do not depend on the
 // range coder at all: the eight states a sample will find in its context are a function of the earlier samples OF THAT
 // CONTEXT only.  So the table is replaced by three streaming steps, all of them coalesced:
@@ -11,11 +11,13 @@
 //   k_snap_walk    one lane per slice (64 slices per wavefront, like the coder): walks its slice's entries in that order with the
 //                  eight states of the current context in REGISTERS -- a context's samples are consecutive now, a new context
 //                  starts from zeros -- and leaves the bank as it stood BEFORE every sample; a sample's effect on the eight
-//                  states is nine table look-ups (walk_tables.hpp), no range arithmetic, no divergence;
+//                  states is ten byte look-ups (walk_tables.hpp), no range arithmetic, no divergence;
 //   k_snap_unperm  one workgroup per slice: puts the banks back into stream order through LDS.
 // The coder (slice_kernels.hip, k_encode_slices<..., SNAP>) then reads one 8-byte bank and one residual per sample, in order.
-// Every lane-per-slice <-> workgroup-per-slice hand-over uses the PIECE layout below, so that both sides move whole 32-byte
-// pieces and nothing is transposed in a pass of its own.
+// Every lane-per-slice <-> workgroup-per-slice hand-over uses the PIECE layout below, so that both sides move whole pieces and
+// nothing is transposed in a pass of its own.  STORES reach HBM per instruction, as 32-byte sectors (a lone 16-byte store costs
+// 32: WRITE_SIZE read 2x the bytes while a thread wrote a piece in several instructions), so every store instruction of these
+// kernels covers contiguous memory: neighbouring threads write neighbouring 16-byte chunks, the walk transposes through LDS.
 //
 // Piece layout of an array: [lane group][piece][lane][P bytes], P = 32 for the entries (eight u32) and the residuals (sixteen
 // i16), P = 64 for the banks (eight u64).  A wavefront of the lane-per-slice kernels reads element e of its 64 lanes from one
