@@ -84,8 +84,18 @@ def container(w, h, c, tile_w, tile_h, planar, payloads):
     return head + b"".join(struct.pack("<I", len(p)) for p in payloads) + b"".join(payloads)
 
 
-def slice_payloads(ref):
-    cases = [
+# round 4: slicings at the capacity classes of the 2-D encoder's snapshot pass (1024 / 2048 / 4096 samples per slice), the
+# benchmarked slicing for the photo-like content, four interleaved channels on a saturated checkerboard, one channel, ragged
+# tiles -- appended by `gen_golden.py slice_add` (the vectors above are not regenerated)
+SLICE_CASES_R4 = [
+    ("nat", 1920, 1080, 3, 128, 8, True), ("g3", 1920, 1080, 3, 32, 32, False), ("mid", 1920, 1080, 3, 480, 4, True),
+    ("nat", 3840, 2160, 3, 480, 1, True), ("checker", 640, 480, 4, 33, 31, False), ("g3", 1000, 700, 1, 64, 64, True),
+    ("nat", 1920, 1080, 3, 64, 32, True),
+]
+
+
+def slice_payloads(ref, cases=None):
+    cases = cases or [
         ("g1", 16, 16, 3, 8, 8, False), ("g1", 16, 16, 3, 8, 8, True), ("g1", 19, 13, 3, 8, 4, False), ("g1", 19, 13, 3, 8, 4, True),
         ("g3", 19, 13, 4, 5, 5, True), ("g3", 19, 13, 1, 5, 5, False), ("g3", 19, 13, 2, 19, 1, True), ("g1", 40, 6, 3, 40, 1, False),
         ("g1", 40, 6, 3, 40, 1, True), ("mid", 70, 50, 3, 32, 32, True), ("mid", 70, 50, 3, 32, 32, False), ("checker", 20, 20, 3, 7, 7, True),
@@ -263,6 +273,17 @@ def main():
             "generators": "oracle/orc.py GENERATORS (g1,g2,g3=std::mt19937(1234)&255,mid,checker) + const0/const255",
             "hash": "FNV-1a-64 over the bytes"}
     only = set(sys.argv[1:])  # e.g. `gen_golden.py decode` regenerates one file
+    if "slice_add" in only:  # append the round-4 slicings to slice_payloads.json, leaving what is there untouched
+        path = os.path.join(OUT, "slice_payloads.json")
+        doc = json.load(open(path))
+        have = {(v["gen"], v["w"], v["h"], v["c"], v["tile_w"], v["tile_h"], v["planar"]) for v in doc["vectors"]}
+        new = [cs for cs in SLICE_CASES_R4 if cs not in have]
+        if new:
+            doc["vectors"] += slice_payloads(ref, new)
+            with open(path, "w") as f:
+                json.dump(doc, f, indent=1)
+        print("slice_payloads.json:", len(new), "vectors added")
+        return
     for key, fn, make in (("kat", "kat_streams.json", kat_streams), ("slice", "slice_payloads.json", slice_payloads),
                           ("decode", "decode_behaviour.json", decode_behaviour)):
         if only and key not in only:

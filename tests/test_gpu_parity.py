@@ -416,7 +416,7 @@ def test_payload_capacity_overflow_is_reported(mi):
 
 
 # ---- full BASELINE sizes: golden hashes + size-independent properties -------------------------------------------
-@pytest.mark.parametrize("gen", ["g2", "g3", "mid"])
+@pytest.mark.parametrize("gen", ["g2", "g3", "mid", "nat"])
 def test_c3_4k_planar_tiles_golden_and_roundtrip(mi, orc, gen):
     v = [x for x in SLC if x["w"] == 3840 and x["gen"] == gen and x["planar"] and x["tile_w"] == 64][0]
     img = make_image(gen, 3840, 2160, 3)
