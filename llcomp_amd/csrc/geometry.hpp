@@ -131,6 +131,10 @@ inline bool make_geometry(Geometry& g, uint32_t frames, uint32_t w, uint32_t h, 
     g.slice_cap = uint32_t(cap < 0x7FFFFFF0ull ? cap : 0x7FFFFFF0ull);
     g.slice_samples = tile_w * tile_h * g.nch;
     g.lane_shift = tune.lane_shift >= 0 ? uint32_t(tune.lane_shift) : default_lane_shift(g.n_slices);
+    // A few hundred BIG slices (whole-image streams in bulk, one frame in 256x256 tiles): one slice per wavefront, so that every
+    // slice's 63 KB state table sits in LDS (two per CU: 512 fit the GPU at once) instead of HBM -- +13 % measured on 512 legacy
+    // streams and on one 4K frame in 256x256 tiles; smaller slices have the snapshot encoder and stay several to a wavefront.
+    if (tune.lane_shift < 0 && g.tile_h > 1 && g.slice_samples > kSnapMaxSamples && g.n_slices <= 512) g.lane_shift = 0;
     const uint32_t gw = 1u << g.lane_shift;
     g.lpw = gw;
     if (tune.lpw >= 1) {  // rounded down to a power of two: a wavefront never straddles lane groups
