@@ -439,12 +439,13 @@ def test_carries_through_ff_runs_match_oracle(mi, orc):
     thousands of times: the oracle counts its carries through 0xFF runs for this very input, the containers must agree
     byte for byte, and a run of 2+ bytes plus the number of events make a flush-boundary crossing certain."""
     img = make_image("g3", 1920, 1080, 3)
-    for tw, planar in ((480, True), (1920, False)):
+    # (64x64 and 32x32 tiles: the same through the 2-D encoder, whose hand-written sample is the snapshot form of the block)
+    for tw, th, planar in ((480, 1, True), (1920, 1, False), (64, 64, True), (32, 32, False)):
         orc.carry_stats(reset=True)
-        want = orc.compress_sliced(img, tile_w=tw, tile_h=1, planar=planar)
+        want = orc.compress_sliced(img, tile_w=tw, tile_h=th, planar=planar)
         runs, longest = orc.carry_stats()
         assert runs > 1000 and longest >= 2, (runs, longest)
-        got = mi.compress_image(img, 1920, 1080, 3, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=1, planar=planar)
+        got = mi.compress_image(img, 1920, 1080, 3, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar)
         assert got == want
         assert np.array_equal(mi.decompress_image(got).pixels, img)
 
