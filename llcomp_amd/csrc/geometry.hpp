@@ -38,6 +38,7 @@ enum : uint32_t {
     kGeoSmallModel = 8u,   // bitstream variant: the reference built with LargeModel = false (llcomp.hpp:21, 26-32, 427-429)
     kGeoSnapshot = 16u,    // 2-D slices of at most kSnapMaxSamples samples: the ENCODER streams state snapshots (snapshot_kernels.hip)
                            // instead of read-modify-writing a 63 KB table per slice in HBM; the decoder still needs that table
+    kGeoBankCache = 32u,   // 2-D decoder with tables in HBM: per-lane write-back cache of 32 state banks in LDS (slice_kernels.hip)
 };
 constexpr uint32_t kSnapMaxSamples = 4096;  // a slice's samples are sorted by context inside one workgroup's LDS
 
@@ -51,6 +52,7 @@ struct Tuning {
     bool noldstab = false;     // LLCOMP_MI_NOLDSTAB=1: single-slice launches keep their table in HBM
     bool force_replay = false; // LLCOMP_MI_FORCE_REPLAY=1
     bool nosnap = false;       // LLCOMP_MI_NOSNAP=1: the 2-D encoder keeps its state tables in HBM (the path before round 4)
+    bool nocache = false;      // LLCOMP_MI_NOCACHE=1: the 2-D decoder fetches and writes every state bank in HBM (the path before round 5)
 };
 inline Tuning tuning_from_env() {
     Tuning t;
@@ -67,8 +69,11 @@ inline Tuning tuning_from_env() {
     t.noldstab = flag("LLCOMP_MI_NOLDSTAB");
     t.force_replay = flag("LLCOMP_MI_FORCE_REPLAY");
     t.nosnap = flag("LLCOMP_MI_NOSNAP");
+    t.nocache = flag("LLCOMP_MI_NOCACHE");
     return t;
 }
+
+inline int bank_cache_log2(const Geometry& g) { return (g.flags & kGeoBankCache) ? 5 : 0; }
 
 // lane order: element k of slice `id` inside an array laid out [group][k][group width]
 LLMI_HD inline size_t lane_order_index(const Geometry& g, uint32_t id, uint32_t k) {
@@ -146,6 +151,8 @@ inline bool make_geometry(Geometry& g, uint32_t frames, uint32_t w, uint32_t h, 
     if (g.tile_h == 1 && !tune.norows && g.nch <= 4) g.flags |= kGeoRows;  // (the register-resident row kernels exist for 1..4 channels)
     else if (g.lpw == 1 && !tune.noldstab) g.flags |= kGeoLdsTable;
     else if (g.slice_samples <= kSnapMaxSamples && !tune.nosnap) g.flags |= kGeoSnapshot;
+    // The decoder of the families with tables in HBM (1..4 channels per slice): bank cache in LDS.
+    if (!(g.flags & (kGeoRows | kGeoLdsTable)) && g.nch <= 4 && !tune.nocache) g.flags |= kGeoBankCache;
     if (tune.force_replay) g.flags |= kGeoForceReplay;
     if (small_model) g.flags |= kGeoSmallModel;
     return true;

@@ -69,9 +69,34 @@ struct ProbeStamp {
 };
 #define LLMI_PROBE_START() ProbeStamp probe_stamp; probe_stamp.start()
 #define LLMI_PROBE_STOP(kernel) probe_stamp.stop(kernel)
+// Where a sample of the 2-D decoder spends its shader cycles: [block & mask][context arithmetic, bank fetch (issue -> data),
+// decoding, write-back + neighbour rotation]; every stamp drains the wavefront's LDS / scalar-memory queue (s_memtime is a
+// scalar-memory read), so the four parts are serialised -- a decomposition of the chain, not of the undisturbed kernel.
+__device__ unsigned long long g_probe_parts[kProbeSlots][4];
+struct PartClock {
+    unsigned long long acc[4] = {0, 0, 0, 0}, last;
+    __device__ __forceinline__ void start() { last = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void lap(int part) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        acc[part] += now - last;
+        last = now;
+    }
+    __device__ __forceinline__ void flush() {
+        if (threadIdx.x == 0)
+            for (int k = 0; k < 4; ++k) g_probe_parts[blockIdx.x & (kProbeSlots - 1)][k] = acc[k];
+    }
+};
+#define LLMI_PARTS_DECL() PartClock part_clock
+#define LLMI_PARTS_START() part_clock.start()
+#define LLMI_PARTS_LAP(part) part_clock.lap(part)
+#define LLMI_PARTS_FLUSH() part_clock.flush()
 #else
 #define LLMI_PROBE_START() do {} while (0)
 #define LLMI_PROBE_STOP(kernel) do {} while (0)
+#define LLMI_PARTS_DECL() do {} while (0)
+#define LLMI_PARTS_START() do {} while (0)
+#define LLMI_PARTS_LAP(part) do {} while (0)
+#define LLMI_PARTS_FLUSH() do {} while (0)
 #endif
 
 // ---- sensitivity experiments (make exp EXP=n: diagnostic builds for tools/exp_time.py, never shipped) -------------------
@@ -126,6 +151,10 @@ __device__ __forceinline__ void load_table(entry_t* tab) {
 }
 // the entry at an absolute LDS address taken from a half-entry / a wide row bank
 __device__ __forceinline__ entry_t lds_entry(uint32_t address) { return *reinterpret_cast<lds_entry_ptr>(uintptr_t(address)); }
+
+// s_waitcnt vmcnt(0) as an instruction hipcc's own wait-count pass sees (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt and
+// lgkmcnt left at their maxima): everything the wavefront has sent to vector memory is done afterwards, and the compiler knows it.
+__device__ __forceinline__ void drain_vector_memory() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 __device__ __forceinline__ uint32_t byte_of(uint32_t w, int k) { return (w >> (8 * k)) & 0xFF; }
 __device__ __forceinline__ uint32_t consume_here(uint32_t v);
@@ -894,6 +923,12 @@ __device__ __forceinline__ void dec_append(RangeDec& d) {  // requires window_lo
     d.win = ((0x100000000ull | ready) << sh) | rest;
     dec_prefetch(d);
 }
+// The checked replay's top-up (rare): the dword it requests is waited for at once, so that no request of the replay is still
+// in flight when the sample is done -- the sample loops can then rely on "nothing pending behind the last drain" (2-D decoder).
+__device__ __forceinline__ void dec_append_drained(RangeDec& d) {
+    dec_append(d);
+    drain_vector_memory();
+}
 __device__ __forceinline__ void dec_open(RangeDec& d, const uint32_t* group, uint32_t lane, uint32_t shift, uint32_t len) {
     d.gbase = reinterpret_cast<const char*>(group);
     d.ofs = lane * 4;
@@ -930,7 +965,7 @@ __device__ __forceinline__ void dec_refill(RangeDec& d) {
 }
 template <bool CHECKED>
 __device__ __forceinline__ bool dec_core(RangeDec& d, uint32_t P) {  // llcomp.hpp:98-121, branch-free refill
-    if (CHECKED && d.win <= 1) dec_append(d);  // no byte left
+    if (CHECKED && d.win <= 1) dec_append_drained(d);  // no byte left
     const uint32_t r1 = __umul24(d.range, P) >> 8;
     const uint32_t r0 = d.range - r1;
     uint32_t diff;
@@ -949,7 +984,7 @@ __device__ __forceinline__ bool dec_core(RangeDec& d, uint32_t P) {  // llcomp.h
 // Returns the half of entry `cur` that belongs to the decoded bit.
 template <bool CHECKED>
 __device__ __forceinline__ uint32_t dec_step_acc(RangeDec& d, uint32_t P, entry_t cur, uint32_t& w) {
-    if (CHECKED && d.win <= 1) dec_append(d);  // no byte left
+    if (CHECKED && d.win <= 1) dec_append_drained(d);  // no byte left
     const uint32_t r1 = __umul24(d.range, P) >> 8;
     const uint32_t r0 = d.range - r1;
     uint32_t diff, nx;
@@ -1006,7 +1041,7 @@ __device__ __forceinline__ bool dec_residual(RangeDec& d, Bank& bank, const entr
                 entry_t cur = E.e4;
                 int n = 0;  // bins of the unary tail: n - 1 ones and the closing zero
                 for (;;) {
-                    if (CHECKED && d.win <= 1) dec_append(d);
+                    if (CHECKED && d.win <= 1) dec_append_drained(d);
                     const uint32_t r1 = __umul24(d.range, prob_of(cur)) >> 8;
                     d.range -= r1;
                     ++n;
@@ -1092,7 +1127,16 @@ __device__ __forceinline__ bool dec_sample(RangeDec& d, Bank& bank, const entry_
     return ok;
 }
 
-template <int NCH, bool ROWS, bool LDSTAB = false>
+// CACHE (2-D slices with their tables in HBM): log2 of the entries of a per-lane, direct-mapped, write-back cache of state
+// banks in the dynamic LDS block -- banks u64 [entry][lane], then tags u8 [entry][lane] (tag = context >> CACHE, 0xFF = empty;
+// entry = context & (2^CACHE - 1)).  A hit costs two LDS reads and one LDS write instead of a 64-byte line fill and a 32-byte
+// sector write in HBM; a miss fills, and writes the victim back behind the sample.  Nothing is flushed at the end: the table is
+// per call (generation tags), whatever stays in LDS is not needed again.  32 entries = 18 KB per wavefront = eight wavefronts per
+// CU; 64 entries (four per CU) were measured slower whenever a launch has more than 1024 wavefronts and 1-3 % faster below
+// (profiles/r05_bank_cache_ab.txt).  0 = no cache.
+constexpr int kBankCacheLog2 = 5;
+constexpr uint32_t bank_cache_lds_bytes(int log2_entries) { return log2_entries ? (64u * 9u) << log2_entries : 0u; }
+template <int NCH, bool ROWS, bool LDSTAB = false, int CACHE = 0>
 __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const uint32_t lpw_and_flags,
                                                       const uint8_t* __restrict__ units,
                                                       const uint32_t* __restrict__ slice_len,
@@ -1100,7 +1144,12 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                                                       uint32_t* status, const uint64_t gpat) {
     __shared__ entry_t tab[128];  // (entries carry absolute LDS addresses, load_table: the hand-written loop needs no base)
     __shared__ uint32_t rowbank[ROWS ? kWideBankWords : 1];
+    static_assert(CACHE == 0 || (!ROWS && !LDSTAB && NCH != 0), "the bank cache belongs to the 2-D kernels with tables in HBM");
     clear_lds_states<LDSTAB>();
+    if constexpr (CACHE != 0) {  // every entry empty
+        uint32_t* tg = reinterpret_cast<uint32_t*>(dyn_lds + (512u << CACHE));
+        for (uint32_t i = threadIdx.x; i < (16u << CACHE); i += blockDim.x) tg[i] = 0xFFFFFFFFu;
+    }
     load_table(tab);
     const uint32_t lpw = lpw_and_flags & 0xFF;
     const bool replay_always = (lpw_and_flags >> 8) & 1;  // test hook: send every sample through the checked replay too
@@ -1235,7 +1284,34 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
         const ptrdiff_t up = ptrdiff_t(r.sw) * NCH * GW;  // one slice row back, in lane-order elements
         uint32_t held_ctx = ~0u;   // context of the previous sample; its updated bank is still in registers
         uint64_t held_bank = 0;
+        [[maybe_unused]] uint64_t wb_bank = 0;       // CACHE: the victim of this sample's miss, written back behind the decoding
+        [[maybe_unused]] uint64_t* wb_ptr = nullptr;
+        // CACHE: wave-uniform.  Every four rows from row 8 on the wavefront looks at the hit rate of the last four; content whose
+        // contexts do not come back soon enough (a dithered gradient: 1600 contexts in a 64x64 slice, 4 % hits behind the first
+        // rows) pays for the cache path without saving a transaction -- the entries are written back once and the rest of the
+        // slices runs on the plain path.  (profiles/r05_bank_cache_ab.txt)
+        [[maybe_unused]] bool use_cache = CACHE != 0;
+        [[maybe_unused]] uint32_t n_miss = 0, n_seen = 0;
+        LLMI_PARTS_DECL();
+        LLMI_PARTS_START();
         for (uint32_t y = 0; y < r.sh; ++y) {
+            if constexpr (CACHE != 0) {
+                const uint32_t yu = __builtin_amdgcn_readfirstlane(y);
+                if (use_cache && yu >= 8 && (yu & 3) == 0) {
+                    if (n_miss * 8 > n_seen * 7) {  // fewer than 1 hit in 8
+                        const uint64_t* c_banks = reinterpret_cast<const uint64_t*>(dyn_lds) + threadIdx.x;
+                        const uint8_t* c_tags = dyn_lds + (512u << CACHE) + threadIdx.x;
+#pragma unroll 1
+                        for (uint32_t e = 0; e < (1u << CACHE); ++e) {
+                            const uint32_t tg = c_tags[e * 64];
+                            if (tg != 0xFFu) banks[size_t((tg << CACHE) | e) << bsh] = bank_tagged<false>(c_banks[e * 64], gpat);
+                        }
+                        use_cache = false;
+                        held_ctx = ~0u;
+                    }
+                    n_miss = n_seen = 0;
+                }
+            }
             int16_t* row = p0 + ptrdiff_t(y) * up;
             int l[NCH], L[NCH], t[NCH], tl[NCH], tr[NCH], T[NCH];
 #pragma unroll
@@ -1245,6 +1321,9 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 tr[k] = (y > 0 && r.sw > 1) ? row[(k + NCH) * GW - up] : 0;
                 T[k] = y > 1 ? row[k * GW - 2 * up] : 0;
             }
+            // The row's first neighbours are waited for HERE, once per row.  Their first use is inside the sample loop, and a
+            // wait that hipcc places there runs for every sample -- as vmcnt(0), behind the stores of the sample before.
+            drain_vector_memory();
             for (uint32_t x = 0; x < r.sw; ++x) {
                 int16_t* q = row + ptrdiff_t(x) * NCH * GW;
                 int tr_n[NCH], T_n[NCH];
@@ -1264,8 +1343,46 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                     // most samples stay in the context of their predecessor, and when EVERY lane of the wavefront does, the
                     // table read -- the one memory round trip that hangs on the sample just decoded -- is skipped.  The test
                     // is wave-uniform: lanes never diverge here, and rough content pays one compare.
+                    uint64_t* c_bank = nullptr;
+#ifdef LLMI_CLOCK_PROBE
+                    asm volatile("" : "+v"(ctx));
+                    LLMI_PARTS_LAP(0);
+#endif
+                    if (CACHE != 0 && use_cache) {
+                        // bank and tag of the context's cache entry are requested together; on a miss the victim goes back to
+                        // the table (one sector write) and the context's bank is fetched (one line fill)
+                        const uint32_t entry = uint32_t(ctx) & ((1u << CACHE) - 1), want = uint32_t(ctx) >> CACHE;
+                        c_bank = reinterpret_cast<uint64_t*>(dyn_lds) + entry * 64 + threadIdx.x;
+                        uint8_t* c_tag = dyn_lds + (512u << CACHE) + entry * 64 + threadIdx.x;
+                        const uint32_t have = *c_tag;
+                        held_bank = *c_bank;
+                        n_miss += uint32_t(__popcll(__builtin_amdgcn_ballot_w64(have != want)));
+                        n_seen += uint32_t(__popcll(__builtin_amdgcn_ballot_w64(true)));
+                        if (have != want) {
+                            // (the victim leaves only behind this sample's decoding: a store issued here would sit in the
+                            // queue in front of the fill, and the fill's data come back in order behind it)
+                            if (have != 0xFFu) {
+                                wb_bank = bank_tagged<false>(held_bank, gpat);
+                                wb_ptr = banks + (size_t((have << CACHE) | entry) << bsh);
+                            }
+                            held_bank = bank_fresh<false>(banks[size_t(ctx) << bsh], gpat);
+                            *c_tag = uint8_t(want);
+                        }
+                    } else {
                     if (__builtin_amdgcn_ballot_w64(uint32_t(ctx) != held_ctx) != 0) held_bank = bank_fresh<LDSTAB>(banks[size_t(ctx) << bsh], gpat);
                     held_ctx = uint32_t(ctx);
+                    }
+#ifdef LLMI_CLOCK_PROBE
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(held_bank) : : "memory");
+                    LLMI_PARTS_LAP(1);
+#endif
+                    // ONE drain of the vector-memory queue per sample, where the bank is needed anyway: the neighbours requested for
+                    // the next sample, the stream dword requested by the top-up and the stores of the sample before are then all
+                    // known to be done, on every path (also when the table read was skipped) -- so hipcc needs no wait of its own at
+                    // the head of the next sample, where it would stand in front of the context arithmetic as vmcnt(0) right behind
+                    // this sample's stores and the neighbour loads just issued: a second memory round trip per sample, serialised
+                    // with the bank fetch (45 % of a sample's 11 000 cycles at 16 frames, profiles/r05_dec2d_parts.jsonl).
+                    drain_vector_memory();
                     Bank bank{{uint32_t(held_bank), uint32_t(held_bank >> 32)}, nullptr};
                     uint32_t v;
                     const bool ok = dec_sample<false>(d, bank, tab, hot, replay_always, v);
@@ -1273,8 +1390,18 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                         atomicOr(status, kStBadExponent);
                         return;  // this lane's slice is unusable; the whole call reports the error
                     }
-                        held_bank = uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32);
-                    banks[size_t(ctx) << bsh] = bank_tagged<LDSTAB>(held_bank, gpat);
+#ifdef LLMI_CLOCK_PROBE
+                    asm volatile("" : "+v"(v), "+v"(bank.w[0]), "+v"(bank.w[1]));
+                    LLMI_PARTS_LAP(2);
+#endif
+                    held_bank = uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32);
+                    if (CACHE != 0 && use_cache) {
+                        *c_bank = held_bank;
+                        if (wb_ptr) {
+                            *wb_ptr = wb_bank;
+                            wb_ptr = nullptr;
+                        }
+                    } else banks[size_t(ctx) << bsh] = bank_tagged<LDSTAB>(held_bank, gpat);
                     if (neg) v = 0u - v;
                     const int val = int(int16_t(uint32_t(predict(n)) + v));
                     q[k * GW] = int16_t(val);
@@ -1284,9 +1411,14 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                     t[k] = tr[k];
                     tr[k] = tr_n[k];
                     T[k] = T_n[k];
+#ifdef LLMI_CLOCK_PROBE
+                    asm volatile("" : "+v"(l[k]), "+v"(t[k]));
+                    LLMI_PARTS_LAP(3);
+#endif
                 }
             }
         }
+        LLMI_PARTS_FLUSH();
         }
     }
     LLMI_PROBE_STOP(1);
@@ -1304,6 +1436,11 @@ extern "C" uint32_t llcomp_mi_probe_read(unsigned long long* out) {
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe), zeros, sizeof(g_probe));
     }
     return kProbeSlots;
+}
+// the 2-D decoder's per-sample parts (u64[slots][4] shader cycles summed over a wavefront's samples)
+extern "C" void llcomp_mi_probe_read_parts(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe_parts), sizeof(g_probe_parts));
 }
 #endif
 
@@ -1385,6 +1522,20 @@ hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_units, const
     const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
     const uint32_t arg = lpw | ((g.flags & kGeoForceReplay) ? 0x100u : 0u);  // tests: rollback + checked replay everywhere
     const bool lds = states_in_lds(g);
+    if (bank_cache_log2(g) == kBankCacheLog2) {  // 2-D slices, tables in HBM, 1..4 channels: per-lane bank cache in LDS
+#define LLMI_DECODE_CACHED(NCHV)                                                                                          \
+    k_decode_slices<NCHV, false, false, kBankCacheLog2><<<dim3(blocks), dim3(64), bank_cache_lds_bytes(kBankCacheLog2), stream>>>( \
+        g, arg, d_units, d_slice_len, d_states, d_rec, d_status, gpat)
+        switch (g.nch) {
+            case 1: LLMI_DECODE_CACHED(1); break;
+            case 2: LLMI_DECODE_CACHED(2); break;
+            case 3: LLMI_DECODE_CACHED(3); break;
+            case 4: LLMI_DECODE_CACHED(4); break;
+            default: return hipErrorInvalidValue;
+        }
+#undef LLMI_DECODE_CACHED
+        return hipGetLastError();
+    }
     LLMI_DISPATCH_SLICE(g.nch, rows_mode(g), lds, {
         auto kernel = k_decode_slices<C, R, T>;
         if (T) {

@@ -25,5 +25,8 @@ int main() {
     Tuning norows; norows.norows = true;
     show("rows_forced_general", 4, 960, 64, 3, 480, 1, 1, norows);
     show("nine_channels_one_row", 2, 400, 20, 9, 100, 1, 0);
+    Tuning nocache; nocache.nocache = true;
+    show("tiles_4k_64x64_nocache", 16, 3840, 2160, 3, 64, 64, 1, nocache);
+    show("nine_channels_tiles", 16, 1920, 1080, 9, 32, 8, 0);
     return 0;
 }

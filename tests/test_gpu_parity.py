@@ -617,6 +617,40 @@ def test_2d_encoder_snapshot_pass_or_state_tables_same_bytes(mi, orc, set_hook):
                 assert np.array_equal(mi.decompress_image(s).pixels, img)
 
 
+def test_2d_decoder_bank_cache_or_plain_same_pixels(mi, orc, set_hook):
+    """The 2-D decoder keeps a per-lane write-back cache of 32 state banks in LDS (slice_kernels.hip, CACHE) and gives it up in
+    the middle of a slice when fewer than one access in eight hits; LLCOMP_MI_NOCACHE=1 fetches and writes every bank in HBM (the
+    path before round 5).  Same pixels either way, and the containers equal the oracle's: contents that stay cached (noise,
+    photo-like, flat), content that trips the bypass (dithered gradient: the slices are 40 rows high, the decision falls at rows
+    8, 12, ...), mixtures inside one wavefront, every channel count, interleaved and planar, both model sizes, slices above
+    4096 samples (the decoder is the same kernel there), batches of three frames on one codec object called twice (entries of the
+    first call must not leak into the second: tables are per call)."""
+    cases = [(640, 80, 3, 64, 40, True, "mid"), (640, 80, 3, 64, 40, True, "nat"), (640, 80, 1, 64, 40, True, "g3"), (520, 90, 3, 32, 45, False, "mid"),
+             (300, 150, 4, 40, 25, False, "g2"), (400, 100, 2, 50, 50, False, "mid"), (700, 140, 3, 128, 70, True, "mid"), (512, 64, 3, 64, 64, True, "checker")]
+    for i, (w, h, c, tw, th, planar, gen) in enumerate(cases):
+        img = make_image(gen, w, h, c)
+        if i & 1:
+            img[:, w // 2:] = make_image("g3", w - w // 2, h, c)  # half of the lanes of a wavefront keep hitting, the others do not
+        for small in ((False, True) if i < 4 else (False,)):
+            orc.set_small_model(small)
+            try:
+                want = orc.compress_sliced(img, tw, th, planar)
+            finally:
+                orc.set_small_model(False)
+            # (so few slices would get one wavefront each and their tables in LDS: the lane-group width is forced, 64 and 8 lanes)
+            for nocache, shift in (("0", "6"), ("0", "3"), ("1", "6")):
+                set_hook("LLCOMP_MI_NOCACHE", nocache)
+                set_hook("LLCOMP_MI_LANE_SHIFT", shift)
+                s = mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar, small_model=small)
+                assert s == want, (w, h, c, tw, th, planar, gen, small, nocache, shift)
+                assert np.array_equal(mi.decompress_image(s, small_model=small).pixels, img), (w, h, c, tw, th, planar, gen, small, nocache, shift)
+    set_hook("LLCOMP_MI_LANE_SHIFT", "6")
+    for nocache in ("0", "1"):
+        set_hook("LLCOMP_MI_NOCACHE", nocache)
+        for gens in (["mid", "g3", "nat"], ["nat", "mid", "mid"]):
+            assert _batch_roundtrip(mi, orc, 3, 260, 90, 3, 64, 45, True, gens) > 0
+
+
 @pytest.mark.parametrize("tile", [(32, 32, True), (33, 31, True), (32, 33, True), (64, 32, True), (64, 33, True), (65, 63, True), (64, 64, True),
                                   (1365, 3, True), (16, 21, False), (26, 26, False), (37, 37, False), (4, 2, True)],
                          ids=lambda t: "%dx%d%s" % (t[0], t[1], "p" if t[2] else "i"))

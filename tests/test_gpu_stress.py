@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 import pytest  # noqa: E402
 
-HOOKS = ("LLCOMP_MI_LANE_SHIFT", "LLCOMP_MI_NOROWS", "LLCOMP_MI_NOLDSTAB", "LLCOMP_MI_FORCE_REPLAY", "LLCOMP_MI_NOSNAP")
+HOOKS = ("LLCOMP_MI_LANE_SHIFT", "LLCOMP_MI_NOROWS", "LLCOMP_MI_NOLDSTAB", "LLCOMP_MI_FORCE_REPLAY", "LLCOMP_MI_NOSNAP", "LLCOMP_MI_NOCACHE")
 
 
 def make(rng, w, h, c, kind):
@@ -67,6 +67,8 @@ def run_case(mi, orc, seed, check_legacy):
         env["LLCOMP_MI_FORCE_REPLAY"] = "1"
     if extra.random() < 0.3:  # the 2-D encoder with its state tables in HBM instead of the snapshot pass (same bytes)
         env["LLCOMP_MI_NOSNAP"] = "1"
+    if extra.random() < 0.3:  # the 2-D decoder without its bank cache in LDS (same pixels)
+        env["LLCOMP_MI_NOCACHE"] = "1"
     for k in HOOKS:
         os.environ.pop(k, None)
     os.environ.update(env)
@@ -217,6 +219,8 @@ def run_tiles_case(mi, orc, seed):
     env = {"LLCOMP_MI_NOSNAP": "1"} if rng.random() < 0.2 else {}
     if rng.random() < 0.2:
         env["LLCOMP_MI_LANE_SHIFT"] = str(int(rng.integers(0, 7)))
+    if np.random.default_rng(seed ^ 0xC0DE).random() < 0.25:  # (own stream: the draws above define the same cases as before)
+        env["LLCOMP_MI_NOCACHE"] = "1"
     for k in HOOKS:
         os.environ.pop(k, None)
     os.environ.update(env)
