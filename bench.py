@@ -184,7 +184,7 @@ def measure(frames_np, tile_w, tile_h, planar, streams, steps, warmup, local_ran
 
     def check():
         torch.cuda.synchronize()
-        if os.environ.get("LLCOMP_BENCH_NOCHECK"):  # tools/exp_time.py with a diagnostic build whose bytes are wrong on purpose
+        if os.environ.get("LLCOMP_BENCH_NOCHECK"):  # tools/attic/exp_time.py with a diagnostic build whose bytes are wrong on purpose
             return
         for p in parts:
             assert int(p["st"][0].item()) == 0 and int(p["st"][1].item()) == 0, f"status {p['st'].tolist()}"
@@ -358,7 +358,7 @@ def c5_stream(frames_np, tile_w, tile_h, planar, depth=6, frames_per_job=8, pipe
     product's pipeline (llcomp_mi_stream_*, jobs of `frames_per_job` frames), `passes` times over the batch; every frame verified
     bit-exact.  `pipelines` stream objects, each driven by its own thread over its own share of the frames: one pipeline
     hands its results back in submission order and leaves the two DMA directions idle now and then.  Defaults = the shape
-    that was both fastest and steadiest in tools/c5_repeat.py (profiles/r03_c5_repeat.txt): two pipelines, jobs of 8 frames
+    that was both fastest and steadiest in tools/attic/c5_repeat.py (profiles/r03_c5_repeat.txt): two pipelines, jobs of 8 frames
     (200 MB copies), 6 slots, 2 encodes in flight each -- 5.65-6.07 GPix/s over five repetitions against 5.3-6.4 with jobs of
     4 frames in 8 slots; the link gives 97 GB/s with both directions busy = 7.1 GPix/s at 114 MB per frame."""
     import threading
@@ -428,7 +428,7 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     from llcomp_amd import sharding
 
     dev = torch.device("cuda", local_rank)
-    height = height or size  # (tools/c4_overhead.py codes bands of the config-4 image: one rank's share at N > 1, on one GPU)
+    height = height or size  # (tools/attic/c4_overhead.py codes bands of the config-4 image: one rank's share at N > 1, on one GPU)
     # 3, 2 or 1 part batches (measured on one GPU: 2, 3 and 6 parts all take 82 ms per step), each spreading its containers evenly over the ranks
     halves = next(p for p in ((parts,) if parts else ()) + (3, 2, 1) if images % p == 0 and (images // p) % world == 0 or p == 1)
     per = images // halves
@@ -462,7 +462,7 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
                 return fn(*a, **kw)
 
         if os.environ.get("LLCOMP_BENCH_C4_ORDER", "one-ahead") == "deep":
-            # every part's coding queued before the host waits for the first part's sizes.  Measured (tools/c4_overhead.py,
+            # every part's coding queued before the host waits for the first part's sizes.  Measured (tools/attic/c4_overhead.py,
             # profiles/r03_c4_overhead.jsonl): 2-3 % SLOWER than one part ahead at every modelled rank count -- the path's cost
             # beside the coding is not host latency
             for k in range(halves):
@@ -911,7 +911,7 @@ def main():
         want = lambda leg: not only or leg in only  # noqa: E731
         legacy_box = {}
 
-        def leg_c5():  # three repetitions: the pipeline's steady state is sensitive to how the copies of the jobs fall over each other (tools/c5_repeat.py)
+        def leg_c5():  # three repetitions: the pipeline's steady state is sensitive to how the copies of the jobs fall over each other (tools/attic/c5_repeat.py)
             link = dict(link0, measured="at the start of the process")
             c5_stream(frames_np, args.tile_w, args.tile_h, planar, passes=2)  # untimed: first touch of the pinned buffers, lanes, code objects
             runs = sorted((c5_stream(frames_np, args.tile_w, args.tile_h, planar, link=link) for _ in range(3)), key=lambda r: r["value"])

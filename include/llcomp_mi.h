@@ -158,6 +158,9 @@ int llcomp_mi_codec_create_ex(llcomp_mi_codec** codec, int32_t device, uint32_t 
  * dead event when the blocks are taken out again and drains the whole device instead. */
 void llcomp_mi_codec_destroy(llcomp_mi_codec* codec);
 uint32_t llcomp_mi_codec_slices(const llcomp_mi_codec* codec);        /* total = frames * slices per frame */
+/* Device bytes the codec can hold at most.  The per-slice state tables (decoding 2-D slices; 63 KB per slice) and the snapshot
+ * arrays of the 2-D encoder (22 B per sample) are allocated by the first call that needs them, so an encode-only or decode-only
+ * codec stays below this figure; that first call can return LLCOMP_MI_NOMEM. */
 uint64_t llcomp_mi_codec_workspace_bytes(const llcomp_mi_codec* codec);
 /* Upper bound on the packed payload bytes the codec can emit for any input (13 B per sample + slack). */
 uint64_t llcomp_mi_codec_max_payload_bytes(const llcomp_mi_codec* codec);

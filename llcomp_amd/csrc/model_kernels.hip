@@ -941,37 +941,7 @@ hipError_t launch_from_lane_order_i16(const Geometry& g, const int16_t* d_lanes,
 
 bool model_is_fused(const Geometry& g) { return g.planar && rows_mode(g) && g.c <= 4; }
 
-// Diagnostic builds (make exp EXP=20..23, tools/exp_time.py): after its first calls in the process one of the memory-bound kernels is
-// not launched any more -- its output buffers still hold the previous step's (identical) data, so the slice kernels do the same
-// work: what is left of the step says what that kernel costs BESIDE the slice kernels.  20 rows_fwd, 21 rows_inv, 22 pack, 23 stage.
-// (Only 21 and 22 are clean: the lane-order symbol array and the staged streams share their memory with the decoder's output /
-// the encoder's scratch, so without rows_fwd / stage the slice kernels find the other direction's data.  Measured: each of the
-// two costs 2.5-2.7 % of the three-pipeline step for 0.5-0.65 ms alone, profiles/r03_sensitivity.jsonl.)
-#ifndef LLMI_EXP
-#define LLMI_EXP 0
-#endif
-static bool exp_skip(int which, const void* out) {
-#if LLMI_EXP >= 20 && LLMI_EXP <= 24
-    if (LLMI_EXP == 24 || LLMI_EXP == 20 + which) {  // (per output buffer: every buffer is filled for real twice first)
-        static const void* seen[4][64];
-        static int calls[4][64];
-        for (int i = 0; i < 64; ++i) {
-            if (seen[which][i] == out) return ++calls[which][i] > 2;
-            if (!seen[which][i]) {
-                seen[which][i] = out;
-                calls[which][i] = 1;
-                return false;
-            }
-        }
-    }
-#endif
-    (void)which;
-    (void)out;
-    return false;
-}
-
 hipError_t launch_model_rows_fwd(const Geometry& g, const uint8_t* d_px, uint16_t* d_lanes, hipStream_t stream) {
-    if (exp_skip(0, d_lanes)) return hipSuccess;
     const uint64_t blocks = xcd_grid(lane_groups(g), (g.tile_w + 63) / 64);
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     LLMI_DISPATCH_C(g.c, (k_model_rows_fwd<C><<<dim3(uint32_t(blocks)), dim3(256), 0, stream>>>(g, d_px, d_lanes)));
@@ -979,7 +949,6 @@ hipError_t launch_model_rows_fwd(const Geometry& g, const uint8_t* d_px, uint16_
 }
 
 hipError_t launch_model_rows_inv(const Geometry& g, const int16_t* d_lanes, uint8_t* d_px, hipStream_t stream) {
-    if (exp_skip(1, d_px)) return hipSuccess;
     const uint64_t blocks = xcd_chunk_grid(lane_groups(g), (g.tile_w + 63) / 64);
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     LLMI_DISPATCH_C(g.c, (k_model_rows_inv<C><<<dim3(uint32_t(blocks)), dim3(256), 0, stream>>>(g, d_lanes, d_px)));
@@ -1032,7 +1001,6 @@ hipError_t launch_range_sums(const uint32_t* d_vals, const uint64_t* d_start, co
 hipError_t launch_pack_payload(const Geometry& g, const uint8_t* d_units, const uint32_t* d_slice_len,
                                const uint64_t* d_offsets, uint8_t* d_payload, uint64_t payload_cap,
                                uint32_t* d_status, hipStream_t stream) {
-    if (exp_skip(2, d_payload)) return hipSuccess;
     k_pack_payload<<<dim3(lane_groups(g)), dim3(256), 0, stream>>>(g, reinterpret_cast<const uint4*>(d_units), d_slice_len,
                                                                    d_offsets, d_payload, payload_cap, d_status);
     return hipGetLastError();
@@ -1041,7 +1009,6 @@ hipError_t launch_pack_payload(const Geometry& g, const uint8_t* d_units, const 
 hipError_t launch_stage_streams(const Geometry& g, const uint8_t* d_payload, uint64_t payload_bytes,
                                 const uint32_t* d_slice_len, const uint64_t* d_offsets, uint8_t* d_units,
                                 uint32_t* d_status, hipStream_t stream) {
-    if (exp_skip(3, d_units)) return hipSuccess;
     k_stage_streams<<<dim3(lane_groups(g)), dim3(256), 0, stream>>>(g, d_payload, payload_bytes, d_slice_len, d_offsets,
                                                                     reinterpret_cast<uint4*>(d_units), d_status);
     return hipGetLastError();

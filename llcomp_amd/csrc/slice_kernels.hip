@@ -99,31 +99,6 @@ struct PartClock {
 #define LLMI_PARTS_FLUSH() do {} while (0)
 #endif
 
-// ---- sensitivity experiments (make exp EXP=n: diagnostic builds for tools/exp_time.py, never shipped) -------------------
-//   1: four extra INDEPENDENT 2-cycle VALU instructions per bin   2: four extra scalar instructions per bin
-//   3: the encoder does not store its output bytes / the decoder does not refill (wrong bytes, same control flow)
-//   4: four extra independent 4-cycle (VOP3) VALU instructions per bin
-//   5: the encoder never looks for a carry into a held 0xFF (no compare + branch per renormalisation; rare wrong bytes)
-//   7: new states are not stored (the models never adapt: other bytes, same instruction stream minus the LDS byte stores)
-#ifndef LLMI_EXP
-#define LLMI_EXP 0
-#endif
-#ifndef LLMI_TABLE_LANE_MAJOR
-#define LLMI_TABLE_LANE_MAJOR 0
-#endif
-__device__ __forceinline__ void exp_pad() {
-#if LLMI_EXP == 1
-    uint32_t t;
-    asm volatile("v_mov_b32 %0, 1\n\tv_mov_b32 %0, 2\n\tv_mov_b32 %0, 3\n\tv_mov_b32 %0, 4" : "=v"(t));
-#elif LLMI_EXP == 2
-    uint32_t t;
-    asm volatile("s_mov_b32 %0, 1\n\ts_mov_b32 %0, 2\n\ts_mov_b32 %0, 3\n\ts_mov_b32 %0, 4" : "=s"(t));
-#elif LLMI_EXP == 4
-    uint32_t t;
-    asm volatile("v_add3_u32 %0, 1, 2, 3\n\tv_add3_u32 %0, 1, 2, 3\n\tv_add3_u32 %0, 1, 2, 3\n\tv_add3_u32 %0, 1, 2, 3" : "=v"(t));
-#endif
-}
-
 // ---- model table ------------------------------------------------------------------------------------------------
 // entry = entry_lo | entry_hi << 32 (tables.hpp), always moved as ONE 64-bit LDS access
 using entry_t = unsigned long long;
@@ -193,9 +168,6 @@ __device__ __forceinline__ uint32_t wide_offset(const uint32_t (&w)[4]) {
 }
 template <int SLOT, bool INLDS>
 __device__ __forceinline__ void put_state(Bank& b, uint32_t ns) {  // ns: new state in byte 0
-#if LLMI_EXP == 7
-    if constexpr (INLDS) return;
-#endif
     if constexpr (INLDS) b.lds[rowbank_byte(SLOT)] = uint8_t(ns);
     else set_slot_state<SLOT>(b.w, ns & 0xFF);
 }
@@ -328,19 +300,14 @@ __device__ __forceinline__ void enc_carry_back(RangeEnc& e) {
 // The held byte is stored straight out of bits 16..23 of `low` (ds_write_b8_d16_hi), then the 16 low bits move up by 8:
 // the old bits 8..15 become the new held byte.
 __device__ __forceinline__ void enc_renorm(RangeEnc& e) {
-    exp_pad();
     if (e.range < 0x100) {
-#if LLMI_EXP != 3
         asm volatile("ds_write_b8_d16_hi %0, %1" : : "v"(e.wp), "v"(e.low) : "memory");
-#endif
         // held was 0xFF and a carry arrived: rare, so the test is a wave-uniform branch (no exec bookkeeping when no
         // lane needs it)
-#if LLMI_EXP != 5
         const bool wrapped = e.low > 0xFFFFFFu;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(wrapped) != 0, 0)) {
             if (wrapped) enc_carry_back(e);
         }
-#endif
         ++e.wp;
         asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
             : "=v"(e.low) : "v"(8u), "v"(e.low));  // (low & 0xFFFF) << 8
@@ -659,73 +626,6 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
         uint32_t sofs = (id & ((1u << g.lane_shift) - 1)) * uint32_t(sizeof(SYM)), sstep = uint32_t(sizeof(SYM)) << g.lane_shift;
         asm volatile("" : "+v"(sstep));  // (a vector value: a VALU add with a scalar operand costs twice as much)
         auto load_sym = [&](uint32_t ofs) -> uint32_t { return *reinterpret_cast<const SYM*>(gsym + ofs); };
-#if LLMI_EXP == 30
-        // EXPERIMENT, never shipped (make exp EXP=30 XFLAGS=-DLLMI_ASM_ENC=0; profiles/r04_lockstep_ab.jsonl): the lanes of a
-        // wavefront DECOUPLED -- every iteration each lane codes ONE bin of whatever sample and phase it is in (a
-        // per-lane phase state machine), so a sample costs a lane its own 2*exponent + 3 iterations instead of the wavefront's
-        // 2*max(exponent) + 3 slots.  The price: the slot is a per-lane LDS index (state byte and entry are two dependent LDS
-        // reads per bin), the symbol fetch is a per-lane gather (lanes drift apart), and the per-sample prologue -- fetch, context,
-        // binarisation into a bin program, flush test -- runs in nearly every iteration, because some lane starts a sample in 99 %.
-        {
-            // the sequence of slots of a sample with exponent ex, three bits per bin, first bin lowest (llcomp.hpp:166-206)
-            __shared__ unsigned long long s_slots[9];
-            for (uint32_t ex = 0; ex < 9 && threadIdx.x == 0; ++ex) {  // (lane 0 always owns a slice)
-                unsigned long long p = 0;  // bin 0: slot 0
-                uint32_t at = 1;
-                for (uint32_t i = 1; i <= ex + 1; ++i, ++at) p |= (unsigned long long)(i < 4 ? i : 4) << (3 * at);  // unary: ex ones + a zero
-                if (ex > 0) { p |= 5ull << (3 * at); ++at; }
-                for (uint32_t i = 1; i < ex; ++i, ++at) p |= 6ull << (3 * at);
-                p |= 7ull << (3 * at);
-                s_slots[ex] = p;
-            }
-            __syncthreads();
-            uint8_t* const mybank = reinterpret_cast<uint8_t*>(rowbank) + threadIdx.x * 4;
-            uint32_t k = 0, nb = 0, word = 0, bofs = 0;
-            unsigned long long slots = 0;
-            uint32_t nxt = load_sym(sofs);
-            sofs += sstep;
-            for (;;) {
-                if (nb == 0) {
-                    if (k >= total) break;
-                    const uint32_t sy = nxt;
-                    ++k;
-                    if (k < total) nxt = load_sym(sofs);
-                    sofs += sstep;
-                    int res;
-                    if constexpr (sizeof(SYM) == 2) {
-                        bofs = (sy >> 3) & 0x600u;
-                        res = int(sy << 20) >> 20;
-                    } else {
-                        bofs = (((sy & 0xFFFF) * 109u) >> 7) & 0x600u;
-                        res = int(sy) >> 16;
-                    }
-                    if (e.wp >= e.base + 16) enc_flush16(e);
-                    if (res == 0) {
-                        word = 1; nb = 1; slots = 0;
-                    } else {
-                        const uint32_t a = uint32_t(res < 0 ? -res : res);
-                        const uint32_t ex = 31u - uint32_t(__clz(int(a)));
-                        const uint32_t man = ex ? __brev(a & ((1u << ex) - 1u)) >> (32 - ex) : 0u;  // mantissa, MSB first
-                        word = (((1u << ex) - 1u) << 1) | (man << (ex + 2)) | (uint32_t(res < 0) << (2 * ex + 2));
-                        nb = 2 * ex + 3;
-                        slots = s_slots[ex];
-                    }
-                }
-                const uint32_t bit = word & 1u, slot = uint32_t(slots) & 7u;
-                word >>= 1;
-                slots >>= 3;
-                --nb;
-                uint8_t* const sp = mybank + bofs + ((slot >> 2) << 8) + (slot & 3u);
-                const entry_t en = tab[*sp];
-                const uint32_t m = 0u - bit;
-                enc_core(e, prob_of(en), m);
-                *sp = uint8_t(successor_m(en, m));
-            }
-        }
-        constexpr bool kDecoupledDone = true;
-#else
-        constexpr bool kDecoupledDone = false;
-#endif
         uint32_t s0 = load_sym(sofs);
         sofs += sstep;
         uint32_t s1 = total > 1 ? load_sym(sofs) : 0;
@@ -769,8 +669,8 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
         // the loop with the tests.
         const uint32_t total0 = __builtin_amdgcn_readfirstlane(total);
         const bool same = __builtin_amdgcn_ballot_w64(total != total0) == 0;
-        const uint32_t n_bulk = kDecoupledDone ? 0 : same && total0 > 2 ? total0 - 2 : 0;
-        uint32_t i = kDecoupledDone ? total : 0;
+        const uint32_t n_bulk = same && total0 > 2 ? total0 - 2 : 0;
+        uint32_t i = 0;
         for (; i < n_bulk; ++i) {
             s0 = consume_here(s0);  // loaded two samples ago
             const uint32_t s2 = load_sym(sofs);
@@ -804,13 +704,8 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
             banks = reinterpret_cast<uint64_t*>(dyn_lds);
             bsh = 0;
         } else {
-#if LLMI_TABLE_LANE_MAJOR  // experiment: a slice's table contiguous ([lane][context]) instead of context-major inside the lane group
-            banks = states + size_t(id) * kContexts;
-            bsh = 0;
-#else
             banks = states + ((size_t(id >> g.lane_shift) * kContexts) << g.lane_shift) + (id & ((1u << g.lane_shift) - 1));
             bsh = g.lane_shift;
-#endif
         }
         uint32_t fk = 0;
         auto fetch = [&]() -> uint32_t { return p0[size_t(fk++) * GW]; };
@@ -956,7 +851,6 @@ __device__ __forceinline__ unsigned long long window_next(unsigned long long w) 
 }
 // Refill inside ONE exec-masked region with constant shift amounts (llcomp.hpp:115-120).
 __device__ __forceinline__ void dec_refill(RangeDec& d) {
-    exp_pad();
     if (d.range < 0x100) {
         d.range <<= 8;
         d.low = (d.low << 8) | (uint32_t(d.win) & 0xFF);  // low < range < 0x100 here
@@ -1243,13 +1137,8 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
             banks = reinterpret_cast<uint64_t*>(dyn_lds);
             bsh = 0;
         } else {
-#if LLMI_TABLE_LANE_MAJOR  // experiment: a slice's table contiguous ([lane][context]) instead of context-major inside the lane group
-            banks = states + size_t(id) * kContexts;
-            bsh = 0;
-#else
             banks = states + ((size_t(id >> g.lane_shift) * kContexts) << g.lane_shift) + (id & ((1u << g.lane_shift) - 1));
             bsh = g.lane_shift;
-#endif
         }
         if constexpr (NCH == 0) {
             // Any channel count (c > 4, channels interleaved): the plain form -- all six neighbours are read back from the

@@ -8,7 +8,8 @@
 
 namespace llcomp_mi {
 
-// kGeoSnapshot is set (geometry.hpp) for slices of more than one row and at most kSnapMaxSamples samples that share a wavefront.
+// kGeoSnapshot is set (geometry.hpp) for slices of at most kSnapMaxSamples samples that share a wavefront and do not run the
+// one-row kernels: slices of several rows, and one-row slices that miss those kernels (more than four channels, LLCOMP_MI_NOROWS).
 bool snapshot_mode(const Geometry& g);
 // sample capacity of one slice in the piece-layout arrays (a multiple of 16) and elements per array (all lane groups)
 uint32_t snapshot_cap(const Geometry& g);

@@ -303,12 +303,18 @@ __global__ __launch_bounds__(kWalkThreads) void k_snap_walk(const Geometry g, co
         ob[1 * 64 + l] = o1;
         ob[2 * 64 + l] = o2;
         ob[3 * 64 + l] = o3;
+        // (the transpose goes from lane to lane inside one wavefront: the fence + wave barrier pin the order of its LDS accesses
+        // for the compiler and compile to nothing)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         uint4* const q = reinterpret_cast<uint4*>(bbase + size_t(r) * (2 * row) + first_in_group * 64u) + l;  // the wavefront's first piece, chunk l
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
             const uint32_t c = j * 64 + l;  // chunk c of the 4 KB belongs to lane c / 4, part c % 4
             if ((c >> 2) < lanes_here) q[j * 64] = ob[(c & 3u) * 64 + (c >> 2)];
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -290,9 +290,10 @@ class ShardedCodec:
         if m_max <= self.MAX_MESSAGE:  # (m_max = the largest message of ANY rank pair: the same decision on every rank)
             dist.all_to_all_single(recv[: sum(recv_split)], src, output_split_sizes=recv_split, input_split_sizes=send_split, group=self.group)
             return recv.to(self.device)
-        # A message beyond MAX_MESSAGE bytes goes in rounds of at most that many bytes per peer (a 2 GB self-message of one
-        # RCCL rank came back damaged on the MI355X box; real multi-rank messages are far smaller).  Every rank derives the
-        # same number of rounds from the same message matrix, so the collectives stay matched.
+        # A message beyond MAX_MESSAGE bytes goes in rounds of at most that many bytes per peer: a self-message above 1 GiB
+        # arrives with only its first half written (RCCL 2.26.6, all_to_all_single and send/recv alike, deterministic:
+        # profiles/r04_rccl_self_message.txt); real multi-rank messages are far smaller.  Every rank derives the same number of
+        # rounds from the same message matrix, so the collectives stay matched.
         rounds = -(-int(m_max) // self.MAX_MESSAGE)
         s_off = np.concatenate([[0], np.cumsum(send_split)]).astype(np.int64)
         r_off = np.concatenate([[0], np.cumsum(recv_split)]).astype(np.int64)

@@ -113,6 +113,22 @@ def test_more_than_four_channels_match_oracle(mi, orc, c):
             assert np.array_equal(mi.decompress_image(t).pixels, img)
 
 
+@pytest.mark.parametrize("c", [5, 7])
+def test_more_than_four_channels_through_the_snapshot_pass(mi, orc, c):
+    """Interleaved slices with more than four channels miss the one-row kernels and the specialised 2-D kernels; once there are
+    enough of them to share wavefronts (>= 192 slices) they take the snapshot encoder with the generic symbol path -- one-row
+    slices and 2-D tiles, the decoder reading its neighbours back from memory.  Containers == the oracle's, round trips lossless."""
+    rng = np.random.default_rng(900 + c)
+    w, h = 260, 48
+    y, x, k = np.meshgrid(np.arange(h), np.arange(w), np.arange(c), indexing="ij")
+    img = ((x * 3 + y * 5 + k * 29 + rng.integers(-3, 4, size=(h, w, c))) & 0xFF).astype(np.uint8)
+    img[:, w // 2:] = rng.integers(0, 256, size=(h, w - w // 2, c), dtype=np.uint8)
+    for tw, th in ((52, 1), (20, 12), (9, 5)):  # 240 one-row slices, 52 x 4 = 208 tiles, 29 x 10 = 290 tiles
+        t = mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=False)
+        assert t == orc.compress_sliced(img, tw, th, False), (tw, th)
+        assert np.array_equal(mi.decompress_image(t).pixels, img), (tw, th)
+
+
 @pytest.mark.parametrize("v", SMALL, ids=lambda v: v["kind"] + "-" + _id(v))
 def test_small_model_equals_reference_built_with_largemodel_false(mi, orc, v):
     """the bitstream of a reference built with `LargeModel = false` (llcomp.hpp:21, 26-32, 427-429).  Golden

@@ -5,8 +5,8 @@
 out=gpurun_out/${1:-tiles_ab}
 contents=${2:-g3 nat mid}
 streams=${3:-1}
-mkdir -p $out
 cd $GRAFT_REPO_ROOT
+mkdir -p $out
 for c in $contents; do
   A="--no-cpu-baseline --no-also --frames 16 --streams $streams --tile-w 64 --tile-h 64 --steps 5 --warmup 2 --content $c"
   timeout -k 10 300 python3 bench.py $A > $out/snap_$c.json 2> $out/snap_$c.err || exit 1

@@ -4,8 +4,8 @@
 out=gpurun_out/${1:-tiles_sweep}
 c=${2:-g3}
 cfgs=${3:-"16:1 16:2 32:2 48:3"}
-mkdir -p $out
 cd $GRAFT_REPO_ROOT
+mkdir -p $out
 for cfg in $cfgs; do
   f=${cfg%%:*}; s=${cfg##*:}
   A="--no-cpu-baseline --no-also --no-isolated --frames $f --streams $s --tile-w ${TW:-64} --tile-h ${TH:-64} --steps 4 --warmup 2 --content $c"

@@ -5,8 +5,8 @@ out=gpurun_out/${1:-lib_ab}
 other=$2
 args=$3
 reps=${4:-2}
-mkdir -p $out
 cd $GRAFT_REPO_ROOT
+mkdir -p $out
 for r in $(seq 1 $reps); do
   timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-also --no-isolated $args > $out/base_$r.json 2> $out/base_$r.err || exit 1
   LLCOMP_MI_LIB=$PWD/$other timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-also --no-isolated $args > $out/other_$r.json 2> $out/other_$r.err || exit 1

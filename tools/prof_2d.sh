@@ -4,8 +4,8 @@
 out=gpurun_out/${1:-prof_2d}
 content=${2:-g3}
 export TMPDIR=/tmp
-mkdir -p $out
 cd $GRAFT_REPO_ROOT
+mkdir -p $out
 A="--no-cpu-baseline --no-isolated --no-also --frames 16 --streams 1 --tile-w 64 --tile-h 64 --steps 3 --warmup 1 --content $content"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $A > $out/bench_under_trace.json 2> $out/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py $A > /dev/null 2> $out/f.err
