@@ -153,3 +153,32 @@ def test_sharded_path_world2_rccl():
                      (("mid", 640, 360, 3), (64, 64), True, 3, 2, 1),
                      (("g3", 8192, 2048, 3), (512, 1), True, 2, 4),
                      (("g3", 8192, 8192, 3), (512, 1), True, 1, 4)], own_gpu=True)
+
+
+def test_bench_line_from_four_ranks_rehearsed_on_one_gpu():
+    """bench.py's N > 1 path end to end, as the driver starts it (bare `--gpus N`: bench.py spawns torch.distributed.run itself):
+    four ranks share cuda:0 and exchange over gloo (`--rehearse-one-gpu`; a one-GPU box allows at most six processes on the card,
+    so 8 ranks cannot be rehearsed here -- the world-8 index arithmetic runs on the CPU in tests/test_sharding_gloo.py).  Exactly
+    one JSON line must come out, carrying the contract's keys, all four ranks in every leg, and a sharded config-4 leg whose
+    containers were verified against the one-piece container inside bench.py.  The numbers themselves mean nothing."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rehearse-one-gpu", "--steps", "2", "--warmup", "1",
+                        "--frames", "4", "--streams", "2", "--c4-images", "4", "--no-cpu-baseline", "--legs-timeout", "400"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 4 and d["ranks_seen"] == 4 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert len(d["per_rank_one_gpu_value"]) == 4 and all(v > 0 for v in d["per_rank_one_gpu_value"])
+    assert d["collective_backend"] == "gloo"  # (the rehearsal; the driver's run says nccl)
+    c4 = d["c4_sharded"]
+    assert c4.get("ranks_seen") == 4 and c4["value"] > 0 and c4["scaling"] == "strong" and c4["images_per_step"] == 4, c4
+    c5 = d["c5_replica_pcie"]
+    assert c5["ranks_ok"] == 4 and c5["value"] > 0, c5

@@ -157,6 +157,77 @@ def test_sharded_containers_equal_one_piece(world, case):
     assert all(p.exitcode == 0 for p in procs)
 
 
+# ---- world 8: the size the 8-GPU node runs, rehearsed on the CPU ----------------------------------------------------------
+def _worker_world8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+
+    import orc as orc_mod
+    from llcomp_amd import sharding
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = orc_mod.Orc()
+        # BASELINE config 4's plan scaled down: one-row slices narrower than the image (bench.py: 512 x 1 of 8192), planar, four
+        # chunks of tile rows per rank; 67 rows do not divide by the 32 chunks (sizes 2 and 3).  Image counts below, at and above
+        # the world size, none of them but 8 a multiple of it; containers spread round-robin (root None) or funnelled to rank 5.
+        w, h, c, tw, th, cpr = 96, 67, 3, 40, 1, 4
+        done = []
+        for images in (1, 3, 8, 11):
+            full = np.stack([np.roll(orc_mod.gen_mid(w, h, c) if b % 2 == 0 else orc_mod.gen_g3(w, h, c, seed=5 + b), 3 * b, axis=1) for b in range(images)])
+            want = [orc.compress_sliced(full[b], tw, th, True) for b in range(images)] if rank in (0, 5) else None
+            for root in (None, 5):
+                sc = sharding.ShardedCodec(w, h, c, tw, th, True, images=images, chunks_per_rank=cpr, root=root, device=torch.device("cpu"),
+                                           band_factory=oracle_band_factory(orc))
+                sc.MAX_MESSAGE = 4096 if images == 8 else 1 << 30  # (one count also through the rounds of the chunked exchange)
+                band = sc.take_local(full)
+                rows = [y for y0, y1 in sc.rows for y in range(y0, y1)]
+                assert band.shape == (images, len(rows), w, c) and len(sc.rows) == cpr
+                conts = sc.encode(band)
+                mine = [b for b in range(images) if (b % world if root is None else root) == rank]
+                assert sorted(conts) == mine, (images, root, sorted(conts))
+                for b in mine:
+                    one_piece = want[b] if want is not None else orc.compress_sliced(full[b], tw, th, True)
+                    assert bytes(conts[b].numpy()) == one_piece, f"images {images} root {root}: container {b} differs from the one-piece container"
+                out = sc.decode(conts)
+                assert np.array_equal(out.numpy(), full[sc.frame_images][:, rows]), (images, root)
+                px = sc.gather_pixels(out)
+                if rank == 0:
+                    assert np.array_equal(px.numpy(), full)
+                done.append((images, root, len(mine)))
+        q.put((rank, "ok", done))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc(), None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world8_plan_shapes_of_config4():
+    """Largest world the N > 1 path is meant for (the 8-GPU node), on the CPU with the oracle as local coder: per_root / perm index
+    arithmetic with image counts that do not divide by the world, both gathering modes, the exchange in rounds."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_world8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(400)
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert [(r, m) for r, m, _ in res] == [(r, "ok") for r in range(world)], [m for _, m, _ in res if m != "ok"][:1]
+    assert all(p.exitcode == 0 for p in procs)
+    # every container was gathered exactly once: 1 + 3 + 8 + 11 images, twice (two gathering modes)
+    assert sum(n for _, _, d in res for _, _, n in d) == 2 * (1 + 3 + 8 + 11)
+    assert [n for _, _, n in res[5][2] if True][1::2] == [1, 3, 8, 11]  # root 5 holds all of them in the funnel mode
+
+
 def test_chunk_plan_covers_image():
     from llcomp_amd import sharding
 
