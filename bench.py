@@ -44,10 +44,11 @@ RMW_UBENCH = 24.06e9       # uniformly random dependent 8-byte read-modify-write
 # HBM bytes per sample of the 2-D tile legs' kernels, (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction) / samples, from the
 # committed PMC passes of 16 frames / one pipeline (tools/prof_2d.sh).  encode_all_kernels = stage A 5.4 + k_snap_sort 8.0 + k_snap_walk
 # 12.0 + k_snap_unperm 22.0 + k_encode_slices + k_pack_payload; decode_all_kernels = k_stage_streams + k_decode_slices + k_from_lane_order
-# 4.0 + inverse stage A (3, not in the pass).  Round 3's encoder (state tables in HBM) moved 131 (g3) / 147 (nat) in k_encode_slices alone.
-TILE_HBM_SOURCE = "profiles/r04_tiles64_f16_{g3,nat}_pmc_summary.txt"
-TILE_HBM_BYTES_PER_SAMPLE = {"g3": {"k_encode_slices": 12.9, "encode_all_kernels": 63.6, "k_decode_slices": 152.5, "decode_all_kernels": 162.9},
-                             "nat": {"k_encode_slices": 10.7, "encode_all_kernels": 58.9, "k_decode_slices": 164.4, "decode_all_kernels": 172.3}}
+# 4.0 + inverse stage A 3.0.  Round 3's encoder (state tables in HBM) moved 131 (g3) / 147 (nat) in k_encode_slices alone; round 4's
+# decoder (two memory round trips per sample, every bank fetched and written in HBM) 156 / 168 in k_decode_slices.
+TILE_HBM_SOURCE = "profiles/r05_tiles64_f16_{g3,nat}_pmc_summary.txt (KiB counters x 1024)"
+TILE_HBM_BYTES_PER_SAMPLE = {"g3": {"k_encode_slices": 12.9, "encode_all_kernels": 63.6, "k_decode_slices": 98.6, "decode_all_kernels": 109.1},
+                             "nat": {"k_encode_slices": 10.7, "encode_all_kernels": 58.9, "k_decode_slices": 120.6, "decode_all_kernels": 128.5}}
 
 
 def make_frames(content, frames, rank, w=W4K, h=H4K, c=C4K, distinct=None):
@@ -149,9 +150,11 @@ def cpu_baseline(img, label, tile_w, tile_h, planar, same_slicing=False):
     return res
 
 
-def measure(frames_np, tile_w, tile_h, planar, streams, steps, warmup, local_rank, barrier=None, isolated=False):
+def measure(frames_np, tile_w, tile_h, planar, streams, steps, warmup, local_rank, barrier=None, isolated=False, per_step=False):
     """The device-resident round trip of bench.py: frames_np [F,h,w,c] resident in HBM, split over `streams` pipelines.
-    Returns a dict with the wall time of `steps` timed steps and the per-kernel event timings."""
+    Returns a dict with the wall time of `steps` timed steps and the per-kernel event timings.  per_step: every step is
+    bracketed by a device synchronisation of its own and timed alone (`step_ms`, for legs that report median and range); the
+    wall time is then the sum of the steps."""
     import torch
 
     import llcomp_amd as mi
@@ -212,10 +215,18 @@ def measure(frames_np, tile_w, tile_h, planar, streams, steps, warmup, local_ran
     if barrier:
         barrier()
     torch.cuda.synchronize()
+    step_ms = []
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
+    if per_step:
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            step_ms.append((time.perf_counter() - t1) * 1e3)
+    else:
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
     if barrier:
         barrier()
     dt = time.perf_counter() - t0
@@ -251,15 +262,30 @@ def measure(frames_np, tile_w, tile_h, planar, streams, steps, warmup, local_ran
     torch.cuda.empty_cache()
     container_bytes = total + 24 * F + 4 * n_slices  # per-frame container headers + slice tables
     return dict(dt=dt, steps=steps, F=F, S=S, w=w, h=h, c=c, n_slices=n_slices, payload=total, container_bytes=container_bytes,
-                raw_bytes=int(frames_np.size), prof=prof, frame0_container=frame0_container, frame0_fnv=frame0_fnv, n_enc=n_enc, n_dec=n_dec, iso=iso, iso_enc=iso_enc, iso_dec=iso_dec,
+                raw_bytes=int(frames_np.size), prof=prof, step_ms=step_ms, frame0_container=frame0_container, frame0_fnv=frame0_fnv, n_enc=n_enc, n_dec=n_dec, iso=iso, iso_enc=iso_enc, iso_dec=iso_dec,
                 mpix=F * w * h * steps / dt / 1e6, ratio=frames_np.size / container_bytes)
 
 
 def brief(m, **extra):
     d = {"value": round(m["mpix"], 1), "unit": "MPix/s", "ms_per_step": round(m["dt"] / m["steps"] * 1e3, 3), "steps": m["steps"],
          "frames": m["F"], "streams": m["S"], "compression_ratio": round(m["ratio"], 4)}
+    if m.get("step_ms"):  # steps timed one by one: the value is the MEDIAN step's rate, the range says how far single steps fall from it
+        ms = sorted(m["step_ms"])
+        med = ms[len(ms) // 2] if len(ms) & 1 else (ms[len(ms) // 2 - 1] + ms[len(ms) // 2]) / 2
+        pix = m["F"] * m["w"] * m["h"] / 1e6
+        d.update({"value": round(pix / (med * 1e-3), 1), "value_is": "median step", "ms_per_step": round(med, 3),
+                  "ms_per_step_min_max": [round(ms[0], 3), round(ms[-1], 3)], "value_min_max": [round(pix / (ms[-1] * 1e-3), 1), round(pix / (ms[0] * 1e-3), 1)]})
     d.update(extra)
     return d
+
+
+def tile_sides(m):
+    """per launch (one pipeline's frames), summed over the kernels of a direction, from the library's own events"""
+    p, ne, nd = m["prof"], max(1, m["n_enc"]), max(1, m["n_dec"])
+    enc = {"stage_a": p["k_model_fwd"] / ne, "state_snapshot_pass": p["clear_states_enc"] / ne, "k_encode_slices": p["k_encode_slices"] / ne, "scan+pack": p["scan+pack"] / ne}
+    dec = {"scan+stage": p["k_scan_lengths_dec"] / nd, "k_decode_slices": p["k_decode_slices"] / nd, "stage_a_inverse": (p["k_model_inv"] + p["clear_states_dec"]) / nd}
+    return {"encode_ms_per_launch": {k_: round(v_, 3) for k_, v_ in enc.items()}, "encode_ms_per_launch_sum": round(sum(enc.values()), 3),
+            "decode_ms_per_launch": {k_: round(v_, 3) for k_, v_ in dec.items()}, "decode_ms_per_launch_sum": round(sum(dec.values()), 3)}
 
 
 def profile_numbers(F, tile_w, tile_h, planar, content, S, dom):
@@ -903,6 +929,16 @@ def main():
             assert res["golden_pin"]["match"], "frame 0's container differs from the reference's (length or FNV-1a-64)"
     except OSError:
         pass
+    if not args.no_also and args.tile_h == 1:
+        # The headline's slicing (one-row slices) leaves llcomp's vertical context -- quant11 over three gradients, the two-row window, the
+        # median of left / top / gradient -- out of the timed region: with no row above, the context collapses to 605 * quant5(L - l).
+        # The same batch and pipelines through 64x64 planar tiles run the FULL model (and keep the reference's ratio): reported next to `value`.
+        mf = measure(frames_np, 64, 64, True, args.streams, max(12, args.steps), 2, local_rank, per_step=True)
+        bf = brief(mf)
+        res["value_full_model"] = bf["value"]
+        res["full_model"] = dict(bf, **tile_sides(mf), workload=f"the headline's batch ({F} frames 4K {args.content}, {mf['S']} pipelines) in 64x64 planar tiles: "
+                                 f"{mf['n_slices'] // F} slices per frame, all five context terms and the median predictor live",
+                                 vs_value=round(bf["value"] / res["value"], 4))
     if not args.no_also:
         also = {}
         sub = max(3, args.steps // 3)
@@ -938,17 +974,10 @@ def main():
                                                                workload=f"{F} frames 4K {content}, {args.tile_w}x{args.tile_h} planar")
 
         def leg_tiles():  # 2-D tiles keep vertical prediction (and the reference's ratio): the mode that runs llcomp's full context model
-            def sides(m):  # per launch (one pipeline's frames), summed over the kernels of a direction, from the library's own events
-                p, ne, nd = m["prof"], max(1, m["n_enc"]), max(1, m["n_dec"])
-                enc = {"stage_a": p["k_model_fwd"] / ne, "state_snapshot_pass": p["clear_states_enc"] / ne, "k_encode_slices": p["k_encode_slices"] / ne, "scan+pack": p["scan+pack"] / ne}
-                dec = {"scan+stage": p["k_scan_lengths_dec"] / nd, "k_decode_slices": p["k_decode_slices"] / nd, "stage_a_inverse": (p["k_model_inv"] + p["clear_states_dec"]) / nd}
-                return {"encode_ms_per_launch": {k_: round(v_, 3) for k_, v_ in enc.items()}, "encode_ms_per_launch_sum": round(sum(enc.values()), 3),
-                        "decode_ms_per_launch": {k_: round(v_, 3) for k_, v_ in dec.items()}, "decode_ms_per_launch_sum": round(sum(dec.values()), 3)}
-
             for content in ("nat", "mid", "g3"):
                 for frames, streams in ((16, 2), (48, 3)):  # round 3's leg (8 frames per pipeline: latency-bound) and the throughput configuration
                     fr = frames_np[:frames] if content == args.content and frames <= len(frames_np) else make_frames(content, frames, 0, distinct=4)
-                    m2 = measure(fr, 64, 64, True, streams, sub, 1, local_rank)
+                    m2 = measure(fr, 64, 64, True, streams, max(12, sub), 2, local_rank, per_step=True)
                     samples = 2 * frames * W4K * H4K * C4K * m2["steps"]
                     extra = {}
                     if content in TILE_HBM_BYTES_PER_SAMPLE:  # HBM-side traffic from the committed PMC passes of this configuration (one pipeline of 16 frames)
@@ -958,9 +987,9 @@ def main():
                     also[f"{content}_tiles64x64_{frames}frames"] = brief(
                         m2, workload=f"{frames} frames 4K {content}, 64x64 planar tiles, {streams} pipelines; encoder: state snapshot pass + sequential coder (no state "
                                      f"table), decoder: per-slice state tables in HBM (generation-tagged)",
-                        samples_per_s=round(samples / m2["dt"] / 1e9, 2), **sides(m2), **extra,
-                        note="the decoder stays bound by random state-bank transactions (one 128-byte line fill + partial write-back per sample: the next context "
-                             "needs the sample just decoded); the encoder knows every context in advance and streams its states")
+                        samples_per_s=round(samples / m2["dt"] / 1e9, 2), **tile_sides(m2), **extra,
+                        note="the decoder is bound by random state-bank transactions (the next context needs the sample just decoded), cut by a per-lane bank "
+                             "cache in LDS; the encoder knows every context in advance and streams its states")
 
         def leg_latency():  # latency of ONE frame: at the throughput slicing, and at the width the library suggests for one frame per call
             m1 = measure(frames_np[:1], args.tile_w, args.tile_h, planar, 1, 20, 2, local_rank)
