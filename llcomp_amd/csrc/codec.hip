@@ -109,21 +109,6 @@ int next_state_generation(llcomp_mi_codec* k, hipStream_t s) {
     return LLCOMP_MI_OK;
 }
 
-// The chained scan inside pack / stage tags its entries with a 16-bit generation (kernels.hpp): the array is cleared before the
-// first launch and whenever the generation would repeat.  LLCOMP_MI_SCANKERNELS=1 (A/B hook): 0 = offsets from the scan kernels.
-int next_scan_generation(llcomp_mi_codec* k, hipStream_t s, uint32_t* gen) {
-    if (current_tuning().scan_kernels) {
-        *gen = 0;
-        return LLCOMP_MI_OK;
-    }
-    if (k->scan_generation == 0 || k->scan_generation >= 65535) {
-        HIP_TRY(hipMemsetAsync(k->d_group_off, 0, (uint64_t(lane_groups(k->g)) + 1) * 8, s));
-        k->scan_generation = k->scan_generation == 0 ? uint32_t(current_tuning().scan_generation0) : 0;  // (test hook: a new codec starts just below the wrap)
-    }
-    *gen = ++k->scan_generation;
-    return LLCOMP_MI_OK;
-}
-
 // the snapshot pass's arrays (2-D encoder): allocated by the first encode -- a decode-only codec never pays for them
 int ensure_snapshot_arrays(llcomp_mi_codec* k) {
     if (k->d_snap_sorted) return LLCOMP_MI_OK;
@@ -320,22 +305,18 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
         HIP_TRY(launch_snapshot(g, static_cast<const uint32_t*>(k->d_sym_or_rec), k->d_lane_order, k->d_snap_sorted,
                                 k->d_snap_banks, k->d_snap_res, s));
     }
-    uint32_t gen = 0;  // (chained scan inside pack: the encoder need not leave its group sums behind)
-    if (int rc = next_scan_generation(k, s, &gen)) return rc;
     {
         Timed t(k, s, 2);
         const bool snap = snapshot_mode(g);
         HIP_TRY(launch_encode_slices(g, snap ? k->d_snap_res : k->d_lane_order, snap ? static_cast<uint64_t*>(k->d_snap_banks) : k->d_states,
                                      k->state_generation, k->d_scratch, static_cast<uint32_t*>(d_slice_len),
-                                     gen ? nullptr : k->d_group_off, static_cast<uint32_t*>(d_status), s));
+                                     k->d_group_off, static_cast<uint32_t*>(d_status), s));
     }
     {
         Timed t(k, s, 3);
-        if (gen == 0) {
-            if (!encoder_writes_group_sums(g)) HIP_TRY(launch_group_sums(g, static_cast<const uint32_t*>(d_slice_len), k->d_group_off, s));
-            HIP_TRY(launch_scan_groups(g, k->d_group_off, static_cast<uint64_t*>(d_total), s));
-        }
-        HIP_TRY(launch_pack_payload(g, k->d_scratch, static_cast<const uint32_t*>(d_slice_len), k->d_group_off, gen, static_cast<uint64_t*>(d_total),
+        if (!encoder_writes_group_sums(g)) HIP_TRY(launch_group_sums(g, static_cast<const uint32_t*>(d_slice_len), k->d_group_off, s));
+        HIP_TRY(launch_scan_groups(g, k->d_group_off, static_cast<uint64_t*>(d_total), s));
+        HIP_TRY(launch_pack_payload(g, k->d_scratch, static_cast<const uint32_t*>(d_slice_len), k->d_group_off,
                                     static_cast<uint8_t*>(d_payload), payload_cap, static_cast<uint32_t*>(d_status), s));
     }
     ++k->n_encode;
@@ -357,14 +338,13 @@ int llcomp_mi_codec_decode(llcomp_mi_codec* k, const void* d_payload, uint64_t p
     }
     {
         Timed t(k, s, 4);
-        uint32_t gen = 0;
-        if (int rc = next_scan_generation(k, s, &gen)) return rc;
-        if (gen == 0) {
-            HIP_TRY(launch_group_sums(g, static_cast<const uint32_t*>(d_slice_len), k->d_group_off, s));
-            HIP_TRY(launch_scan_groups(g, k->d_group_off, k->d_total_tmp, s));
-        }
+        HIP_TRY(launch_group_sums(g, static_cast<const uint32_t*>(d_slice_len), k->d_group_off, s));
+        HIP_TRY(launch_scan_groups(g, k->d_group_off, k->d_total_tmp, s));
+    }
+    {
+        Timed t(k, s, 4);
         HIP_TRY(launch_stage_streams(g, static_cast<const uint8_t*>(d_payload), payload_bytes,
-                                     static_cast<const uint32_t*>(d_slice_len), k->d_group_off, gen, k->d_total_tmp, k->d_scratch,
+                                     static_cast<const uint32_t*>(d_slice_len), k->d_group_off, k->d_scratch,
                                      static_cast<uint32_t*>(d_status), s));
     }
     {

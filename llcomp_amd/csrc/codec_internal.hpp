@@ -35,7 +35,6 @@ struct llcomp_mi_codec {
     uint64_t workspace_bytes = 0;
     bool need_states = true;  // false when the states live in LDS (1-row slices; one slice per wavefront)
     uint32_t state_generation = 0;  // tag of the last call that used d_states (kernels.hpp); 0 = the table has not been cleared yet
-    uint32_t scan_generation = 0;   // tag of the last pack / stage launch's chained scan in d_group_off (1..65535); 0 = not cleared yet
     // optional per-kernel timing (hipEvents on the caller's stream)
     bool profiling = false;
     struct Span { hipEvent_t a, b; int slot; };

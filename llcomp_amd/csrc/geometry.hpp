@@ -52,8 +52,6 @@ struct Tuning {
     bool noldstab = false;     // LLCOMP_MI_NOLDSTAB=1: single-slice launches keep their table in HBM
     bool force_replay = false; // LLCOMP_MI_FORCE_REPLAY=1
     bool nosnap = false;       // LLCOMP_MI_NOSNAP=1: the 2-D encoder keeps its state tables in HBM (the path before round 4)
-    bool scan_kernels = false; // LLCOMP_MI_SCANKERNELS=1: slice offsets from k_group_sums + k_scan_groups in front of pack / stage (before round 5)
-    int scan_generation0 = 0;  // LLCOMP_MI_SCAN_GENERATION0: first generation of a new codec's chained scan (tests: start just below the wrap)
     bool nocache = false;      // LLCOMP_MI_NOCACHE=1: the 2-D decoder fetches and writes every state bank in HBM (the path before round 5)
 };
 inline Tuning tuning_from_env() {
@@ -72,8 +70,6 @@ inline Tuning tuning_from_env() {
     t.force_replay = flag("LLCOMP_MI_FORCE_REPLAY");
     t.nosnap = flag("LLCOMP_MI_NOSNAP");
     t.nocache = flag("LLCOMP_MI_NOCACHE");
-    t.scan_kernels = flag("LLCOMP_MI_SCANKERNELS");
-    t.scan_generation0 = num("LLCOMP_MI_SCAN_GENERATION0", 0, 65534, 0);
     return t;
 }
 

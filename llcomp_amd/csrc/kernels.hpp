@@ -58,15 +58,11 @@ hipError_t launch_frame_bytes(const Geometry& g, const uint32_t* d_slice_len, ui
 // instead of unit arithmetic).  slice_cap/16 units
 // per slice (model_kernels.hip).  pack: that order -> payload (slices back to back, capacity payload_cap);
 // stage: payload -> that order.
-// scan_generation != 0: no scan kernel ran in front -- d_group_off is the array of the single-pass chained scan inside pack / stage
-// (model_kernels.hip: chained_group_offset; u64[lane_groups], entries tagged with the 16-bit generation, cleared by the caller
-// before generation 1 is used again) and the last block leaves the sum of all lengths in *d_total.  scan_generation == 0:
-// d_group_off holds the offsets launch_scan_groups computed.
 hipError_t launch_pack_payload(const Geometry& g, const uint8_t* d_units, const uint32_t* d_slice_len,
-                               uint64_t* d_group_off, uint32_t scan_generation, uint64_t* d_total, uint8_t* d_payload, uint64_t payload_cap,
+                               const uint64_t* d_group_off, uint8_t* d_payload, uint64_t payload_cap,
                                uint32_t* d_status, hipStream_t stream);
 hipError_t launch_stage_streams(const Geometry& g, const uint8_t* d_payload, uint64_t payload_bytes,
-                                const uint32_t* d_slice_len, uint64_t* d_group_off, uint32_t scan_generation, uint64_t* d_total, uint8_t* d_units,
+                                const uint32_t* d_slice_len, const uint64_t* d_group_off, uint8_t* d_units,
                                 uint32_t* d_status, hipStream_t stream);
 // n_seg byte ranges src[src_off[i] .. +len[i]) -> dst[dst_off[i] .. +len[i]) in one launch (offsets / lengths in HBM, any
 // alignment); max_len = an upper bound of the lengths (grid sizing only).  The device-side concatenator of the multi-GPU path.

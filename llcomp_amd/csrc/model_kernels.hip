@@ -323,74 +323,15 @@ struct GroupStreams {
     uint32_t len[64];
     uint32_t max_len;
 };
-
-// Offset of a lane group in the packed payload WITHOUT a scan kernel in front of pack / stage: a single-pass chained scan
-// ("decoupled look-back") over one u64 per lane group, `scan[group]` = [generation:16][1 = prefix, 0 = the group's own sum][47-bit
-// value].  A block publishes the sum of its 64 lengths at once, walks back over its predecessors -- 64 per step, one per lane --
-// adding their sums until it meets one that already knows its inclusive prefix, then publishes its own.  Entries of earlier calls
-// carry another generation and read as "not there yet" (the array is never cleared between calls; the host clears it when the
-// 16-bit generation wraps).  Blocks are dispatched in the order of their index, so every predecessor a block waits for is
-// already running; the wait is bounded all the same (kStInternal, never a hang).  Reads and writes of the entries are
-// device-scope atomics: the L2s of the eight XCDs are not coherent with each other for ordinary accesses.
-constexpr unsigned long long kScanValueMask = (1ull << 47) - 1, kScanPrefixBit = 1ull << 47;
-constexpr uint32_t kScanMaxPolls = 1u << 22;
-__device__ __forceinline__ unsigned long long chained_group_offset(unsigned long long* scan, uint32_t gen, uint32_t group, unsigned long long own_sum,
-                                                                   uint32_t* status) {  // called by the 64 lanes of the block's first wavefront
-    const uint32_t lane = threadIdx.x;
-    const unsigned long long tag = (unsigned long long)gen << 48;
-    if (lane == 0 && group != 0) __hip_atomic_store(scan + group, tag | (own_sum & kScanValueMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long before = 0;
-    for (long long top = (long long)group - 1;; top -= 64) {
-        const long long j = top - lane;
-        unsigned long long e = tag | kScanPrefixBit;  // in front of group 0: a prefix of zero
-        if (j >= 0) {
-            uint32_t polls = 0;
-            for (;;) {
-                e = __hip_atomic_load(scan + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((e >> 48) == gen) break;
-                if (++polls >= kScanMaxPolls) {  // (cannot happen: block j was dispatched before this one)
-                    atomicOr(status, kStInternal);
-                    e = tag | kScanPrefixBit;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        const unsigned long long is_prefix = __builtin_amdgcn_ballot_w64((e & kScanPrefixBit) != 0);
-        unsigned long long v = e & kScanValueMask;
-        if (is_prefix) {  // the nearest predecessor that knows its prefix closes the walk
-            const uint32_t first = uint32_t(__builtin_ctzll(is_prefix));
-            if (lane > first) v = 0;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-        before += v;
-        if (is_prefix) break;
-    }
-    if (lane == 0) __hip_atomic_store(scan + group, tag | kScanPrefixBit | ((before + own_sum) & kScanValueMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return before;
-}
-
-// gen != 0: `group_off` is the chained scan's array (above) and the last block leaves the sum of all lengths in *total;
-// gen == 0: `group_off` holds ready offsets (k_scan_groups ran in front).
 __device__ __forceinline__ void load_group_streams(const Geometry& g, uint32_t group, const uint32_t* slice_len,
-                                                   uint64_t* group_off, uint32_t gen, uint64_t* total, uint64_t limit, uint32_t* status,
+                                                   const uint64_t* group_off, uint64_t limit, uint32_t* status,
                                                    uint32_t err_bit, GroupStreams& gs) {
     if (threadIdx.x < 64) {
         const uint32_t id = (group << g.lane_shift) + threadIdx.x;
         const bool live = threadIdx.x < (1u << g.lane_shift) && id < g.n_slices;
         uint32_t n = live ? slice_len[id] : 0;
         // offset of the slice = offset of its lane group + the lengths of the group's slices before it
-        const unsigned long long inc = wave_inclusive_scan(n, threadIdx.x);
-        unsigned long long base;
-        if (gen != 0) {
-            const unsigned long long sum = __shfl(inc, 63, 64);
-            base = chained_group_offset(reinterpret_cast<unsigned long long*>(group_off), gen, group, sum, status);
-            if (threadIdx.x == 0 && group + 1 == gridDim.x) *total = base + sum;
-        } else {
-            base = group_off[group];
-        }
-        unsigned long long o = base + inc - n;
+        unsigned long long o = group_off[group] + wave_inclusive_scan(n, threadIdx.x) - n;
         if (live) {
             if (o + n > limit) {  // the slice does not fit the payload (decode: table promises too much)
                 atomicOr(status, err_bit);
@@ -414,11 +355,12 @@ __device__ __forceinline__ void load_group_streams(const Geometry& g, uint32_t g
 // stream lane order -> packed payload (after the encoder)
 __global__ __launch_bounds__(256) void k_pack_payload(const Geometry g, const uint4* __restrict__ units,
                                                       const uint32_t* __restrict__ slice_len,
-                                                      uint64_t* off, const uint32_t gen, uint64_t* total, uint8_t* __restrict__ payload,
+                                                      const uint64_t* __restrict__ off, uint8_t* __restrict__ payload,
                                                       uint64_t payload_cap, uint32_t* status) {
     __shared__ uint32_t tile[64][kChunkDwords + 1];
     __shared__ GroupStreams gs;
     const uint32_t group = blockIdx.x;
+    load_group_streams(g, group, slice_len, off, payload_cap, status, kStOverflow, gs);
     const uint32_t cap16 = g.slice_cap >> 4;
     const uint32_t a = threadIdx.x & 63, b = threadIdx.x >> 6;
     // 1 KiB rows of units.  All four loads of a thread are in flight before the first is stored (see k_model_rows_inv),
@@ -432,8 +374,7 @@ __global__ __launch_bounds__(256) void k_pack_payload(const Geometry g, const ui
             if (u < cap16 && a < (1u << g.lane_shift)) v[t] = units[((size_t(group) * cap16 + u) << g.lane_shift) + a];
         }
     };
-    request(0);  // (in flight while the group's offset is found)
-    load_group_streams(g, group, slice_len, off, gen, total, payload_cap, status, kStOverflow, gs);
+    if (gs.max_len) request(0);
     for (uint32_t c0 = 0; c0 * 256 < gs.max_len; ++c0) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -461,12 +402,12 @@ __global__ __launch_bounds__(256) void k_pack_payload(const Geometry g, const ui
 // packed payload -> stream lane order (before the decoder)
 __global__ __launch_bounds__(256) void k_stage_streams(const Geometry g, const uint8_t* __restrict__ payload,
                                                        uint64_t payload_bytes, const uint32_t* __restrict__ slice_len,
-                                                       uint64_t* off, const uint32_t gen, uint64_t* total, uint4* __restrict__ units,
+                                                       const uint64_t* __restrict__ off, uint4* __restrict__ units,
                                                        uint32_t* status) {
     __shared__ uint32_t tile[64][kChunkDwords + 1];
     __shared__ GroupStreams gs;
     const uint32_t group = blockIdx.x;
-    load_group_streams(g, group, slice_len, off, gen, total, payload_bytes, status, kStTruncated, gs);
+    load_group_streams(g, group, slice_len, off, payload_bytes, status, kStTruncated, gs);
     const uint32_t capdw = g.slice_cap >> 2;
     const uint32_t a = threadIdx.x & 63, b = threadIdx.x >> 6;
     // "+ 4": the dword right behind every stream is staged too (as zeros) -- the decoder clamps its reads to it.
@@ -1058,17 +999,17 @@ hipError_t launch_range_sums(const uint32_t* d_vals, const uint64_t* d_start, co
 }
 
 hipError_t launch_pack_payload(const Geometry& g, const uint8_t* d_units, const uint32_t* d_slice_len,
-                               uint64_t* d_offsets, uint32_t scan_generation, uint64_t* d_total, uint8_t* d_payload, uint64_t payload_cap,
+                               const uint64_t* d_offsets, uint8_t* d_payload, uint64_t payload_cap,
                                uint32_t* d_status, hipStream_t stream) {
     k_pack_payload<<<dim3(lane_groups(g)), dim3(256), 0, stream>>>(g, reinterpret_cast<const uint4*>(d_units), d_slice_len,
-                                                                   d_offsets, scan_generation, d_total, d_payload, payload_cap, d_status);
+                                                                   d_offsets, d_payload, payload_cap, d_status);
     return hipGetLastError();
 }
 
 hipError_t launch_stage_streams(const Geometry& g, const uint8_t* d_payload, uint64_t payload_bytes,
-                                const uint32_t* d_slice_len, uint64_t* d_offsets, uint32_t scan_generation, uint64_t* d_total, uint8_t* d_units,
+                                const uint32_t* d_slice_len, const uint64_t* d_offsets, uint8_t* d_units,
                                 uint32_t* d_status, hipStream_t stream) {
-    k_stage_streams<<<dim3(lane_groups(g)), dim3(256), 0, stream>>>(g, d_payload, payload_bytes, d_slice_len, d_offsets, scan_generation, d_total,
+    k_stage_streams<<<dim3(lane_groups(g)), dim3(256), 0, stream>>>(g, d_payload, payload_bytes, d_slice_len, d_offsets,
                                                                     reinterpret_cast<uint4*>(d_units), d_status);
     return hipGetLastError();
 }

@@ -1380,7 +1380,7 @@ hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* 
     const uint64_t gpat = slices_need_state_tables(g) ? state_generation_tag(generation) : 0;
     const uint32_t lpw = g.lpw;
     const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
-    uint64_t* const d_group_sum = (d_group_off && encoder_writes_group_sums(g)) ? d_group_off : nullptr;
+    uint64_t* const d_group_sum = encoder_writes_group_sums(g) ? d_group_off : nullptr;
     if (model_is_fused(g)) {  // planar 1-row slices: 16-bit symbols, always the ROWS kernel
         k_encode_slices<1, true, uint16_t><<<dim3(blocks), dim3(64), LLMI_ASM_ENC ? kRowsEncLdsBytes : 0, stream>>>(
             g, lpw, static_cast<const uint16_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status, gpat);

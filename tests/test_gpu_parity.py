@@ -633,53 +633,6 @@ def test_2d_encoder_snapshot_pass_or_state_tables_same_bytes(mi, orc, set_hook):
                 assert np.array_equal(mi.decompress_image(s).pixels, img)
 
 
-def test_slice_offsets_from_the_chained_scan_or_the_scan_kernels(mi, orc, set_hook):
-    """pack / stage find a lane group's offset in the packed payload by a single-pass chained scan over one tagged u64 per group
-    (model_kernels.hip: chained_group_offset); LLCOMP_MI_SCANKERNELS=1 runs k_group_sums + k_scan_groups in front instead (the path
-    before round 5).  Same containers, same pixels: one group, a few, thousands (the walk back crosses several 64-entry steps),
-    lane groups narrower than a wavefront, empty-ish slices; then 70 000 calls' worth of generations on one codec object is too
-    slow to test -- the wrap is exercised by starting the generation just below it (LLCOMP_MI_SCAN_GENERATION0)."""
-    import torch
-
-    cases = [(64, 8, 3, 16, 1, True), (300, 200, 3, 20, 1, True), (1920, 300, 3, 30, 1, True), (700, 500, 1, 7, 1, False), (640, 360, 3, 64, 64, True),
-             (97, 41, 2, 50, 21, False), (1000, 64, 4, 1000, 1, False)]
-    for w, h, c, tw, th, planar in cases:
-        img = make_image("mid", w, h, c)
-        img[h // 2:] = make_image("g3", w, h - h // 2, c)
-        want = orc.compress_sliced(img, tw, th, planar)
-        for hook in ("0", "1"):
-            set_hook("LLCOMP_MI_SCANKERNELS", hook)
-            s = mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar)
-            assert s == want, (w, h, c, tw, th, planar, hook)
-            assert np.array_equal(mi.decompress_image(s).pixels, img)
-    # one codec object across the wrap of the 16-bit generation: encode + decode use a generation each
-    set_hook("LLCOMP_MI_SCANKERNELS", "0")
-    set_hook("LLCOMP_MI_SCAN_GENERATION0", "65520")
-    frames, w, h, c, tw, th = 2, 640, 96, 3, 40, 1
-    codec = mi.Codec(frames, w, h, c, tw, th, True)
-    st = torch.cuda.current_stream().cuda_stream
-    imgs = np.stack([make_image("mid", w, h, c), make_image("g3", w, h, c)])
-    ref = [orc.compress_sliced(imgs[f], tw, th, True) for f in range(frames)]
-    spf = codec.n_slices // frames
-    want_pay = b"".join(r[24 + 4 * spf:] for r in ref)
-    d_px = torch.from_numpy(imgs).cuda()
-    cap = len(want_pay) + 4096
-    d_pay = torch.empty(cap, dtype=torch.uint8, device="cuda")
-    d_len = torch.empty(codec.n_slices, dtype=torch.int32, device="cuda")
-    d_tot = torch.zeros(1, dtype=torch.int64, device="cuda")
-    d_st = torch.zeros(2, dtype=torch.int32, device="cuda")
-    d_out = torch.empty_like(d_px)
-    for i in range(20):  # generations 65521 .. 65535, then the clear, then 1 ..
-        d_out.zero_()
-        codec.encode(d_px.data_ptr(), d_pay.data_ptr(), cap, d_len.data_ptr(), d_tot.data_ptr(), d_st.data_ptr(), st)
-        codec.decode(d_pay.data_ptr(), cap, d_len.data_ptr(), d_out.data_ptr(), d_st[1:].data_ptr(), st)
-        torch.cuda.synchronize()
-        assert d_st.tolist() == [0, 0], i
-        assert int(d_tot.item()) == len(want_pay) and d_pay[:len(want_pay)].cpu().numpy().tobytes() == want_pay, i
-        assert torch.equal(d_out, d_px), i
-    codec.close()
-
-
 def test_2d_decoder_bank_cache_or_plain_same_pixels(mi, orc, set_hook):
     """The 2-D decoder keeps a per-lane write-back cache of 32 state banks in LDS (slice_kernels.hip, CACHE) and gives it up in
     the middle of a slice when fewer than one access in eight hits; LLCOMP_MI_NOCACHE=1 fetches and writes every bank in HBM (the

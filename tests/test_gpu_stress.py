@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 import pytest  # noqa: E402
 
-HOOKS = ("LLCOMP_MI_LANE_SHIFT", "LLCOMP_MI_NOROWS", "LLCOMP_MI_NOLDSTAB", "LLCOMP_MI_FORCE_REPLAY", "LLCOMP_MI_NOSNAP", "LLCOMP_MI_NOCACHE", "LLCOMP_MI_SCANKERNELS")
+HOOKS = ("LLCOMP_MI_LANE_SHIFT", "LLCOMP_MI_NOROWS", "LLCOMP_MI_NOLDSTAB", "LLCOMP_MI_FORCE_REPLAY", "LLCOMP_MI_NOSNAP", "LLCOMP_MI_NOCACHE")
 
 
 def make(rng, w, h, c, kind):
@@ -69,8 +69,6 @@ def run_case(mi, orc, seed, check_legacy):
         env["LLCOMP_MI_NOSNAP"] = "1"
     if extra.random() < 0.3:  # the 2-D decoder without its bank cache in LDS (same pixels)
         env["LLCOMP_MI_NOCACHE"] = "1"
-    if extra.random() < 0.25:  # slice offsets from the scan kernels instead of the chained scan inside pack / stage
-        env["LLCOMP_MI_SCANKERNELS"] = "1"
     for k in HOOKS:
         os.environ.pop(k, None)
     os.environ.update(env)
