@@ -717,11 +717,17 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
             const uint32_t s2 = i + 2 < total ? fetch() : 0;
             const uint32_t ctx0 = s0 & 0xFFFF, ctx1 = s1 & 0xFFFF;
             const int res = int(s0) >> 16;
-            uint64_t b1 = (i + 1 < total) ? bank_fresh<LDSTAB>(banks[size_t(ctx1) << bsh], gpat) : 0;
+            // The next sample's bank is REQUESTED here and looked at only behind this sample's coding (its tag test right here
+            // put a wait for the load -- and for everything sent before it -- in front of the coding: one memory round trip per
+            // sample in the serial chain, as in the decoder before round 5).
+            uint64_t raw1 = (i + 1 < total) ? banks[size_t(ctx1) << bsh] : 0;
             Bank bank{{uint32_t(b0), uint32_t(b0 >> 32)}, nullptr};
             if (hot) enc_residual<true, false>(e, bank, tab, res); else enc_residual<false, false>(e, bank, tab, res);
             hot = __builtin_amdgcn_readfirstlane(2 * __popcll(__ballot(res != 0)) >= __popcll(__ballot(true)));
             b0 = uint64_t(bank.w[0]) | (uint64_t(bank.w[1]) << 32);
+            // one drain per sample, in front of this sample's stores: what it waits for was sent a whole sample ago
+            if constexpr (!LDSTAB) drain_vector_memory();
+            uint64_t b1 = bank_fresh<LDSTAB>(raw1, gpat);
             banks[size_t(ctx0) << bsh] = bank_tagged<LDSTAB>(b0, gpat);
             if (ctx1 == ctx0) b1 = b0;  // the prefetched copy is stale: forward
             b0 = b1;
