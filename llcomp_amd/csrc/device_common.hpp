@@ -42,6 +42,13 @@ __device__ __forceinline__ int context_hash(const Hood& n, bool small = false) {
     const int h3 = quant11(n.l - n.tl) + 11 * quant11(n.tl - n.t) + 121 * quant11(n.t - n.tr);
     return small ? h3 : h3 + 605 * quant5(n.L - n.l) + 3025 * quant5(n.T - n.t);
 }
+// the same through byte tables in LDS: lut[d + 128] = quant11(d), lut[256 + d + 128] = quant5(d) for d = -128 .. 127 (differences
+// are clamped to that range first, as the reference's tables are indexed: llcomp.hpp:335-341)
+__device__ __forceinline__ int context_hash_lut(const Hood& n, const int8_t* lut, bool small = false) {
+    auto at = [](int d) { return min(max(d, -128), 127) + 128; };
+    const int h3 = lut[at(n.l - n.tl)] + 11 * lut[at(n.tl - n.t)] + 121 * lut[at(n.t - n.tr)];
+    return small ? h3 : h3 + 605 * lut[256 + at(n.L - n.l)] + 3025 * lut[256 + at(n.T - n.t)];
+}
 __device__ __forceinline__ int predict(const Hood& n) { return median3(n.l, n.l + n.t - n.tl, n.t); }
 
 // ---- sample layouts in HBM -------------------------------------------------------------------------------

@@ -1044,6 +1044,15 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                                                       uint32_t* status, const uint64_t gpat) {
     __shared__ entry_t tab[128];  // (entries carry absolute LDS addresses, load_table: the hand-written loop needs no base)
     __shared__ uint32_t rowbank[ROWS ? kWideBankWords : 1];
+    // quant11 / quant5 as byte tables over the clamped difference (llcomp.hpp:297-341 has them as tables too): five look-ups that
+    // fly together instead of five compare chains of ~17 dependent instructions each in front of every sample's bank fetch
+    __shared__ int8_t quant_lut[ROWS ? 1 : 512];
+    if constexpr (!ROWS) {
+        for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+            quant_lut[i] = int8_t(quant11(int(i) - 128));
+            quant_lut[256 + i] = int8_t(quant5(int(i) - 128));
+        }
+    }
     static_assert(CACHE == 0 || (!ROWS && !LDSTAB && NCH != 0), "the bank cache belongs to the 2-D kernels with tables in HBM");
     clear_lds_states<LDSTAB>();
     if constexpr (CACHE != 0) {  // every entry empty
@@ -1231,7 +1240,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                 for (int k = 0; k < NCH; ++k) {
                     if (window_low(d)) dec_append(d);
                     const Hood n = apply_borders(l[k], L[k], t[k], tl[k], tr[k], T[k], x, y, r.sw);
-                    int ctx = context_hash(n, small_model);
+                    int ctx = context_hash_lut(n, quant_lut, small_model);
                     const bool neg = ctx < 0;  // llcomp.hpp:511-515
                     if (neg) ctx = -ctx;
                     // The bank just updated stays in registers next to its write-through copy in the table.  On smooth content
