@@ -47,7 +47,7 @@ RMW_UBENCH = 24.06e9       # uniformly random dependent 8-byte read-modify-write
 # 4.0 + inverse stage A 3.0.  Round 3's encoder (state tables in HBM) moved 131 (g3) / 147 (nat) in k_encode_slices alone; round 4's
 # decoder (two memory round trips per sample, every bank fetched and written in HBM) 156 / 168 in k_decode_slices.
 TILE_HBM_SOURCE = "profiles/r05_tiles64_f16_{g3,nat}_pmc_summary.txt (KiB counters x 1024)"
-TILE_HBM_BYTES_PER_SAMPLE = {"g3": {"k_encode_slices": 12.9, "encode_all_kernels": 63.6, "k_decode_slices": 98.6, "decode_all_kernels": 109.1},
+TILE_HBM_BYTES_PER_SAMPLE = {"g3": {"k_encode_slices": 12.9, "encode_all_kernels": 63.6, "k_decode_slices": 98.7, "decode_all_kernels": 109.1},
                              "nat": {"k_encode_slices": 10.7, "encode_all_kernels": 58.9, "k_decode_slices": 120.6, "decode_all_kernels": 128.5}}
 
 
@@ -291,7 +291,7 @@ def tile_sides(m):
 def profile_numbers(F, tile_w, tile_h, planar, content, S, dom):
     """HBM-side bytes and VALU instructions per launch of kernel `dom` from the committed rocprofv3 PMC passes of THIS
     configuration (profiles/*_traffic.json); (None, None, None) when no committed profile matches."""
-    for name in ("r04_default_traffic.json", "r04_single_stream_traffic.json", "r03_default_traffic.json", "r03_single_stream_traffic.json",
+    for name in ("r05_default_traffic.json", "r05_single_stream_traffic.json", "r04_default_traffic.json", "r04_single_stream_traffic.json", "r03_default_traffic.json", "r03_single_stream_traffic.json",
                  "r02_default_traffic.json", "r02_single_stream_traffic.json", "r01_default_traffic.json", "r01_single_stream_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
