@@ -158,6 +158,11 @@ int llcomp_mi_codec_create_ex(llcomp_mi_codec** codec, int32_t device, uint32_t 
  * dead event when the blocks are taken out again and drains the whole device instead. */
 void llcomp_mi_codec_destroy(llcomp_mi_codec* codec);
 uint32_t llcomp_mi_codec_slices(const llcomp_mi_codec* codec);        /* total = frames * slices per frame */
+/* Diagnostic: which kernel family the codec's geometry selected when it was created -- bit 0 one-row slices (states on chip),
+ * bit 1 one slice per wavefront (state table in LDS), bit 2 forced replay (test hook), bit 3 small model, bit 4 the encoder's state
+ * snapshot pass, bit 5 the 2-D decoder's bank cache in LDS; bits 8..15 log2 of the lane-group width, bits 16..23 slices per
+ * wavefront.  No effect on any output byte: tests use it to make sure they run the family they mean to. */
+uint32_t llcomp_mi_codec_kernel_family(const llcomp_mi_codec* codec);
 /* Device bytes the codec can hold at most.  The per-slice state tables (decoding 2-D slices; 63 KB per slice) and the snapshot
  * arrays of the 2-D encoder (22 B per sample) are allocated by the first call that needs them, so an encode-only or decode-only
  * codec stays below this figure; that first call can return LLCOMP_MI_NOMEM. */

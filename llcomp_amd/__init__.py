@@ -390,6 +390,9 @@ class Codec:
         self.n_slices = self._L.llcomp_mi_codec_slices(self._h)
         self.max_payload_bytes = self._L.llcomp_mi_codec_max_payload_bytes(self._h)
         self.workspace_bytes = self._L.llcomp_mi_codec_workspace_bytes(self._h)
+        fam = self._L.llcomp_mi_codec_kernel_family(self._h)  # (diagnostic: tests make sure they run the family they mean to)
+        self.family = {"rows": bool(fam & 1), "lds_table": bool(fam & 2), "snapshot": bool(fam & 16), "bank_cache": bool(fam & 32),
+                       "lane_shift": (fam >> 8) & 0xFF, "slices_per_wave": (fam >> 16) & 0xFF}
 
     def close(self):
         if self._h:

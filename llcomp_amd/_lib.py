@@ -16,7 +16,7 @@ ABI_VERSION = 3  # LLCOMP_MI_ABI_VERSION of the header this binding mirrors
 SYMBOLS = [
     "llcomp_mi_encode", "llcomp_mi_decode", "llcomp_mi_free", "llcomp_mi_strerror", "llcomp_mi_abi_version",
     "llcomp_mi_device_count", "llcomp_mi_probe", "llcomp_mi_slice_count", "llcomp_mi_merge_bands",
-    "llcomp_mi_split_band", "llcomp_mi_codec_create", "llcomp_mi_codec_destroy", "llcomp_mi_codec_slices",
+    "llcomp_mi_split_band", "llcomp_mi_codec_create", "llcomp_mi_codec_destroy", "llcomp_mi_codec_slices", "llcomp_mi_codec_kernel_family",
     "llcomp_mi_codec_workspace_bytes", "llcomp_mi_codec_max_payload_bytes", "llcomp_mi_codec_encode",
     "llcomp_mi_codec_decode", "llcomp_mi_codec_model", "llcomp_mi_status_from_bits",
     "llcomp_mi_codec_set_profiling", "llcomp_mi_codec_get_profile",
@@ -107,6 +107,8 @@ def load():
     L.llcomp_mi_codec_destroy.argtypes = [C.c_void_p]
     L.llcomp_mi_codec_slices.restype = C.c_uint32
     L.llcomp_mi_codec_slices.argtypes = [C.c_void_p]
+    L.llcomp_mi_codec_kernel_family.restype = C.c_uint32
+    L.llcomp_mi_codec_kernel_family.argtypes = [C.c_void_p]
     L.llcomp_mi_codec_workspace_bytes.restype = C.c_uint64
     L.llcomp_mi_codec_workspace_bytes.argtypes = [C.c_void_p]
     L.llcomp_mi_codec_max_payload_bytes.restype = C.c_uint64

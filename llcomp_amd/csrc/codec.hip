@@ -261,6 +261,7 @@ void llcomp_mi_codec_destroy(llcomp_mi_codec* k) {
 }
 
 uint32_t llcomp_mi_codec_slices(const llcomp_mi_codec* k) { return k ? k->g.n_slices : 0; }
+uint32_t llcomp_mi_codec_kernel_family(const llcomp_mi_codec* k) { return k ? (k->g.flags & 0xFFu) | (k->g.lane_shift << 8) | (k->g.lpw << 16) : 0; }
 uint64_t llcomp_mi_codec_workspace_bytes(const llcomp_mi_codec* k) { return k ? k->workspace_bytes : 0; }
 uint64_t llcomp_mi_codec_max_payload_bytes(const llcomp_mi_codec* k) {
     return k ? uint64_t(k->g.n_slices) * k->g.slice_cap : 0;

@@ -28,7 +28,10 @@ def mi():
 def set_hook(mi, monkeypatch):
     """The library reads its LLCOMP_MI_* test hooks once per process; a test that changes one says so (reload_tuning)."""
     def _set(name, value):
-        monkeypatch.setenv(name, value)
+        if value is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, value)
         mi.reload_tuning()
 
     yield _set
@@ -286,13 +289,16 @@ def test_model_kernel_matches_oracle_symbols(mi, orc, shape):
 
 
 # ---- device-resident batch codec --------------------------------------------------------------------------------
-def _batch_roundtrip(mi, orc, frames, w, h, c, tw, th, planar, gens, small_model=False):
+def _batch_roundtrip(mi, orc, frames, w, h, c, tw, th, planar, gens, small_model=False, expect=None):
+    """`expect`: kernel-family properties the codec object must report (Codec.family), so that a test runs the family it means to"""
     import torch
 
     imgs = np.stack([make_image(gens[i % len(gens)], w, h, c) for i in range(frames)])
     for i in range(frames):
         imgs[i] = np.roll(imgs[i], i * 7, axis=1)
     codec = mi.Codec(frames, w, h, c, tw, th, planar, small_model=small_model) if small_model else mi.Codec(frames, w, h, c, tw, th, planar)
+    for key, val in (expect or {}).items():
+        assert codec.family[key] == val, (key, codec.family)
     st = torch.cuda.current_stream().cuda_stream
     d_px = torch.from_numpy(imgs).cuda()
     cap = min(codec.max_payload_bytes, 2 * imgs.size + 64 * codec.n_slices + 4096)
@@ -329,15 +335,18 @@ def test_batch_codec_small(mi, orc):
     _batch_roundtrip(mi, orc, 2, 61, 50, 1, 61, 1, False, ["g3", "g2"])
 
 
-def test_state_tables_survive_generation_wrap(mi, orc):
+@pytest.mark.parametrize("nocache", ["0", "1"])
+def test_state_tables_survive_generation_wrap(mi, orc, set_hook, nocache):
     """State tables in HBM are not cleared per call: every bank carries the 8-bit generation of the call that wrote it
     (slice_kernels.hip, bank_fresh) and the table is cleared for real once per 255 calls.  600 calls on one codec object,
     three different batches in turn, across two wraps of the generation: every payload equals the oracle's, every decode
     is lossless -- stale states of an earlier call must never leak into a later one."""
     import torch
 
-    frames, w, h, c, tw, th = 2, 96, 80, 3, 16, 16   # 180 slices per call: several slices per wavefront -> tables in HBM
-    codec = mi.Codec(frames, w, h, c, tw, th, True)
+    set_hook("LLCOMP_MI_NOCACHE", nocache)  # (the decoder's bank cache in LDS in front of the tables, or every bank straight from them)
+    frames, w, h, c, tw, th = 2, 96, 80, 3, 8, 8   # 720 slices per call: four slices per wavefront -> tables in HBM (fewer than 192
+    codec = mi.Codec(frames, w, h, c, tw, th, True)  # slices would get one wavefront each and their tables in LDS)
+    assert not codec.family["lds_table"] and not codec.family["rows"] and codec.family["bank_cache"] == (nocache == "0"), codec.family
     st = torch.cuda.current_stream().cuda_stream
     batches, wants = [], []
     for k, gens in enumerate((["g3", "mid"], ["checker", "g1"], ["mid", "g3"])):
@@ -626,11 +635,20 @@ def test_2d_encoder_snapshot_pass_or_state_tables_same_bytes(mi, orc, set_hook):
                 want = orc.compress_sliced(img, tw, th, planar)
             finally:
                 orc.set_small_model(False)
-            for nosnap in ("0", "1"):
+            # (images this small have so few slices that each would get a wavefront of its own and its table in LDS -- neither 2-D
+            # encoder: the lane-group width is forced; the last round runs the geometry as the library picks it)
+            for nosnap, shift in (("0", "6"), ("1", "6"), ("0", "3"), ("0", None)):
                 set_hook("LLCOMP_MI_NOSNAP", nosnap)
+                set_hook("LLCOMP_MI_LANE_SHIFT", shift)  # (None: unset)
                 s = mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar, small_model=small)
-                assert s == want, (w, h, c, tw, th, planar, small, nosnap)
-                assert np.array_equal(mi.decompress_image(s).pixels, img)
+                assert s == want, (w, h, c, tw, th, planar, small, nosnap, shift)
+                assert np.array_equal(mi.decompress_image(s, small_model=small).pixels, img)
+    set_hook("LLCOMP_MI_LANE_SHIFT", "6")
+    for nosnap in ("0", "1"):
+        set_hook("LLCOMP_MI_NOSNAP", nosnap)
+        k = mi.Codec(1, 200, 150, 3, 64, 64, True)
+        assert k.family["snapshot"] == (nosnap == "0") and not k.family["lds_table"], k.family
+        k.close()
 
 
 def test_2d_decoder_bank_cache_or_plain_same_pixels(mi, orc, set_hook):
@@ -664,23 +682,25 @@ def test_2d_decoder_bank_cache_or_plain_same_pixels(mi, orc, set_hook):
     for nocache in ("0", "1"):
         set_hook("LLCOMP_MI_NOCACHE", nocache)
         for gens in (["mid", "g3", "nat"], ["nat", "mid", "mid"]):
-            assert _batch_roundtrip(mi, orc, 3, 260, 90, 3, 64, 45, True, gens) > 0
+            assert _batch_roundtrip(mi, orc, 3, 260, 90, 3, 64, 45, True, gens, expect={"bank_cache": nocache == "0", "lds_table": False, "snapshot": True}) > 0
 
 
 @pytest.mark.parametrize("tile", [(32, 32, True), (33, 31, True), (32, 33, True), (64, 32, True), (64, 33, True), (65, 63, True), (64, 64, True),
                                   (1365, 3, True), (16, 21, False), (26, 26, False), (37, 37, False), (4, 2, True)],
                          ids=lambda t: "%dx%d%s" % (t[0], t[1], "p" if t[2] else "i"))
-def test_snapshot_pass_capacity_classes(mi, orc, tile):
+def test_snapshot_pass_capacity_classes(mi, orc, tile, set_hook):
     """The snapshot pass sorts a slice's samples in one of three capacity classes (1024 / 2048 / 4096 keys) and moves its arrays
     in pieces of 8 / 16 samples: slices of exactly, one below and one above every boundary (planar: tile_w x tile_h samples;
     interleaved RGB: x 3), a batch of three frames so that the slice count is no multiple of a lane group, ragged last tiles."""
     tw, th, planar = tile
     w, h = min(2 * tw + 5, 1400), 2 * th + 3
     total = 0
+    set_hook("LLCOMP_MI_LANE_SHIFT", "6")  # (so few slices would get one wavefront each and their tables in LDS: no snapshot pass)
     for small in (False, True):
         orc.set_small_model(small)
         try:
-            total += _batch_roundtrip(mi, orc, 3, w, h, 3, tw, th, planar, ["g3", "nat", "mid"], small_model=small)
+            total += _batch_roundtrip(mi, orc, 3, w, h, 3, tw, th, planar, ["g3", "nat", "mid"], small_model=small,
+                                      expect={"snapshot": tw * th * (1 if planar else 3) <= 4096, "lds_table": False, "bank_cache": True})
         finally:
             orc.set_small_model(False)
     assert total > 0
