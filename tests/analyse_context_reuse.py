@@ -35,8 +35,55 @@ def lru_hits(seq, n):
     return hit
 
 
+def direct_mapped_hits(seq, n, ways=1):
+    """hits of an n-entry cache indexed by the low context bits (the decoder's bank cache, slice_kernels.hip: CACHE); ways = 2:
+    two-way sets with LRU inside a set"""
+    if ways == 1:
+        tags, hit = [-1] * n, 0
+        for c in seq:
+            s = c & (n - 1)
+            if tags[s] == c:
+                hit += 1
+            else:
+                tags[s] = c
+        return hit
+    sets = [[-1, -1] for _ in range(n // 2)]
+    hit = 0
+    for c in seq:
+        e = sets[c & (n // 2 - 1)]
+        if e[0] == c:
+            hit += 1
+        elif e[1] == c:
+            hit += 1
+            e[0], e[1] = e[1], e[0]
+        else:
+            e[1], e[0] = e[0], c
+    return hit
+
+
+def direct_mapped_table(orc):
+    """Round 5 (profiles/r05_bank_cache_ab.txt): what a direct-mapped / two-way cache of 16..128 banks per lane hits, and how the
+    hit rate of the first rows differs from the rest of a slice (the bypass decision looks at four rows at a time).
+        python tests/analyse_context_reuse.py dm"""
+    print("direct-mapped (low context bits) and two-way hit rates, 64x64 planar slices of a 3840x2160 RGB8 frame, 20 slices per content")
+    for gen in ("nat", "mid", "g3"):
+        rct = orc.forward_rct(synth.GENERATORS[gen](W, H, 3))
+        rng = np.random.default_rng(1)
+        seqs = []
+        for _ in range(20):
+            tx, ty, ch = int(rng.integers(0, W // 64)), int(rng.integers(0, H // 64)), int(rng.integers(0, 3))
+            ctx, _res = orc.model_samples(rct[ty * 64:(ty + 1) * 64, tx * 64:(tx + 1) * 64, ch:ch + 1])
+            seqs.append([int(x) for x in ctx.reshape(-1)])
+        total = sum(len(s) for s in seqs)
+        row = "  ".join(f"{n}: {sum(direct_mapped_hits(s, n) for s in seqs) / total:.3f} / {sum(direct_mapped_hits(s, n, 2) for s in seqs) / total:.3f}" for n in (16, 32, 64, 128))
+        first = sum(direct_mapped_hits(s[:512], 32) for s in seqs) / (512 * len(seqs))
+        print(f"{gen}: entries: direct-mapped / two-way   {row}   | 32 entries, first 512 samples only: {first:.3f}")
+
+
 def main():
     orc = orc_mod.Orc()
+    if len(sys.argv) > 1 and sys.argv[1] == "dm":
+        return direct_mapped_table(orc)
     print("LRU hit rates of per-slice state-bank caches, 64x64 planar slices of a 3840x2160 RGB8 frame (20 random slices per content)")
     for gen in ("nat", "mid", "g3", "g2"):
         rct = orc.forward_rct(synth.GENERATORS[gen](W, H, 3))
