@@ -154,7 +154,12 @@ constexpr uint32_t kEntryPosShift = 10, kEntryFirstBit = 22;
 template <uint32_t kOwn>
 __global__ __launch_bounds__(kSortThreads) void k_snap_sort(const Geometry g, const uint32_t cap, const uint32_t* __restrict__ sym,
                                                            uint8_t* __restrict__ entries) {
-    __shared__ uint32_t key_a[kOwn * kRowPad], key_b[kOwn * kRowPad];
+    // ONE key buffer: a pass reads its thread's keys into registers first and scatters them behind two barriers, so source and
+    // destination may be the same array.  (With two buffers the kernel held 49 KB of LDS per workgroup; beside the 2-D decoder,
+    // whose wavefronts keep 19.5 KB each for their bank cache, a CU then rarely had room for a sorting workgroup at all: 10.1 ms
+    // per launch at 48 frames x 3 pipelines where the kernel alone takes 1.6.)
+    __shared__ uint32_t key_a[kOwn * kRowPad];
+    uint32_t* const key_b = key_a;
     __shared__ uint32_t cnt[8 * kSortThreads];
     __shared__ uint32_t tot[8];
     __shared__ int16_t res_of[kOwn * kSortThreads];
