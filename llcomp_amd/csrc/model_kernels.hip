@@ -245,9 +245,12 @@ __device__ __forceinline__ unsigned long long wave_inclusive_scan(unsigned long 
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_group_sums(const uint32_t* __restrict__ len, uint32_t n, uint32_t lane_shift,
+// (One wavefront per workgroup, here and in k_scan_groups: beside the slice kernels, whose one-wavefront workgroups take every
+// wave slot as it comes free, a workgroup of four wavefronts waits until four slots of ONE CU are free at the same moment.)
+constexpr uint32_t kSumThreads = 64;
+__global__ __launch_bounds__(kSumThreads) void k_group_sums(const uint32_t* __restrict__ len, uint32_t n, uint32_t lane_shift,
                                                     uint64_t* __restrict__ group_sum) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = blockIdx.x * kSumThreads + threadIdx.x;
     unsigned long long v = i < n ? len[i] : 0;
     for (uint32_t d = 1; d < (1u << lane_shift); d <<= 1) v += __shfl_xor(v, int(d), 64);  // groups are aligned pieces of a wave
     if ((i & ((1u << lane_shift) - 1)) == 0 && i < n) group_sum[i >> lane_shift] = v;
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256) void k_frame_bytes(const uint32_t* __restrict_
     if (threadIdx.x == 0) out[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
-constexpr uint32_t kScanThreads = 256, kScanPerThread = 4;
+constexpr uint32_t kScanThreads = 64, kScanPerThread = 16;
 // in: sums[0 .. ng)   out: sums[g] = sum of the groups before g, sums[ng] = *total = sum of all
 __global__ __launch_bounds__(kScanThreads) void k_scan_groups(uint64_t* __restrict__ sums, uint32_t ng, uint64_t* total) {
     __shared__ unsigned long long wave_sum[kScanThreads / 64];
@@ -967,7 +970,7 @@ hipError_t launch_model_inv(const Geometry& g, const int16_t* d_rec, uint8_t* d_
 }
 
 hipError_t launch_group_sums(const Geometry& g, const uint32_t* d_slice_len, uint64_t* d_group_off, hipStream_t stream) {
-    k_group_sums<<<dim3((g.n_slices + 255) / 256), dim3(256), 0, stream>>>(d_slice_len, g.n_slices, g.lane_shift, d_group_off);
+    k_group_sums<<<dim3((g.n_slices + kSumThreads - 1) / kSumThreads), dim3(kSumThreads), 0, stream>>>(d_slice_len, g.n_slices, g.lane_shift, d_group_off);
     return hipGetLastError();
 }
 
