@@ -324,45 +324,72 @@ __global__ __launch_bounds__(kWalkThreads) void k_snap_walk(const Geometry g, co
 }
 
 // ---- back into stream order --------------------------------------------------------------------------------------------------
-constexpr uint32_t kUnpermThreads = kSnapMaxSamples / 8;  // a thread moves eight entries and their eight banks
+// One workgroup per slice, 256 threads, HALF a slice's positions at a time (kUnpermSpan = 2048): a thread keeps its two pieces of
+// eight entries and banks in registers, scatters the ones whose stream position falls into the current half into LDS, and the
+// workgroup writes that half out in order.  (Round 4: 512 threads and all 4096 positions at once = 41 KB of LDS and eight wave
+// slots on one CU per workgroup; beside the cached decoder's wavefronts such a workgroup waits long for its place.)
+constexpr uint32_t kUnpermThreads = 256, kUnpermSpan = 2048;
 __global__ __launch_bounds__(kUnpermThreads) void k_snap_unperm(const Geometry g, const uint32_t cap, const uint8_t* __restrict__ entries,
                                                                const uint8_t* __restrict__ sorted_banks, uint8_t* __restrict__ banks,
                                                                uint8_t* __restrict__ residuals) {
-    __shared__ __attribute__((aligned(16))) uint2 bank_of[kSnapMaxSamples];
-    __shared__ __attribute__((aligned(16))) int16_t res_of[kSnapMaxSamples];
+    __shared__ __attribute__((aligned(16))) uint2 bank_of[kUnpermSpan];
+    __shared__ __attribute__((aligned(16))) int16_t res_of[kUnpermSpan];
     uint32_t id, group, lane;
     if (!block_slice(g, id, group, lane)) return;
     const uint32_t n = slice_span(g, id).n;
-    const uint32_t q = threadIdx.x;
+    const uint32_t t = threadIdx.x;
     const size_t row = size_t(32) << g.lane_shift;
     const uint8_t* const ein = entries + size_t(group) * (size_t(cap) * 4 << g.lane_shift) + lane * 32u;
     const uint8_t* const bin = sorted_banks + size_t(group) * (size_t(cap) * 8 << g.lane_shift) + lane * 64u;
-    if (q * 8 < n) {  // one piece of eight entries, one piece of their eight banks: six loads in flight, then the scatter
-        const uint4* ep = reinterpret_cast<const uint4*>(ein + q * row);
-        const uint4* bp = reinterpret_cast<const uint4*>(bin + q * (2 * row));
-        const uint4 ea = ep[0], eb = ep[1], b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
-        const uint32_t e[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
-        const uint32_t bx[8] = {b0.x, b0.z, b1.x, b1.z, b2.x, b2.z, b3.x, b3.z};
-        const uint32_t by[8] = {b0.y, b0.w, b1.y, b1.w, b2.y, b2.w, b3.y, b3.w};
-#pragma unroll
-        for (uint32_t j = 0; j < 8; ++j) {
-            if (q * 8 + j < n) {
-                const uint32_t k = (e[j] >> kEntryPosShift) & 0xFFFu;
-                bank_of[k] = make_uint2(bx[j], by[j]);
-                res_of[k] = int16_t(int32_t(e[j] << 22) >> 22);
-            }
-        }
-    }
-    __syncthreads();
     uint8_t* const bout = banks + size_t(group) * (size_t(cap) * 8 << g.lane_shift) + lane * 64u;
     uint8_t* const rout = residuals + size_t(group) * (size_t(cap) * 2 << g.lane_shift) + lane * 32u;
-    // out: 16-byte chunks, neighbouring threads the neighbouring chunks of a piece (whole sectors per store instruction, see
-    // k_snap_sort)
-    for (uint32_t u = 0; u < 4; ++u) {  // (the workgroup has a thread per eight samples of the capacity: four chunks of two banks each)
-        const uint32_t c = q + blockDim.x * u;
-        if (c * 2 < n) *reinterpret_cast<uint4*>(bout + size_t(c >> 2) * (2 * row) + ((c & 3u) << 4)) = *reinterpret_cast<const uint4*>(&bank_of[c * 2]);
+    // this thread's pieces: q = t and q = t + 256 (a piece = eight entries + their eight banks; twelve loads in flight)
+    uint32_t e[2][8], bx[2][8], by[2][8];
+#pragma unroll
+    for (uint32_t h = 0; h < 2; ++h) {
+        const uint32_t q = t + kUnpermThreads * h;
+        if (q * 8 < n) {
+            const uint4* ep = reinterpret_cast<const uint4*>(ein + q * row);
+            const uint4* bp = reinterpret_cast<const uint4*>(bin + q * (2 * row));
+            const uint4 ea = ep[0], eb = ep[1], b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+            e[h][0] = ea.x; e[h][1] = ea.y; e[h][2] = ea.z; e[h][3] = ea.w; e[h][4] = eb.x; e[h][5] = eb.y; e[h][6] = eb.z; e[h][7] = eb.w;
+            bx[h][0] = b0.x; bx[h][1] = b0.z; bx[h][2] = b1.x; bx[h][3] = b1.z; bx[h][4] = b2.x; bx[h][5] = b2.z; bx[h][6] = b3.x; bx[h][7] = b3.z;
+            by[h][0] = b0.y; by[h][1] = b0.w; by[h][2] = b1.y; by[h][3] = b1.w; by[h][4] = b2.y; by[h][5] = b2.w; by[h][6] = b3.y; by[h][7] = b3.w;
+        }
     }
-    if (q * 8 < n) *reinterpret_cast<uint4*>(rout + size_t(q >> 1) * row + ((q & 1u) << 4)) = *reinterpret_cast<const uint4*>(&res_of[q * 8]);
+    for (uint32_t base = 0; base < n; base += kUnpermSpan) {  // (uniform per workgroup)
+#pragma unroll
+        for (uint32_t h = 0; h < 2; ++h) {
+            const uint32_t q = t + kUnpermThreads * h;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+                if (q * 8 + j < n) {
+                    const uint32_t k = ((e[h][j] >> kEntryPosShift) & 0xFFFu) - base;  // (wraps for positions below the half)
+                    if (k < kUnpermSpan) {
+                        bank_of[k] = make_uint2(bx[h][j], by[h][j]);
+                        res_of[k] = int16_t(int32_t(e[h][j] << 22) >> 22);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // out: 16-byte chunks, neighbouring threads the neighbouring chunks of a piece (whole sectors per store instruction, see
+        // k_snap_sort); chunk c of the half = banks 2c, 2c+1 / residuals 8c .. 8c+7
+        const uint32_t left = n - base;  // samples from `base` on (more than the span: this half is full)
+#pragma unroll
+        for (uint32_t u = 0; u < kUnpermSpan / 2 / kUnpermThreads; ++u) {
+            const uint32_t c = t + kUnpermThreads * u;
+            if (c * 2 < left) {
+                const uint32_t cg = c + base / 2;  // chunk index in the slice
+                *reinterpret_cast<uint4*>(bout + size_t(cg >> 2) * (2 * row) + ((cg & 3u) << 4)) = *reinterpret_cast<const uint4*>(&bank_of[c * 2]);
+            }
+        }
+        if (t * 8 < left && t < kUnpermSpan / 8) {
+            const uint32_t qg = t + base / 8;
+            *reinterpret_cast<uint4*>(rout + size_t(qg >> 1) * row + ((qg & 1u) << 4)) = *reinterpret_cast<const uint4*>(&res_of[t * 8]);
+        }
+        __syncthreads();
+    }
 }
 
 }  // namespace
@@ -382,8 +409,7 @@ hipError_t launch_snapshot(const Geometry& g, const uint32_t* d_sym, void* d_ent
     const uint32_t waves = (g.n_slices + g.lpw - 1) / g.lpw;
     k_snap_walk<<<dim3((waves + kWalkThreads / 64 - 1) / (kWalkThreads / 64)), dim3(kWalkThreads), 0, stream>>>(
         g, g.lpw, cap, static_cast<const uint8_t*>(d_entries), static_cast<uint8_t*>(d_sorted));
-    const uint32_t unperm_threads = std::min(kUnpermThreads, ((cap / 8 + 63u) / 64u) * 64u);  // a thread per eight samples of the capacity
-    k_snap_unperm<<<dim3(blocks), dim3(unperm_threads), 0, stream>>>(g, cap, static_cast<const uint8_t*>(d_entries),
+    k_snap_unperm<<<dim3(blocks), dim3(kUnpermThreads), 0, stream>>>(g, cap, static_cast<const uint8_t*>(d_entries),
                                                          static_cast<const uint8_t*>(d_sorted), static_cast<uint8_t*>(d_banks),
                                                          static_cast<uint8_t*>(d_residuals));
     return hipGetLastError();
