@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_groups(uint64_t* __restri
 // cache lines.  (With per-lane contiguous streams rocprofv3 showed 6.8 GB fetched per decode launch for 0.5 GB of
 // payload.)  These two kernels move whole groups between that order and the packed payload of the container through
 // a 64 x 256-byte LDS tile: unit reads/writes are 1 KiB rows, payload reads/writes are 256-byte runs per slice.
-constexpr int kChunkDwords = 64;  // 256 bytes of every slice per LDS tile
+constexpr int kChunkDwords = 32;  // 128 bytes of every slice per LDS tile (64 = 16.6 KB of LDS per workgroup: measured slower beside the slice kernels)
 
 __device__ __forceinline__ uint32_t load_bytes_le(const uint8_t* p, uint32_t n) {  // n = 1..3
     uint32_t w = p[0];
@@ -356,6 +356,10 @@ __device__ __forceinline__ void load_group_streams(const Geometry& g, uint32_t g
 }
 
 // stream lane order -> packed payload (after the encoder)
+// Thread layout of the payload side: a run of kChunkDwords dwords of one slice is moved by kChunkDwords neighbouring threads;
+// 256 / kChunkDwords slices per pass.
+constexpr uint32_t kRunThreads = kChunkDwords, kRunsPerPass = 256 / kChunkDwords, kChunkBytes = kChunkDwords * 4, kChunkUnits = kChunkDwords / 4;
+static_assert(kChunkUnits % 4 == 0 && kChunkDwords % 4 == 0 && 256 % kChunkDwords == 0, "thread layouts of pack / stage");
 __global__ __launch_bounds__(256) void k_pack_payload(const Geometry g, const uint4* __restrict__ units,
                                                       const uint32_t* __restrict__ slice_len,
                                                       const uint64_t* __restrict__ off, uint8_t* __restrict__ payload,
@@ -366,31 +370,33 @@ __global__ __launch_bounds__(256) void k_pack_payload(const Geometry g, const ui
     load_group_streams(g, group, slice_len, off, payload_cap, status, kStOverflow, gs);
     const uint32_t cap16 = g.slice_cap >> 4;
     const uint32_t a = threadIdx.x & 63, b = threadIdx.x >> 6;
-    // 1 KiB rows of units.  All four loads of a thread are in flight before the first is stored (see k_model_rows_inv),
-    // and the loads of the NEXT 256-byte chunk are issued before this chunk's stores: they fly during the store phase.
-    uint4 v[4];
+    const uint32_t dw = threadIdx.x % kRunThreads, jb = threadIdx.x / kRunThreads;
+    // 1 KiB rows of units.  All loads of a thread are in flight before the first is stored (see k_model_rows_inv),
+    // and the loads of the NEXT chunk are issued before this chunk's stores: they fly during the store phase.
+    constexpr int LPT = kChunkUnits / 4;  // units per thread and chunk
+    uint4 v[LPT];
     auto request = [&](uint32_t c0) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const uint32_t u = c0 * 16 + b + 4 * t;
+        for (int t = 0; t < LPT; ++t) {
+            const uint32_t u = c0 * kChunkUnits + b + 4 * t;
             v[t] = make_uint4(0, 0, 0, 0);
             if (u < cap16 && a < (1u << g.lane_shift)) v[t] = units[((size_t(group) * cap16 + u) << g.lane_shift) + a];
         }
     };
     if (gs.max_len) request(0);
-    for (uint32_t c0 = 0; c0 * 256 < gs.max_len; ++c0) {
+    for (uint32_t c0 = 0; c0 * kChunkBytes < gs.max_len; ++c0) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < LPT; ++t) {
             const uint32_t uu = b + 4 * t;
             tile[a][uu * 4 + 0] = v[t].x; tile[a][uu * 4 + 1] = v[t].y; tile[a][uu * 4 + 2] = v[t].z; tile[a][uu * 4 + 3] = v[t].w;
         }
         __syncthreads();
-        if ((c0 + 1) * 256 < gs.max_len) request(c0 + 1);
-        for (uint32_t j = b; j < 64; j += 4) {  // 256-byte runs of one slice
-            const uint32_t n = gs.len[j], p = c0 * 256 + a * 4;
+        if ((c0 + 1) * kChunkBytes < gs.max_len) request(c0 + 1);
+        for (uint32_t j = jb; j < 64; j += kRunsPerPass) {  // runs of one slice
+            const uint32_t n = gs.len[j], p = c0 * kChunkBytes + dw * 4;
             if (p < n) {
                 uint8_t* dst = payload + gs.off[j] + p;
-                const uint32_t w = tile[j][a];
+                const uint32_t w = tile[j][dw];
                 if (p + 4 <= n) {
                     __builtin_memcpy(dst, &w, 4);  // byte offset of a slice is arbitrary: unaligned dword store
                 } else {
@@ -413,15 +419,17 @@ __global__ __launch_bounds__(256) void k_stage_streams(const Geometry g, const u
     load_group_streams(g, group, slice_len, off, payload_bytes, status, kStTruncated, gs);
     const uint32_t capdw = g.slice_cap >> 2;
     const uint32_t a = threadIdx.x & 63, b = threadIdx.x >> 6;
+    const uint32_t dwi = threadIdx.x % kRunThreads, jb = threadIdx.x / kRunThreads;
     // "+ 4": the dword right behind every stream is staged too (as zeros) -- the decoder clamps its reads to it.
-    // All sixteen loads of a thread are in flight before the first is stored, and the loads of the NEXT chunk are issued
+    // All loads of a thread are in flight before the first is stored, and the loads of the NEXT chunk are issued
     // before this chunk's stores.  The last, partial dword of a stream is read as a whole dword and masked wherever the
     // payload has the bytes (always, except at its very end).
-    uint32_t w[16];
+    constexpr int LPT = 64 / kRunsPerPass;  // slices per thread and chunk
+    uint32_t w[LPT];
     auto request = [&](uint32_t c0) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const uint32_t j = b + 4 * t, n = gs.len[j], p = c0 * 256 + a * 4;
+        for (int t = 0; t < LPT; ++t) {
+            const uint32_t j = jb + kRunsPerPass * t, n = gs.len[j], p = c0 * kChunkBytes + dwi * 4;
             w[t] = 0;
             if (p < n) {
                 const unsigned long long at = gs.off[j] + p;
@@ -432,15 +440,15 @@ __global__ __launch_bounds__(256) void k_stage_streams(const Geometry g, const u
         }
     };
     request(0);
-    for (uint32_t c0 = 0; c0 * 256 < gs.max_len + 4; ++c0) {
+    for (uint32_t c0 = 0; c0 * kChunkBytes < gs.max_len + 4; ++c0) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {  // (the mask is applied here, not above: nothing waits for a load before all are issued)
-            const uint32_t j = b + 4 * t, n = gs.len[j], p = c0 * 256 + a * 4;
+        for (int t = 0; t < LPT; ++t) {  // (the mask is applied here, not above: nothing waits for a load before all are issued)
+            const uint32_t j = jb + kRunsPerPass * t, n = gs.len[j], p = c0 * kChunkBytes + dwi * 4;
             const uint32_t keep = n >= p + 4 ? 0xFFFFFFFFu : n > p ? 0xFFFFFFFFu >> (8 * (p + 4 - n)) : 0u;
-            tile[j][a] = w[t] & keep;
+            tile[j][dwi] = w[t] & keep;
         }
         __syncthreads();
-        if ((c0 + 1) * 256 < gs.max_len + 4) request(c0 + 1);
+        if ((c0 + 1) * kChunkBytes < gs.max_len + 4) request(c0 + 1);
         // DWORD lane order for the decoder, [group][dword k][lane]: a wavefront stores one 256-byte row per dword index
         uint32_t* const dw = reinterpret_cast<uint32_t*>(units);
         for (uint32_t kk = b; kk < kChunkDwords; kk += 4) {
