@@ -43,12 +43,12 @@ RMW_UBENCH = 24.06e9       # uniformly random dependent 8-byte read-modify-write
                            # the kernels: their contexts are not uniformly random (lanes share lines, the decoder skips unchanged banks)
 # HBM bytes per sample of the 2-D tile legs' kernels, (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction) / samples, from the
 # committed PMC passes of 16 frames / one pipeline (tools/prof_2d.sh).  encode_all_kernels = stage A 5.4 + k_snap_sort 8.0 + k_snap_walk
-# 12.0 + k_snap_unperm 22.0 + k_encode_slices + k_pack_payload; decode_all_kernels = k_stage_streams + k_decode_slices + k_from_lane_order
+# 12.0 + k_snap_unperm 22.2 + k_encode_slices + k_pack_payload; decode_all_kernels = k_stage_streams + k_decode_slices + k_from_lane_order
 # 4.0 + inverse stage A 3.0.  Round 3's encoder (state tables in HBM) moved 131 (g3) / 147 (nat) in k_encode_slices alone; round 4's
 # decoder (two memory round trips per sample, every bank fetched and written in HBM) 156 / 168 in k_decode_slices.
 TILE_HBM_SOURCE = "profiles/r05_tiles64_f16_{g3,nat}_pmc_summary.txt (KiB counters x 1024)"
-TILE_HBM_BYTES_PER_SAMPLE = {"g3": {"k_encode_slices": 12.9, "encode_all_kernels": 63.6, "k_decode_slices": 98.7, "decode_all_kernels": 109.1},
-                             "nat": {"k_encode_slices": 10.7, "encode_all_kernels": 58.9, "k_decode_slices": 120.6, "decode_all_kernels": 128.5}}
+TILE_HBM_BYTES_PER_SAMPLE = {"g3": {"k_encode_slices": 12.9, "encode_all_kernels": 64.1, "k_decode_slices": 98.7, "decode_all_kernels": 108.9},
+                             "nat": {"k_encode_slices": 10.7, "encode_all_kernels": 59.1, "k_decode_slices": 120.6, "decode_all_kernels": 128.4}}
 
 
 def make_frames(content, frames, rank, w=W4K, h=H4K, c=C4K, distinct=None):
