@@ -621,11 +621,13 @@ def test_one_row_slices_through_both_kernel_families(mi, orc, set_hook):
 
 def test_2d_encoder_snapshot_pass_or_state_tables_same_bytes(mi, orc, set_hook):
     """Slices of several rows and at most 4096 samples are encoded through the state snapshot pass (context sort, walk,
-    unpermute: snapshot_kernels.hip); LLCOMP_MI_NOSNAP=1 keeps the per-slice state tables in HBM (the round-3 encoder, still
-    used for bigger slices).  Same bytes either way: ragged tiles, every channel count, interleaved and planar, both model
+    unpermute: snapshot_kernels.hip); LLCOMP_MI_NOSNAP=1 keeps the per-slice state tables in HBM (the table encoder, which
+    bigger slices always take: 128x128 and 256x256 planes, 64x64 interleaved RGB).  Same bytes either way: ragged tiles, every channel count, interleaved and planar, both model
     sizes, a slice of exactly 4096 samples, slices narrower than a lane group."""
     cases = [(200, 150, 3, 64, 64, True), (200, 150, 3, 32, 32, False), (130, 67, 1, 64, 64, True), (97, 41, 2, 50, 21, False),
-             (300, 20, 4, 128, 8, True), (64, 64, 3, 64, 64, True), (37, 29, 4, 16, 16, False), (500, 9, 3, 480, 2, True)]
+             (300, 20, 4, 128, 8, True), (64, 64, 3, 64, 64, True), (37, 29, 4, 16, 16, False), (500, 9, 3, 480, 2, True),
+             # slices above 4096 samples: the table encoder both ways (next sample's bank in flight while a sample is coded, round 5)
+             (300, 280, 3, 128, 128, True), (200, 150, 3, 64, 64, False), (520, 300, 1, 256, 256, True)]
     for i, (w, h, c, tw, th, planar) in enumerate(cases):
         img = make_image("g3", w, h, c)
         img[:, w // 2:] = make_image("nat" if i & 1 else "mid", w - w // 2, h, c)
