@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 5, profiles/r05_helper_wait.txt; the second library was a build with another kChunkDwords in model_kernels.hip, or with 16 KB
+# of unused LDS added to both kernels: build it from the tree as llcomp_amd/libllcomp_mi_ch32.so before running this)
 # Runs on the GPU box: pack / stage with 128-byte chunks (8.4 KB of LDS) against 256-byte chunks (16.6 KB: libllcomp_mi_ch32.so), 64x64 tiles at 48 x 3 and the headline
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/pad_ab; mkdir -p $out
