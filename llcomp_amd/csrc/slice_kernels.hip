@@ -1201,8 +1201,8 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
         for (uint32_t y = 0; y < r.sh; ++y) {
             if constexpr (CACHE != 0) {
                 const uint32_t yu = __builtin_amdgcn_readfirstlane(y);
-                if (use_cache && yu >= 8 && (yu & 3) == 0) {
-                    if (n_miss * 8 > n_seen * 7) {  // fewer than 1 hit in 8
+                if (use_cache && yu >= 4 && (yu & 3) == 0) {  // (the counters start over at row 4: the first rows hit more than the rest)
+                    if (yu >= 8 && n_miss * 8 > n_seen * 7) {  // fewer than 1 hit in 8 over the last four rows
                         const uint64_t* c_banks = reinterpret_cast<const uint64_t*>(dyn_lds) + threadIdx.x;
                         const uint8_t* c_tags = dyn_lds + (512u << CACHE) + threadIdx.x;
 #pragma unroll 1
