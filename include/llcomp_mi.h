@@ -24,11 +24,12 @@
 extern "C" {
 #endif
 
-/* ABI 3.  The library and its callers are built from ONE header: structs have one layout per ABI version (llcomp_mi_opts is
+/* ABI 4 (round 6: device lists -- llcomp_mi_opts.devices, llcomp_mi_decode_devices, llcomp_mi_stream_create_multi,
+ * llcomp_mi_plan_chunks, llcomp_mi_codec_get_counters).  The library and its callers are built from ONE header: structs have one layout per ABI version (llcomp_mi_opts is
  * checked through struct_size and refused when it differs; llcomp_mi_info and llcomp_mi_stream_result are written in full),
  * so a binding compares llcomp_mi_abi_version() with the LLCOMP_MI_ABI_VERSION it was generated from and refuses to run on
  * a mismatch -- there is no cross-version compatibility mode. */
-#define LLCOMP_MI_ABI_VERSION 3
+#define LLCOMP_MI_ABI_VERSION 4
 
 /* Wire formats.  LEGACY is the reference's own: [0x79][channels u8][width u16 LE][height u16 LE] + ONE
  * range-coded stream (llcomp.hpp:375-378); it is a single serial chain (one GPU lane).  SLICED is this
@@ -53,7 +54,10 @@ typedef enum llcomp_mi_status {
     LLCOMP_MI_HIP_ERROR = 7,       /* a HIP call failed, or a kernel found its own launch assumptions violated and refused to run */
     LLCOMP_MI_NO_DEVICE = 8,
     LLCOMP_MI_NOMEM = 9,
-    LLCOMP_MI_BUSY = 10            /* streaming pipeline: every slot is occupied / the oldest job is still in flight */
+    LLCOMP_MI_BUSY = 10,           /* streaming pipeline: every slot is occupied / the oldest job is still in flight */
+    LLCOMP_MI_DEVICE_FAILED = 11   /* a call over a device list: one of the devices failed (HIP error, out of memory, no such device) and
+                                      nothing was published; llcomp_mi_last_device_error tells which one and why.  Verdicts about the
+                                      DATA (BAD_EXPONENT, TRUNCATED, OUTPUT_OVERFLOW) come back as themselves from any device. */
 } llcomp_mi_status;
 
 typedef enum llcomp_mi_format { LLCOMP_MI_FORMAT_LEGACY = 0, LLCOMP_MI_FORMAT_SLICED = 1 } llcomp_mi_format;
@@ -66,7 +70,19 @@ typedef struct llcomp_mi_opts {
     uint32_t planar;      /* 1 = one slice per colour-transformed channel plane, 0 = channels interleaved */
     int32_t device;       /* HIP device ordinal, -1 = current device */
     uint32_t small_model; /* 1 = code like a reference built with LargeModel = false */
+    /* One image over several GPUs, in this process (BASELINE config 4; SURVEY 8b "device list").  n_devices == 0: one device
+     * (`device`).  n_devices >= 1 (SLICED only; at most LLCOMP_MI_MAX_DEVICES): the image's tile rows are dealt in chunks
+     * round-robin over devices[0..n_devices) (llcomp_mi_plan_chunks), every device gets ONLY its rows over its own PCIe link,
+     * codes them with its own lane and copies its payload straight to its place in the container -- there is no exchange between
+     * the GPUs and no collective, and the container is byte-identical to the one-device container.  An ordinal may repeat (two
+     * lanes on one GPU: how the path is tested on a one-GPU box).  A LEGACY stream is one serial chain and does not shard:
+     * devices[0] codes it.  `device` is ignored when n_devices > 0. */
+    uint32_t n_devices;
+    const int32_t* devices;
+    uint32_t chunks_per_device; /* chunks of tile rows per device (0 = 4): finer chunks balance content whose cost varies over the image */
+    uint32_t reserved;          /* 0 */
 } llcomp_mi_opts;
+#define LLCOMP_MI_MAX_DEVICES 64
 #define LLCOMP_MI_FLAG_SMALL_MODEL 1u /* llcomp_mi_decode_flags / llcomp_mi_codec_create_ex */
 
 /* ---- host-buffer API: drop-in for compressImage / decompressImage ------------------------------------ */
@@ -82,6 +98,20 @@ int llcomp_mi_decode(const uint8_t* data, size_t len, int32_t device, uint8_t** 
 int llcomp_mi_decode_flags(const uint8_t* data, size_t len, int32_t device, uint32_t flags, uint8_t** px, uint32_t* w,
                            uint32_t* h, uint32_t* c);
 void llcomp_mi_free(void* p);
+/* Decoding over a device list: the mirror image of llcomp_mi_opts.devices -- every device receives the table entries and payload
+ * bytes of its chunks of tile rows, decodes them and copies its rows straight to their place in the picture.  Nothing is written to
+ * the output before EVERY device has reported success (the first failing device in list order decides the status).  How the
+ * container was encoded (one device or many, which chunking) does not matter.  A LEGACY stream goes to devices[0]; so does a
+ * container whose slice table does not fit its payload (the one-device path forms the verdict for damaged input).
+ * n_devices == 0 or devices == NULL: BAD_ARGS.  chunks_per_device: 0 = 4. */
+int llcomp_mi_decode_devices(const uint8_t* data, size_t len, const int32_t* devices, uint32_t n_devices, uint32_t chunks_per_device,
+                             uint32_t flags, uint8_t** px, uint32_t* w, uint32_t* h, uint32_t* c);
+int llcomp_mi_decode_into_devices(const uint8_t* data, size_t len, const int32_t* devices, uint32_t n_devices, uint32_t chunks_per_device,
+                                  uint32_t flags, uint8_t* px, size_t px_cap, uint32_t* w, uint32_t* h, uint32_t* c);
+/* After a call of THIS thread returned LLCOMP_MI_DEVICE_FAILED: the HIP ordinal that failed, its position in the device list and the
+ * status it reported (HIP_ERROR, NOMEM, NO_DEVICE, BAD_ARGS for an ordinal that does not exist).  Returns 0 and leaves the outputs
+ * alone when the thread's last device-list call did not fail that way.  Any pointer may be NULL. */
+int llcomp_mi_last_device_error(int32_t* device, uint32_t* index, int* status);
 /* The same two calls with CALLER-PROVIDED output buffers (nothing is allocated for the caller).  If the capacity is too
  * small they return LLCOMP_MI_OUTPUT_OVERFLOW and report what it takes (*out_len; *w,*h,*c), and nothing is written.
  * Every host-buffer call works on a private HIP stream (never the NULL stream); with input and output buffers from
@@ -141,6 +171,13 @@ int llcomp_mi_merge_bands(const uint8_t* const* bands, const size_t* band_lens, 
                           size_t* out_len);
 int llcomp_mi_split_band(const uint8_t* data, size_t len, uint32_t tile_row0, uint32_t tile_row1, uint8_t** out,
                          size_t* out_len);
+/* The work split of every multi-GPU path (device lists here, ranks in llcomp_amd/sharding.py -- ONE implementation): the tile rows of
+ * an image of `height` pixel rows in consecutive chunks, chunk i owned by part i % n_parts; chunks are as even as the tile grid allows,
+ * and with fewer tile rows than n_parts * chunks_per_part every chunk is one tile row.  Writes (tile_row0, tile_row1, owner) triples
+ * to `triples` (room for cap_chunks of them; NULL = only count) and the number of chunks to *n_chunks.  OUTPUT_OVERFLOW when
+ * cap_chunks is too small (*n_chunks says what it takes).  tile_h 0 or > height = the whole height; chunks_per_part 0 = 4. */
+int llcomp_mi_plan_chunks(uint32_t height, uint32_t tile_h, uint32_t n_parts, uint32_t chunks_per_part, uint32_t* triples,
+                          uint32_t cap_chunks, uint32_t* n_chunks);
 
 /* ---- device-resident batch codec: buffers stay in HBM, work is enqueued on the caller's stream --------- */
 /* One codec object = fixed geometry (frames x h x w x c, tiling) + its own workspace on one device.
@@ -234,6 +271,14 @@ int llcomp_mi_stream_create(llcomp_mi_stream** stream, int32_t device, uint32_t 
  * hands out container / frame f of a result that has been returned by wait and not yet released. */
 int llcomp_mi_stream_create_ex(llcomp_mi_stream** stream, int32_t device, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w,
                                uint32_t tile_h, uint32_t planar, uint32_t depth, uint32_t frames_per_job);
+/* The same pipeline over a device list (BASELINE config 5 "round-robin over the GPUs"): one pipeline of `depth` slots PER
+ * DEVICE behind one object; jobs are dealt round-robin (a device whose slots are all occupied is skipped; BUSY when all are), results
+ * still come back in submission order, every other call of this section works on the object unchanged (`slot` values are opaque).
+ * An ordinal may repeat.  1 <= n_devices <= LLCOMP_MI_MAX_DEVICES.  A device that cannot be set up fails the call with
+ * LLCOMP_MI_DEVICE_FAILED (llcomp_mi_last_device_error). */
+int llcomp_mi_stream_create_multi(llcomp_mi_stream** stream, const int32_t* devices, uint32_t n_devices, uint32_t w, uint32_t h, uint32_t c,
+                                  uint32_t tile_w, uint32_t tile_h, uint32_t planar, uint32_t depth, uint32_t frames_per_job);
+uint32_t llcomp_mi_stream_devices(const llcomp_mi_stream* stream); /* pipelines behind the object (1 for a plain stream) */
 uint32_t llcomp_mi_stream_frames_per_job(const llcomp_mi_stream* stream);
 int llcomp_mi_stream_submit_decode_batch(llcomp_mi_stream* stream, const uint8_t* const* data, const size_t* lens, uint64_t tag);
 int llcomp_mi_stream_result_part(llcomp_mi_stream* stream, uint32_t slot, uint32_t frame, const uint8_t** data, uint64_t* len);

@@ -9,7 +9,7 @@
 //   llcomp::ext = ".llcomp"                                    :18      llcomp::ext
 //   std::vector<uint8_t> llcomp::compressImage(rgb,w,h,c)      :358     same signature (+ optional llcomp::Options)
 //   struct llcomp::RawImage{pixels,width,height,channels}      :454     same members (width/height widened to 32 bit)
-//   llcomp::RawImage llcomp::decompressImage(data)             :461     same signature
+//   llcomp::RawImage llcomp::decompressImage(data)             :461     same signature (+ overload with a device list)
 //   throw std::runtime_error("Invalid magic number")           :466     same text
 //   throw std::runtime_error("Invalid exponent")               :233     same text
 //
@@ -36,6 +36,11 @@ struct Options {
     bool planar = true;     // one slice per colour-transformed channel plane
     int device = -1;        // HIP device ordinal, -1 = current
     bool small_model = false;  // bitstream of a reference built with LargeModel = false (llcomp.hpp:21)
+    // One image over several GPUs inside this process (sliced only): the tile rows are dealt over these HIP ordinals, every GPU gets
+    // only its rows over its own PCIe link and copies its payload straight into the container -- byte-identical to one device's.
+    // Empty = `device`.  An ordinal may repeat (two lanes on one GPU).
+    std::vector<int> devices;
+    uint32_t chunks_per_device = 0;  // 0 = 4
 };
 
 struct RawImage {
@@ -49,6 +54,12 @@ namespace detail {
 [[noreturn]] inline void raise(int status) {
     const char* msg = llcomp_mi_strerror(status);
     if (status == LLCOMP_MI_BAD_ARGS || status == LLCOMP_MI_OUT_OF_RANGE) throw std::invalid_argument(msg);
+    if (status == LLCOMP_MI_DEVICE_FAILED) {  // which device of the list, and what it said
+        int32_t dev = -1;
+        int why = 0;
+        if (llcomp_mi_last_device_error(&dev, nullptr, &why))
+            throw std::runtime_error(std::string(msg) + " [device " + std::to_string(dev) + ": " + llcomp_mi_strerror(why) + "]");
+    }
     throw std::runtime_error(msg);
 }
 // this header and the library it is linked against must come from the same ABI version (llcomp_mi.h: one struct layout per version)
@@ -72,6 +83,10 @@ inline std::vector<uint8_t> compressImage(const std::vector<uint8_t>& rgb, int w
     o.planar = opt.planar ? 1u : 0u;
     o.device = opt.device;
     o.small_model = opt.small_model ? 1u : 0u;
+    std::vector<int32_t> devs(opt.devices.begin(), opt.devices.end());
+    o.n_devices = uint32_t(devs.size());
+    o.devices = devs.empty() ? nullptr : devs.data();
+    o.chunks_per_device = opt.chunks_per_device;
     uint8_t* out = nullptr;
     size_t n = 0;
     if (int rc = llcomp_mi_encode(rgb.data(), uint32_t(width), uint32_t(height), uint32_t(channels), &o, &out, &n))
@@ -86,6 +101,21 @@ inline RawImage decompressImage(const std::vector<uint8_t>& data, int device = -
     uint8_t* px = nullptr;
     uint32_t w = 0, h = 0, c = 0;
     if (int rc = llcomp_mi_decode_flags(data.data(), data.size(), device, legacy_small_model ? LLCOMP_MI_FLAG_SMALL_MODEL : 0u, &px, &w, &h, &c))
+        detail::raise(rc);
+    RawImage img{std::vector<uint8_t>(px, px + size_t(w) * h * c), w, h, uint8_t(c)};
+    llcomp_mi_free(px);
+    return img;
+}
+
+// ... decoded over a list of GPUs inside this process (llcomp_mi_decode_devices); how the stream was encoded does not matter
+inline RawImage decompressImage(const std::vector<uint8_t>& data, const std::vector<int>& devices, bool legacy_small_model = false) {
+    if (devices.empty()) return decompressImage(data, -1, legacy_small_model);
+    detail::check_abi();
+    std::vector<int32_t> devs(devices.begin(), devices.end());
+    uint8_t* px = nullptr;
+    uint32_t w = 0, h = 0, c = 0;
+    if (int rc = llcomp_mi_decode_devices(data.data(), data.size(), devs.data(), uint32_t(devs.size()), 0,
+                                          legacy_small_model ? LLCOMP_MI_FLAG_SMALL_MODEL : 0u, &px, &w, &h, &c))
         detail::raise(rc);
     RawImage img{std::vector<uint8_t>(px, px + size_t(w) * h * c), w, h, uint8_t(c)};
     llcomp_mi_free(px);

@@ -22,7 +22,7 @@ from ._lib import Info, Opts
 
 EXT = ".llcomp"
 FORMAT_LEGACY, FORMAT_SLICED = 0, 1
-(OK, BAD_MAGIC, BAD_EXPONENT, TRUNCATED, BAD_ARGS, OUT_OF_RANGE, OUTPUT_OVERFLOW, HIP_ERROR, NO_DEVICE, NOMEM, BUSY) = range(11)
+(OK, BAD_MAGIC, BAD_EXPONENT, TRUNCATED, BAD_ARGS, OUT_OF_RANGE, OUTPUT_OVERFLOW, HIP_ERROR, NO_DEVICE, NOMEM, BUSY, DEVICE_FAILED) = range(12)
 JOB_ENCODE, JOB_DECODE = 0, 1
 
 RawImage = namedtuple("RawImage", "pixels width height channels")
@@ -32,6 +32,8 @@ class LlcompError(RuntimeError):
     def __init__(self, status, detail=None):
         self.status = int(status)
         msg = _lib.load().llcomp_mi_strerror(int(status)).decode()
+        # a call over a device list: (HIP ordinal, position in the list, that device's own status)
+        self.device_error = last_device_error() if self.status == DEVICE_FAILED else None
         super().__init__(msg if not detail else f"{msg} ({detail})")
 
 
@@ -40,20 +42,51 @@ def _check(rc):
         raise LlcompError(rc)
 
 
+def last_device_error():
+    """(HIP ordinal, position in the device list, that device's own status) behind this thread's last DEVICE_FAILED, else None"""
+    dev, idx, st = C.c_int32(), C.c_uint32(), C.c_int()
+    if not _lib.load().llcomp_mi_last_device_error(C.byref(dev), C.byref(idx), C.byref(st)):
+        return None
+    return dev.value, idx.value, st.value
+
+
+def _opts(format, tile_w, tile_h, planar, device, small_model, devices=None, chunks_per_device=0):
+    """llcomp_mi_opts (+ the int32 array its `devices` points at: keep it alive for the call)"""
+    o = Opts(C.sizeof(Opts), format, tile_w, tile_h, int(bool(planar)), device, int(bool(small_model)), 0, None, int(chunks_per_device), 0)
+    arr = None
+    if devices is not None:
+        arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        o.n_devices, o.devices = len(devices), C.cast(arr, C.POINTER(C.c_int32))
+    return o, arr
+
+
+def plan_chunks(height, tile_h, n_parts, chunks_per_part=4):
+    """[(tile_row0, tile_row1, owner)] -- llcomp_mi_plan_chunks, the one work split of every multi-GPU path (device lists in the
+    library, ranks in llcomp_amd.sharding)"""
+    L = _lib.load()
+    n = C.c_uint32()
+    _check(L.llcomp_mi_plan_chunks(height, max(0, tile_h), n_parts, max(1, chunks_per_part), None, 0, C.byref(n)))
+    tri = (C.c_uint32 * (3 * n.value))()
+    _check(L.llcomp_mi_plan_chunks(height, max(0, tile_h), n_parts, max(1, chunks_per_part), tri, n.value, C.byref(n)))
+    return [(tri[3 * i], tri[3 * i + 1], tri[3 * i + 2]) for i in range(n.value)]
+
+
 def device_count():
     return _lib.load().llcomp_mi_device_count()
 
 
-def compress_image(rgb, width, height, channels, *, format=FORMAT_LEGACY, tile_w=0, tile_h=0, planar=False, device=-1, small_model=False):
+def compress_image(rgb, width, height, channels, *, format=FORMAT_LEGACY, tile_w=0, tile_h=0, planar=False, device=-1, small_model=False,
+                   devices=None, chunks_per_device=0):
     """bytes of an llcomp stream.  Default = the reference's own whole-image format (magic 0x79), byte-identical to
     llcomp::compressImage; format=FORMAT_SLICED produces the parallel container (magic 0x9C).  small_model=True codes like
     a reference built with LargeModel = false (llcomp.hpp:21); a legacy stream does not record that, so it must be passed
-    to decompress_image as well."""
+    to decompress_image as well.  devices=[ordinals]: the image's tile rows are dealt over these GPUs inside this process
+    (llcomp_mi_opts.devices; the container is byte-identical to the one-device container)."""
     L = _lib.load()
     buf = np.ascontiguousarray(np.frombuffer(rgb, dtype=np.uint8) if isinstance(rgb, (bytes, bytearray, memoryview)) else rgb, dtype=np.uint8).reshape(-1)
     if buf.size != width * height * channels:  # the reference only asserts this (llcomp.hpp:361)
         raise LlcompError(BAD_ARGS)
-    o = Opts(C.sizeof(Opts), format, tile_w, tile_h, int(bool(planar)), device, int(bool(small_model)))
+    o, _keep = _opts(format, tile_w, tile_h, planar, device, small_model, devices, chunks_per_device)
     out, n = _lib.u8p(), C.c_size_t()
     _check(L.llcomp_mi_encode(buf.ctypes.data_as(_lib.u8p), width, height, channels, C.byref(o), C.byref(out), C.byref(n)))
     try:
@@ -62,13 +95,19 @@ def compress_image(rgb, width, height, channels, *, format=FORMAT_LEGACY, tile_w
         L.llcomp_mi_free(out)
 
 
-def decompress_image(data, *, device=-1, small_model=False):
-    """RawImage(pixels: np.uint8[h,w,c], width, height, channels) from either wire format."""
+def decompress_image(data, *, device=-1, small_model=False, devices=None, chunks_per_device=0):
+    """RawImage(pixels: np.uint8[h,w,c], width, height, channels) from either wire format.  devices=[ordinals]: decoded over
+    these GPUs inside this process (llcomp_mi_decode_devices)."""
     L = _lib.load()
     data = bytes(data)  # no copy when it already is bytes
     src = C.cast(C.c_char_p(data or b"\0"), _lib.u8p)  # borrows the bytes object's buffer for the call
     px, w, h, c = _lib.u8p(), C.c_uint32(), C.c_uint32(), C.c_uint32()
-    _check(L.llcomp_mi_decode_flags(src, len(data), device, 1 if small_model else 0, C.byref(px), C.byref(w), C.byref(h), C.byref(c)))
+    if devices is not None:
+        arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        _check(L.llcomp_mi_decode_devices(src, len(data), arr, len(devices), int(chunks_per_device), 1 if small_model else 0, C.byref(px), C.byref(w),
+                                          C.byref(h), C.byref(c)))
+    else:
+        _check(L.llcomp_mi_decode_flags(src, len(data), device, 1 if small_model else 0, C.byref(px), C.byref(w), C.byref(h), C.byref(c)))
     try:
         n = w.value * h.value * c.value
         pixels = np.ctypeslib.as_array(px, shape=(max(n, 1),))[:n].copy().reshape(h.value, w.value, c.value)
@@ -118,11 +157,12 @@ class PinnedBuffer:
     __del__ = close
 
 
-def compress_image_into(rgb, width, height, channels, out, *, format=FORMAT_LEGACY, tile_w=0, tile_h=0, planar=False, device=-1, small_model=False):
+def compress_image_into(rgb, width, height, channels, out, *, format=FORMAT_LEGACY, tile_w=0, tile_h=0, planar=False, device=-1, small_model=False,
+                        devices=None, chunks_per_device=0):
     """llcomp_mi_encode_into: `rgb` and `out` are numpy uint8 arrays owned by the caller (pinned: PinnedBuffer.array);
     returns the container length.  Raises LlcompError(OUTPUT_OVERFLOW) with .needed set when `out` is too small."""
     L = _lib.load()
-    o = Opts(C.sizeof(Opts), format, tile_w, tile_h, int(bool(planar)), device, int(bool(small_model)))
+    o, _keep = _opts(format, tile_w, tile_h, planar, device, small_model, devices, chunks_per_device)
     n = C.c_size_t()
     rc = L.llcomp_mi_encode_into(rgb.ctypes.data, width, height, channels, C.byref(o), out.ctypes.data, out.size, C.byref(n))
     if rc != OK:
@@ -132,11 +172,16 @@ def compress_image_into(rgb, width, height, channels, out, *, format=FORMAT_LEGA
     return n.value
 
 
-def decompress_image_into(data, out, *, device=-1, small_model=False):
-    """llcomp_mi_decode_into_flags: `data` / `out` numpy uint8 arrays owned by the caller -> (width, height, channels)."""
+def decompress_image_into(data, out, *, device=-1, small_model=False, devices=None, chunks_per_device=0):
+    """llcomp_mi_decode_into_flags / _into_devices: `data` / `out` numpy uint8 arrays owned by the caller -> (width, height, channels)."""
     L = _lib.load()
     w, h, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
-    rc = L.llcomp_mi_decode_into_flags(data.ctypes.data, data.size, device, 1 if small_model else 0, out.ctypes.data, out.size, C.byref(w), C.byref(h), C.byref(c))
+    if devices is not None:
+        arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        rc = L.llcomp_mi_decode_into_devices(data.ctypes.data, data.size, arr, len(devices), int(chunks_per_device), 1 if small_model else 0,
+                                             out.ctypes.data, out.size, C.byref(w), C.byref(h), C.byref(c))
+    else:
+        rc = L.llcomp_mi_decode_into_flags(data.ctypes.data, data.size, device, 1 if small_model else 0, out.ctypes.data, out.size, C.byref(w), C.byref(h), C.byref(c))
     if rc != OK:
         e = LlcompError(rc)
         e.shape = (w.value, h.value, c.value)
@@ -154,10 +199,15 @@ class Stream:
     output buffer: frames_per_job == 1: the container (encode) / the frame [h,w,c] (decode); more frames per job: a list of
     containers (encode) / the frames [F,h,w,c] (decode)."""
 
-    def __init__(self, w, h, c, tile_w=0, tile_h=0, planar=True, depth=4, device=-1, frames_per_job=1):
+    def __init__(self, w, h, c, tile_w=0, tile_h=0, planar=True, depth=4, device=-1, frames_per_job=1, devices=None):
         self._L = _lib.load()
         self._h = C.c_void_p()
-        _check(self._L.llcomp_mi_stream_create_ex(C.byref(self._h), device, w, h, c, tile_w, tile_h, int(bool(planar)), depth, frames_per_job))
+        if devices is not None:  # one pipeline of `depth` slots per device behind one object, jobs dealt round-robin
+            arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            _check(self._L.llcomp_mi_stream_create_multi(C.byref(self._h), arr, len(devices), w, h, c, tile_w, tile_h, int(bool(planar)), depth, frames_per_job))
+        else:
+            _check(self._L.llcomp_mi_stream_create_ex(C.byref(self._h), device, w, h, c, tile_w, tile_h, int(bool(planar)), depth, frames_per_job))
+        self.n_devices = self._L.llcomp_mi_stream_devices(self._h)
         self.shape = (h, w, c)
         self.frames_per_job = frames_per_job
         self.container_capacity = self._L.llcomp_mi_stream_container_capacity(self._h)

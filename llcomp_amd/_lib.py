@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # in-kernel clock stamps, csrc/Makefile `probe`); the tests, bench.py and smoke() never set it
 LIB_PATH = os.environ.get("LLCOMP_MI_LIB") or os.path.join(_HERE, "libllcomp_mi.so")
 
-ABI_VERSION = 3  # LLCOMP_MI_ABI_VERSION of the header this binding mirrors
+ABI_VERSION = 4  # LLCOMP_MI_ABI_VERSION of the header this binding mirrors
 
 # every symbol include/llcomp_mi.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = [
@@ -27,6 +27,8 @@ SYMBOLS = [
     "llcomp_mi_stream_submit_encode", "llcomp_mi_stream_submit_decode", "llcomp_mi_stream_pending",
     "llcomp_mi_stream_poll", "llcomp_mi_stream_wait", "llcomp_mi_stream_release",
     "llcomp_mi_set_pool_limit", "llcomp_mi_pool_limit", "llcomp_mi_pool_idle_bytes", "llcomp_mi_fnv1a64", "llcomp_mi_suggest_tile_w", "llcomp_mi_decode_into_flags", "llcomp_mi_device_range_sums",
+    "llcomp_mi_decode_devices", "llcomp_mi_decode_into_devices", "llcomp_mi_last_device_error", "llcomp_mi_plan_chunks",
+    "llcomp_mi_stream_create_multi", "llcomp_mi_stream_devices",
 ]
 
 u8p = C.POINTER(C.c_uint8)
@@ -34,7 +36,8 @@ u8p = C.POINTER(C.c_uint8)
 
 class Opts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("format", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32),
-                ("planar", C.c_uint32), ("device", C.c_int32), ("small_model", C.c_uint32)]
+                ("planar", C.c_uint32), ("device", C.c_int32), ("small_model", C.c_uint32),
+                ("n_devices", C.c_uint32), ("devices", C.POINTER(C.c_int32)), ("chunks_per_device", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Info(C.Structure):
@@ -107,8 +110,9 @@ def load():
     L.llcomp_mi_codec_destroy.argtypes = [C.c_void_p]
     L.llcomp_mi_codec_slices.restype = C.c_uint32
     L.llcomp_mi_codec_slices.argtypes = [C.c_void_p]
-    L.llcomp_mi_codec_kernel_family.restype = C.c_uint32
-    L.llcomp_mi_codec_kernel_family.argtypes = [C.c_void_p]
+    if hasattr(L, "llcomp_mi_codec_kernel_family"):  # (a stale library must reach the ABI check below, not an AttributeError)
+        L.llcomp_mi_codec_kernel_family.restype = C.c_uint32
+        L.llcomp_mi_codec_kernel_family.argtypes = [C.c_void_p]
     L.llcomp_mi_codec_workspace_bytes.restype = C.c_uint64
     L.llcomp_mi_codec_workspace_bytes.argtypes = [C.c_void_p]
     L.llcomp_mi_codec_max_payload_bytes.restype = C.c_uint64
@@ -188,6 +192,21 @@ def load():
     L.llcomp_mi_stream_wait.argtypes = [C.c_void_p, C.POINTER(StreamResult)]
     L.llcomp_mi_stream_release.restype = C.c_int
     L.llcomp_mi_stream_release.argtypes = [C.c_void_p, C.c_uint32]
+    old_ab_build = "LLCOMP_MI_LIB" in os.environ and L.llcomp_mi_abi_version() != ABI_VERSION  # (tools/lib_ab.sh against earlier commits)
+    if not old_ab_build:
+        i32p = C.POINTER(C.c_int32)
+        L.llcomp_mi_decode_devices.restype = C.c_int
+        L.llcomp_mi_decode_devices.argtypes = [u8p, C.c_size_t, i32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(u8p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.llcomp_mi_decode_into_devices.restype = C.c_int
+        L.llcomp_mi_decode_into_devices.argtypes = [C.c_void_p, C.c_size_t, i32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.llcomp_mi_last_device_error.restype = C.c_int
+        L.llcomp_mi_last_device_error.argtypes = [i32p, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        L.llcomp_mi_plan_chunks.restype = C.c_int
+        L.llcomp_mi_plan_chunks.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]
+        L.llcomp_mi_stream_create_multi.restype = C.c_int
+        L.llcomp_mi_stream_create_multi.argtypes = [C.POINTER(C.c_void_p), i32p, C.c_uint32] + [C.c_uint32] * 8
+        L.llcomp_mi_stream_devices.restype = C.c_uint32
+        L.llcomp_mi_stream_devices.argtypes = [C.c_void_p]
     if "LLCOMP_MI_LIB" not in os.environ and L.llcomp_mi_abi_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH} has ABI version {L.llcomp_mi_abi_version()}, this binding was written for {ABI_VERSION}: rebuild the library")
     _lib = L

@@ -98,6 +98,7 @@ int next_state_generation(llcomp_mi_codec* k, hipStream_t s) {
             k->d_states = nullptr;
             return LLCOMP_MI_NOMEM;
         }
+        k->allocated_bytes += (uint64_t(lane_groups(g)) * kContexts << g.lane_shift) * 8;
         k->state_generation = 0;
     }
     if (k->state_generation == 0 || k->state_generation >= 255) {
@@ -121,6 +122,7 @@ int ensure_snapshot_arrays(llcomp_mi_codec* k) {
         k->d_snap_sorted = k->d_snap_banks = k->d_snap_res = nullptr;
         return LLCOMP_MI_NOMEM;
     }
+    k->allocated_bytes += el * 18;
     return LLCOMP_MI_OK;
 }
 
@@ -196,6 +198,7 @@ const char* llcomp_mi_strerror(int status) {
         case LLCOMP_MI_NO_DEVICE: return "no HIP device (this library has no CPU path)";
         case LLCOMP_MI_NOMEM: return "out of memory";
         case LLCOMP_MI_BUSY: return "all pipeline slots are in flight (take a finished job first)";
+        case LLCOMP_MI_DEVICE_FAILED: return "a device of the device list failed (llcomp_mi_last_device_error tells which); nothing was published";
         default: return "unknown status";
     }
 }
@@ -249,6 +252,7 @@ int llcomp_mi_codec_create_ex(llcomp_mi_codec** out, int32_t device, uint32_t fr
         llcomp_mi_codec_destroy(k);
         return LLCOMP_MI_NOMEM;
     }
+    k->allocated_bytes = b_sym + b_lanes + b_scratch + b_off + 8;
     *out = k;
     return LLCOMP_MI_OK;
 }

@@ -32,7 +32,8 @@ struct llcomp_mi_codec {
     void* d_snap_sorted = nullptr;   // snapshot pass of the 2-D encoder (snapshot.hpp): banks in context-sorted order,
     void* d_snap_banks = nullptr;    // banks in stream order, residuals in stream order; null unless snapshot_mode(g)
     void* d_snap_res = nullptr;
-    uint64_t workspace_bytes = 0;
+    uint64_t workspace_bytes = 0;    // what the codec can hold at most
+    uint64_t allocated_bytes = 0;    // what it holds right now (state tables / snapshot arrays come with the first call that needs them)
     bool need_states = true;  // false when the states live in LDS (1-row slices; one slice per wavefront)
     uint32_t state_generation = 0;  // tag of the last call that used d_states (kernels.hpp); 0 = the table has not been cleared yet
     // optional per-kernel timing (hipEvents on the caller's stream)
@@ -106,6 +107,27 @@ void lane_destroy(HostLane* l);
 int lane_enqueue_encode(HostLane* l);
 // container in d_container (header + tables + `payload_bytes` of payload) -> frame(s) in d_px, status -> h_meta
 int lane_enqueue_decode(HostLane* l, uint64_t payload_bytes);
+
+// hostapi.hip: a lane for this shape on `device` (-1 = current) from the cache of idle lanes, or a new one; lane_release parks it again
+int lane_acquire(HostLane** out, int32_t device, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar,
+                 bool legacy, uint64_t min_cap, bool small_model);
+void lane_release(HostLane* l);
+
+// multidev.hip: one image over a device list, in this process (llcomp_mi_opts.devices / llcomp_mi_decode_devices)
+struct DeviceList {
+    const int32_t* devices;
+    uint32_t n;
+    uint32_t chunks_per_device;  // 0 = 4
+};
+// `out` != nullptr: caller's buffer of out_cap bytes; else the container is malloc'ed and returned through *out_alloc
+int encode_multi(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar, bool small_model,
+                 const DeviceList& dl, uint8_t* out, size_t out_cap, uint8_t** out_alloc, size_t* out_len);
+// *handled = false (and nothing done) when the container has to go through the one-device path (its table does not fit its payload)
+int decode_multi(const uint8_t* data, size_t len, const llcomp_mi_info& info, const DeviceList& dl, uint8_t* px, size_t px_cap,
+                 uint8_t** px_alloc, uint32_t* w, uint32_t* h, uint32_t* c, bool* handled);
+// the thread's record behind LLCOMP_MI_DEVICE_FAILED (llcomp_mi_last_device_error)
+void clear_device_error();
+int device_failed(int32_t device, uint32_t index, int status);  // records it and returns LLCOMP_MI_DEVICE_FAILED
 
 void codec_release(llcomp_mi_codec* k);  // codec.hip: destroy without the device-wide wait (its work is known to be done)
 

@@ -60,6 +60,32 @@ uint32_t llcomp_mi_suggest_tile_w(uint32_t frames, uint32_t w, uint32_t h, uint3
     return uint32_t(tw);
 }
 
+// The work split of the multi-GPU paths (multidev.hip: device lists; llcomp_amd/sharding.py: ranks, through ctypes).  A chunk is a
+// run of whole tile rows: slices have fresh state and slice-local borders, so a band of whole tile rows coded as an image of its own
+// yields exactly the full image's slices.  Chunk i belongs to part i % n_parts (fine interleaving: the cost of a slice follows its
+// entropy, not its pixels).
+int llcomp_mi_plan_chunks(uint32_t height, uint32_t tile_h, uint32_t n_parts, uint32_t chunks_per_part, uint32_t* triples,
+                          uint32_t cap_chunks, uint32_t* n_chunks) {
+    if (!height || !n_parts || !n_chunks) return LLCOMP_MI_BAD_ARGS;
+    if (tile_h == 0 || tile_h > height) tile_h = height;
+    if (chunks_per_part == 0) chunks_per_part = 4;
+    const uint64_t nty = (uint64_t(height) + tile_h - 1) / tile_h;
+    const uint64_t want = uint64_t(n_parts) * chunks_per_part;
+    const uint64_t n = nty < want ? nty : want;  // >= 1
+    *n_chunks = uint32_t(n);
+    if (!triples) return LLCOMP_MI_OK;
+    if (n > cap_chunks) return LLCOMP_MI_OUTPUT_OVERFLOW;
+    uint64_t t = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t cnt = nty / n + (i < nty % n ? 1 : 0);
+        triples[3 * i + 0] = uint32_t(t);
+        triples[3 * i + 1] = uint32_t(t + cnt);
+        triples[3 * i + 2] = uint32_t(i % n_parts);
+        t += cnt;
+    }
+    return LLCOMP_MI_OK;
+}
+
 uint32_t llcomp_mi_slice_count(uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar) {
     Geometry g;
     if (!make_geometry(g, 1, w, h, c, tile_w, tile_h, planar)) return 0;

@@ -147,10 +147,15 @@ struct LaneCache {
         {
             std::lock_guard<std::mutex> lock(mu);
             idle.push_back({l, ++clock});
-            auto bytes = [&]() { uint64_t b = 0; for (auto& it : idle) b += it.l->k->workspace_bytes + it.l->bytes; return b; };
-            while (idle.size() > kMaxIdle || (idle.size() > 1 && bytes() > kMaxIdleBytes)) {
-                size_t oldest = 0;
-                for (size_t i = 1; i < idle.size(); ++i) if (idle[i].stamp < idle[oldest].stamp) oldest = i;
+            // the limits hold PER DEVICE (a device list parks one lane on every GPU); bytes = what the lane holds right now (the
+            // codec's state tables / snapshot arrays only once a call has allocated them)
+            const int dev = l->k->device;
+            auto count = [&]() { size_t n = 0; for (auto& it : idle) n += it.l->k->device == dev; return n; };
+            auto bytes = [&]() { uint64_t b = 0; for (auto& it : idle) if (it.l->k->device == dev) b += it.l->k->allocated_bytes + it.l->bytes; return b; };
+            while (count() > kMaxIdle || (count() > 1 && bytes() > kMaxIdleBytes)) {
+                size_t oldest = idle.size();
+                for (size_t i = 0; i < idle.size(); ++i)
+                    if (idle[i].l->k->device == dev && (oldest == idle.size() || idle[i].stamp < idle[oldest].stamp)) oldest = i;
                 drop.push_back(idle[oldest].l);
                 idle.erase(idle.begin() + long(oldest));
             }
@@ -172,16 +177,32 @@ LaneCache& lane_cache() {
     return *c;
 }
 
-int acquire_lane(HostLane** out, int32_t device, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar,
+}  // namespace
+
+namespace llcomp_mi {
+int lane_acquire(HostLane** out, int32_t device, uint32_t w, uint32_t h, uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar,
                  bool legacy, uint64_t min_cap, bool small_model) {
     Geometry g;
     std::memset(&g, 0, sizeof(g));
     if (!make_geometry(g, 1, w, h, c, tile_w, tile_h, planar, current_tuning(), small_model)) return LLCOMP_MI_OUT_OF_RANGE;
     int dev = 0;
     if (int rc = resolve_device(device, &dev)) return rc;
-    if ((*out = lane_cache().take(dev, g, legacy))) return lane_grow(*out, min_cap);
+    if ((*out = lane_cache().take(dev, g, legacy))) {
+        if (int rc = lane_grow(*out, min_cap)) {  // (a lane whose container buffer could not be reallocated is of no use to anybody)
+            lane_destroy(*out);
+            *out = nullptr;
+            return rc;
+        }
+        return LLCOMP_MI_OK;
+    }
     return lane_create(out, dev, w, h, c, tile_w, tile_h, planar, legacy, min_cap, small_model);
 }
+void lane_release(HostLane* l) {
+    if (l) lane_cache().give(l);
+}
+}  // namespace llcomp_mi
+
+namespace {
 
 // Copies between a CALLER's buffer and HBM, stream-ordered on the lane's private stream and complete on return (staged by
 // the runtime for pageable memory, plain DMA for pinned memory).  Measured on a 4K noise frame, buffers reused across
@@ -193,7 +214,7 @@ inline hipError_t copy_user(void* dst, const void* src, size_t n, hipMemcpyKind 
 
 struct LaneLease {  // returns the lane to the cache on every exit path
     HostLane* l = nullptr;
-    ~LaneLease() { if (l) lane_cache().give(l); }
+    ~LaneLease() { lane_release(l); }
 };
 
 // encode into `out` (capacity out_cap) when out != nullptr, else into a malloc'ed buffer returned through *out_alloc
@@ -207,7 +228,8 @@ int encode_common(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, const l
     if (opts) {  // one layout per ABI version: a caller built against another header is refused, not half-read
         if (opts->struct_size != sizeof(llcomp_mi_opts)) return LLCOMP_MI_BAD_ARGS;
         std::memcpy(&o, opts, sizeof(o));
-        if (o.small_model > 1) return LLCOMP_MI_BAD_ARGS;
+        if (o.small_model > 1 || o.reserved) return LLCOMP_MI_BAD_ARGS;
+        if (o.n_devices && (!o.devices || o.n_devices > LLCOMP_MI_MAX_DEVICES)) return LLCOMP_MI_BAD_ARGS;
     }
     if (o.format != LLCOMP_MI_FORMAT_LEGACY && o.format != LLCOMP_MI_FORMAT_SLICED) return LLCOMP_MI_BAD_ARGS;
     const bool legacy = o.format == LLCOMP_MI_FORMAT_LEGACY;
@@ -216,11 +238,21 @@ int encode_common(const uint8_t* px, uint32_t w, uint32_t h, uint32_t c, const l
     const uint32_t tile_h = legacy ? h : (o.tile_h == 0 || o.tile_h > h ? h : o.tile_h);
     const uint32_t planar = legacy ? 0 : (o.planar ? 1 : 0);
     const uint64_t raw = uint64_t(w) * h * c;
+    clear_device_error();
+    if (o.n_devices) {
+        // a device list: the tile rows are dealt over the devices (multidev.hip).  One serial stream does not shard, and a list of
+        // one device is the plain call on that device.
+        if (!legacy && o.n_devices > 1)
+            return encode_multi(px, w, h, c, tile_w, tile_h, planar, o.small_model != 0, DeviceList{o.devices, o.n_devices, o.chunks_per_device}, out,
+                                out_cap, out_alloc, out_len);
+        o.device = o.devices[0];
+        if (o.device < 0) return LLCOMP_MI_BAD_ARGS;
+    }
 
     LaneLease lease;
     // first try with room for 2x raw (incompressible noise needs ~1.25x), then the proven worst case
     const uint64_t first_cap = 2 * raw + 64ull * llcomp_mi_slice_count(w, h, c, tile_w, tile_h, planar) + 4096;
-    if (int rc = acquire_lane(&lease.l, o.device, w, h, c, tile_w, tile_h, planar, legacy, 0, o.small_model != 0)) return rc;
+    if (int rc = lane_acquire(&lease.l, o.device, w, h, c, tile_w, tile_h, planar, legacy, 0, o.small_model != 0)) return rc;
     HostLane* l = lease.l;
     const uint64_t max_payload = llcomp_mi_codec_max_payload_bytes(l->k);
     if (int rc = lane_grow(l, std::min(first_cap, max_payload))) return rc;
@@ -270,7 +302,7 @@ int decode_common(const uint8_t* data, size_t len, int32_t device, uint32_t flag
     *c = info.channels;
     if (px && raw > px_cap) return LLCOMP_MI_OUTPUT_OVERFLOW;  // dimensions are reported: the caller can size its buffer
     LaneLease lease;
-    if (int rc = acquire_lane(&lease.l, device, info.width, info.height, info.channels, info.tile_w, info.tile_h, info.planar, legacy,
+    if (int rc = lane_acquire(&lease.l, device, info.width, info.height, info.channels, info.tile_w, info.tile_h, info.planar, legacy,
                               len - info.payload_offset + 16, legacy ? (flags & LLCOMP_MI_FLAG_SMALL_MODEL) != 0 : info.small_model != 0))
         return rc;
     HostLane* l = lease.l;
@@ -292,6 +324,24 @@ int decode_common(const uint8_t* data, size_t len, int32_t device, uint32_t flag
     }
     if (px_alloc) *px_alloc = dst;
     return LLCOMP_MI_OK;
+}
+
+// decode over a device list: sliced containers whose table fits their payload are dealt over the devices (multidev.hip); a legacy
+// stream, a list of one device and damaged containers (the one-device path forms their verdict) go to devices[0]
+int decode_devices_common(const uint8_t* data, size_t len, const DeviceList& dl, uint32_t flags, uint8_t* px, size_t px_cap, uint8_t** px_alloc,
+                          uint32_t* w, uint32_t* h, uint32_t* c) {
+    if (flags & ~LLCOMP_MI_FLAG_SMALL_MODEL) return LLCOMP_MI_BAD_ARGS;
+    clear_device_error();
+    for (uint32_t i = 0; i < dl.n; ++i)
+        if (dl.devices[i] < 0) return LLCOMP_MI_BAD_ARGS;
+    llcomp_mi_info info;
+    if (int rc = llcomp_mi_probe(data, len, &info)) return rc;
+    if (info.format == LLCOMP_MI_FORMAT_SLICED && dl.n > 1) {
+        bool handled = false;
+        const int rc = decode_multi(data, len, info, dl, px, px_cap, px_alloc, w, h, c, &handled);
+        if (handled) return rc;
+    }
+    return decode_common(data, len, dl.devices[0], flags, px, px_cap, px_alloc, w, h, c);
 }
 
 }  // namespace
@@ -334,6 +384,19 @@ int llcomp_mi_decode_into_flags(const uint8_t* data, size_t len, int32_t device,
                                 uint32_t* h, uint32_t* c) {
     if (!data || !px || !w || !h || !c || (flags & ~LLCOMP_MI_FLAG_SMALL_MODEL)) return LLCOMP_MI_BAD_ARGS;
     return decode_common(data, len, device, flags, px, px_cap, nullptr, w, h, c);
+}
+
+int llcomp_mi_decode_devices(const uint8_t* data, size_t len, const int32_t* devices, uint32_t n_devices, uint32_t chunks_per_device,
+                             uint32_t flags, uint8_t** px, uint32_t* w, uint32_t* h, uint32_t* c) {
+    if (!data || !px || !w || !h || !c || !devices || !n_devices || n_devices > LLCOMP_MI_MAX_DEVICES) return LLCOMP_MI_BAD_ARGS;
+    *px = nullptr;
+    return decode_devices_common(data, len, DeviceList{devices, n_devices, chunks_per_device}, flags, nullptr, 0, px, w, h, c);
+}
+
+int llcomp_mi_decode_into_devices(const uint8_t* data, size_t len, const int32_t* devices, uint32_t n_devices, uint32_t chunks_per_device,
+                                  uint32_t flags, uint8_t* px, size_t px_cap, uint32_t* w, uint32_t* h, uint32_t* c) {
+    if (!data || !px || !w || !h || !c || !devices || !n_devices || n_devices > LLCOMP_MI_MAX_DEVICES) return LLCOMP_MI_BAD_ARGS;
+    return decode_devices_common(data, len, DeviceList{devices, n_devices, chunks_per_device}, flags, px, px_cap, nullptr, w, h, c);
 }
 
 void llcomp_mi_trim(void) {

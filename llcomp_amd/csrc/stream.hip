@@ -60,6 +60,12 @@ struct llcomp_mi_stream {
     std::vector<Slot> slots;
     std::deque<uint32_t> fifo;  // slots in submission order that have not been handed out by wait() yet
     uint64_t jobs_done = 0;
+    // llcomp_mi_stream_create_multi: the object is a dealer in front of one plain pipeline per device -- `subs` non-empty, nothing of
+    // the fields above in use except `mu`; `order` = which pipeline every pending job went to, in submission order; a result's slot
+    // = pipeline index << 8 | that pipeline's slot
+    std::vector<llcomp_mi_stream*> subs;
+    std::deque<uint32_t> order;
+    uint32_t next = 0;
 };
 
 namespace {
@@ -131,6 +137,23 @@ int drained(HostLane* l, int rc) {
     return rc;
 }
 
+// multi-device object: the job goes to the next pipeline in turn that takes it (one whose slots are all occupied is skipped)
+template <typename Submit>
+int deal(llcomp_mi_stream* s, Submit submit) {
+    std::lock_guard<std::mutex> lock(s->mu);
+    const uint32_t n = uint32_t(s->subs.size());
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t i = (s->next + k) % n;
+        const int rc = submit(s->subs[i]);
+        if (rc == LLCOMP_MI_BUSY) continue;
+        if (rc) return rc;
+        s->order.push_back(i);
+        s->next = (i + 1) % n;
+        return LLCOMP_MI_OK;
+    }
+    return LLCOMP_MI_BUSY;
+}
+
 int free_slot(llcomp_mi_stream* s) {
     for (size_t i = 0; i < s->slots.size(); ++i)
         if (s->slots[i].state == kFree) return int(i);
@@ -191,8 +214,40 @@ int llcomp_mi_stream_create_ex(llcomp_mi_stream** out, int32_t device, uint32_t 
     return LLCOMP_MI_OK;
 }
 
+int llcomp_mi_stream_create_multi(llcomp_mi_stream** out, const int32_t* devices, uint32_t n_devices, uint32_t w, uint32_t h, uint32_t c,
+                                  uint32_t tile_w, uint32_t tile_h, uint32_t planar, uint32_t depth, uint32_t frames_per_job) {
+    if (!out) return LLCOMP_MI_BAD_ARGS;
+    *out = nullptr;
+    if (!devices || n_devices < 1 || n_devices > LLCOMP_MI_MAX_DEVICES) return LLCOMP_MI_BAD_ARGS;
+    clear_device_error();
+    for (uint32_t i = 0; i < n_devices; ++i)
+        if (devices[i] < 0) return LLCOMP_MI_BAD_ARGS;  // a list names its devices
+    if (depth < 1 || depth > 16 || frames_per_job < 1 || frames_per_job > 64) return LLCOMP_MI_BAD_ARGS;
+    if (int rc = check_shape(w, h, c, false)) return rc;
+    llcomp_mi_stream* s = new (std::nothrow) llcomp_mi_stream;
+    if (!s) return LLCOMP_MI_NOMEM;
+    for (uint32_t i = 0; i < n_devices; ++i) {
+        llcomp_mi_stream* sub = nullptr;
+        if (int rc = llcomp_mi_stream_create_ex(&sub, devices[i], w, h, c, tile_w, tile_h, planar, depth, frames_per_job)) {
+            llcomp_mi_stream_destroy(s);
+            return device_failed(devices[i], i, rc);
+        }
+        s->subs.push_back(sub);
+    }
+    s->fpj = frames_per_job;
+    *out = s;
+    return LLCOMP_MI_OK;
+}
+
+uint32_t llcomp_mi_stream_devices(const llcomp_mi_stream* s) { return !s ? 0 : s->subs.empty() ? 1 : uint32_t(s->subs.size()); }
+
 void llcomp_mi_stream_destroy(llcomp_mi_stream* s) {
     if (!s) return;
+    if (!s->subs.empty()) {
+        for (auto* sub : s->subs) llcomp_mi_stream_destroy(sub);
+        delete s;
+        return;
+    }
     DeviceGuard guard(s->device);
     for (Slot& sl : s->slots) {
         if (sl.lane && sl.lane->stream) (void)hipStreamSynchronize(sl.lane->stream);
@@ -204,10 +259,13 @@ void llcomp_mi_stream_destroy(llcomp_mi_stream* s) {
     delete s;
 }
 
-uint64_t llcomp_mi_stream_container_capacity(const llcomp_mi_stream* s) { return s ? s->out_cap : 0; }
+uint64_t llcomp_mi_stream_container_capacity(const llcomp_mi_stream* s) {
+    return !s ? 0 : s->subs.empty() ? s->out_cap : s->subs[0]->out_cap;
+}
 
 int llcomp_mi_stream_submit_encode(llcomp_mi_stream* s, const uint8_t* px, uint64_t tag) {
     if (!s || !px) return LLCOMP_MI_BAD_ARGS;
+    if (!s->subs.empty()) return deal(s, [&](llcomp_mi_stream* sub) { return llcomp_mi_stream_submit_encode(sub, px, tag); });
     std::lock_guard<std::mutex> lock(s->mu);
     DeviceGuard guard(s->device);
     if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
@@ -235,6 +293,7 @@ int llcomp_mi_stream_submit_decode(llcomp_mi_stream* s, const uint8_t* data, siz
 
 int llcomp_mi_stream_submit_decode_batch(llcomp_mi_stream* s, const uint8_t* const* data, const size_t* lens, uint64_t tag) {
     if (!s || !data || !lens) return LLCOMP_MI_BAD_ARGS;
+    if (!s->subs.empty()) return deal(s, [&](llcomp_mi_stream* sub) { return llcomp_mi_stream_submit_decode_batch(sub, data, lens, tag); });
     const uint64_t head1 = uint64_t(LLCOMP_MI_SLICED_HEADER_BYTES) + 4ull * s->spf;
     std::vector<uint64_t> pay(s->fpj);  // payload bytes every frame's slice table promises
     for (uint32_t f = 0; f < s->fpj; ++f) {
@@ -297,6 +356,7 @@ uint32_t llcomp_mi_stream_frames_per_job(const llcomp_mi_stream* s) { return s ?
 
 int llcomp_mi_stream_result_part(llcomp_mi_stream* s, uint32_t slot, uint32_t frame, const uint8_t** data, uint64_t* len) {
     if (!s || !data || !len) return LLCOMP_MI_BAD_ARGS;
+    if (!s->subs.empty()) return (slot >> 8) < s->subs.size() ? llcomp_mi_stream_result_part(s->subs[slot >> 8], slot & 0xFF, frame, data, len) : LLCOMP_MI_BAD_ARGS;
     std::lock_guard<std::mutex> lock(s->mu);
     if (slot >= s->slots.size() || frame >= s->fpj) return LLCOMP_MI_BAD_ARGS;
     const Slot& sl = s->slots[slot];
@@ -314,11 +374,27 @@ int llcomp_mi_stream_result_part(llcomp_mi_stream* s, uint32_t slot, uint32_t fr
 int llcomp_mi_stream_pending(llcomp_mi_stream* s) {
     if (!s) return 0;
     std::lock_guard<std::mutex> lock(s->mu);
-    return int(s->fifo.size());
+    return s->subs.empty() ? int(s->fifo.size()) : int(s->order.size());
 }
 
 int llcomp_mi_stream_poll(llcomp_mi_stream* s) {
     if (!s) return LLCOMP_MI_BAD_ARGS;
+    if (!s->subs.empty()) {
+        // every pipeline gets to look at its events (the container copies of younger jobs on OTHER devices are queued by whoever
+        // enters the library next: here); the answer is the oldest job's
+        llcomp_mi_stream* oldest = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(s->mu);
+            if (s->order.empty()) return LLCOMP_MI_OK;
+            oldest = s->subs[s->order.front()];
+        }
+        int rc = LLCOMP_MI_OK;
+        for (auto* sub : s->subs) {
+            const int r = llcomp_mi_stream_poll(sub);
+            if (sub == oldest) rc = r;
+        }
+        return rc;
+    }
     std::lock_guard<std::mutex> lock(s->mu);
     DeviceGuard guard(s->device);
     if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
@@ -337,6 +413,23 @@ int llcomp_mi_stream_poll(llcomp_mi_stream* s) {
 int llcomp_mi_stream_wait(llcomp_mi_stream* s, llcomp_mi_stream_result* r) {
     if (!s || !r) return LLCOMP_MI_BAD_ARGS;
     std::memset(r, 0, sizeof(*r));
+    if (!s->subs.empty()) {
+        uint32_t i = 0;
+        {
+            std::lock_guard<std::mutex> lock(s->mu);
+            if (s->order.empty()) return LLCOMP_MI_BAD_ARGS;
+            i = s->order.front();  // (single consumer: the oldest job cannot change while this thread waits for it)
+        }
+        // the other devices' size mailboxes keep arriving while this thread blocks on the oldest job's pipeline: let them queue their
+        // container copies first (a pipeline pumps itself only when somebody enters it)
+        for (uint32_t j = 0; j < s->subs.size(); ++j)
+            if (j != i) (void)llcomp_mi_stream_poll(s->subs[j]);
+        if (int rc = llcomp_mi_stream_wait(s->subs[i], r)) return rc;
+        r->slot |= i << 8;
+        std::lock_guard<std::mutex> lock(s->mu);
+        s->order.pop_front();
+        return LLCOMP_MI_OK;
+    }
     std::unique_lock<std::mutex> lock(s->mu);
     if (s->fifo.empty()) return LLCOMP_MI_BAD_ARGS;  // nothing was submitted
     DeviceGuard guard(s->device);
@@ -386,6 +479,7 @@ int llcomp_mi_stream_wait(llcomp_mi_stream* s, llcomp_mi_stream_result* r) {
 
 int llcomp_mi_stream_release(llcomp_mi_stream* s, uint32_t slot) {
     if (!s) return LLCOMP_MI_BAD_ARGS;
+    if (!s->subs.empty()) return (slot >> 8) < s->subs.size() ? llcomp_mi_stream_release(s->subs[slot >> 8], slot & 0xFF) : LLCOMP_MI_BAD_ARGS;
     std::lock_guard<std::mutex> lock(s->mu);
     if (slot >= s->slots.size() || s->slots[slot].state != kHeld) return LLCOMP_MI_BAD_ARGS;
     s->slots[slot].state = kFree;

@@ -34,16 +34,12 @@ MAGIC_SLICED, HEADER = 0x9C, 24
 
 def plan_chunks(height, tile_h, world, chunks_per_rank=4):
     """[(tile_row0, tile_row1, owner)]: consecutive chunks of whole tile rows, chunk i -> rank i % world.  Chunks are as
-    even as the tile grid allows; with fewer tile rows than world * chunks_per_rank every chunk is one tile row."""
-    tile_h = height if tile_h <= 0 or tile_h > height else tile_h
-    nty = (height + tile_h - 1) // tile_h
-    n_chunks = max(1, min(nty, world * max(1, chunks_per_rank)))
-    out, t = [], 0
-    for i in range(n_chunks):
-        cnt = nty // n_chunks + (1 if i < nty % n_chunks else 0)
-        out.append((t, t + cnt, i % world))
-        t += cnt
-    return out
+    even as the tile grid allows; with fewer tile rows than world * chunks_per_rank every chunk is one tile row.
+    ONE implementation for every multi-GPU path: llcomp_mi_plan_chunks (csrc/container.cpp) -- the in-process device lists of
+    the C ABI split an image exactly like the ranks here."""
+    from . import plan_chunks as _plan
+
+    return _plan(height, tile_h if tile_h > 0 else 0, world, chunks_per_rank)
 
 
 def local_rows(height, tile_h, world, rank, chunks_per_rank=4):

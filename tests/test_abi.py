@@ -32,13 +32,13 @@ def test_header_symbols_all_exported(mi):
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in llcomp_mi.h but not exported by libllcomp_mi.so"
-    assert lib.llcomp_mi_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.llcomp_mi_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_struct_layouts_match_header(mi):
     from llcomp_amd import _lib
 
-    assert C.sizeof(_lib.Opts) == 28
+    assert C.sizeof(_lib.Opts) == 48 and _lib.Opts.devices.offset == 32 and _lib.Opts.chunks_per_device.offset == 40
     assert C.sizeof(_lib.Info) == 56
     assert C.sizeof(_lib.StreamResult) == 40
 
@@ -124,6 +124,65 @@ def test_band_concatenator_matches_oracle_container(mi, orc, shape, planar):
         assert mi.split_band(whole, a, b) == band
     with pytest.raises(mi.LlcompError):
         mi.merge_bands([bands[0], orc.compress_sliced(img[: th], tw + 1, th, planar)])
+
+
+def _plan_chunks_reference(height, tile_h, world, chunks_per_rank=4):
+    """the split as rounds 2-5 had it in llcomp_amd/sharding.py (pure Python): the pin for llcomp_mi_plan_chunks, which is now the one
+    implementation behind the ranks of sharding.py AND the device lists of the C ABI"""
+    tile_h = height if tile_h <= 0 or tile_h > height else tile_h
+    nty = (height + tile_h - 1) // tile_h
+    n_chunks = max(1, min(nty, world * max(1, chunks_per_rank)))
+    out, t = [], 0
+    for i in range(n_chunks):
+        cnt = nty // n_chunks + (1 if i < nty % n_chunks else 0)
+        out.append((t, t + cnt, i % world))
+        t += cnt
+    return out
+
+
+def test_plan_chunks_one_implementation(mi):
+    from llcomp_amd import sharding
+
+    rng = np.random.default_rng(7)
+    cases = [(8192, 1, 8, 4), (8192, 512, 8, 4), (67, 1, 8, 4), (2160, 64, 3, 4), (10, 0, 3, 4), (1, 1, 8, 4), (4097, 64, 8, 1), (333, 64, 2, 7)]
+    cases += [(int(rng.integers(1, 5000)), int(rng.integers(0, 300)), int(rng.integers(1, 17)), int(rng.integers(1, 9))) for _ in range(300)]
+    for h, th, n, cpr in cases:
+        want = _plan_chunks_reference(h, th, n, cpr)
+        assert mi.plan_chunks(h, th, n, cpr) == want == sharding.plan_chunks(h, th, n, cpr), (h, th, n, cpr)
+        # the chunks tile the tile rows exactly, in order, owners round-robin
+        nty = (h + (th if 0 < th <= h else h) - 1) // (th if 0 < th <= h else h)
+        assert want[0][0] == 0 and want[-1][1] == nty and all(a[1] == b[0] for a, b in zip(want, want[1:]))
+    # the C entry point itself: counting call, capacity check, defaults
+    L = mi._lib.load()
+    n = C.c_uint32()
+    assert L.llcomp_mi_plan_chunks(100, 10, 2, 0, None, 0, C.byref(n)) == mi.OK and n.value == 8  # chunks_per_part 0 = 4
+    tri = (C.c_uint32 * 9)()
+    assert L.llcomp_mi_plan_chunks(100, 10, 2, 0, tri, 3, C.byref(n)) == mi.OUTPUT_OVERFLOW and n.value == 8
+    assert L.llcomp_mi_plan_chunks(0, 10, 2, 0, None, 0, C.byref(n)) == mi.BAD_ARGS
+    assert L.llcomp_mi_plan_chunks(100, 10, 0, 0, None, 0, C.byref(n)) == mi.BAD_ARGS
+
+
+def test_device_list_arguments_are_checked_without_a_gpu(mi):
+    """what the device-list entry points refuse before they touch a device"""
+    L = mi._lib.load()
+    px = np.zeros(12, np.uint8)
+    out, n = mi._lib.u8p(), C.c_size_t()
+    devs = (C.c_int32 * 2)(0, 0)
+    o = mi._lib.Opts(C.sizeof(mi._lib.Opts), mi.FORMAT_SLICED, 0, 0, 1, -1, 0, 2, None, 0, 0)      # a count without a list
+    assert L.llcomp_mi_encode(px.ctypes.data_as(mi._lib.u8p), 2, 2, 3, C.byref(o), C.byref(out), C.byref(n)) == mi.BAD_ARGS
+    o = mi._lib.Opts(C.sizeof(mi._lib.Opts), mi.FORMAT_SLICED, 0, 0, 1, -1, 0, 65, C.cast(devs, C.POINTER(C.c_int32)), 0, 0)  # too many
+    assert L.llcomp_mi_encode(px.ctypes.data_as(mi._lib.u8p), 2, 2, 3, C.byref(o), C.byref(out), C.byref(n)) == mi.BAD_ARGS
+    o = mi._lib.Opts(C.sizeof(mi._lib.Opts), mi.FORMAT_SLICED, 0, 0, 1, -1, 0, 0, None, 0, 7)       # reserved must be 0
+    assert L.llcomp_mi_encode(px.ctypes.data_as(mi._lib.u8p), 2, 2, 3, C.byref(o), C.byref(out), C.byref(n)) == mi.BAD_ARGS
+    o = mi._lib.Opts(28, mi.FORMAT_SLICED, 0, 0, 1, -1, 0, 0, None, 0, 0)                            # an ABI-3 caller's struct
+    assert L.llcomp_mi_encode(px.ctypes.data_as(mi._lib.u8p), 2, 2, 3, C.byref(o), C.byref(out), C.byref(n)) == mi.BAD_ARGS
+    st = C.c_void_p()
+    assert L.llcomp_mi_stream_create_multi(C.byref(st), None, 2, 64, 64, 3, 32, 1, 1, 2, 1) == mi.BAD_ARGS
+    assert L.llcomp_mi_stream_create_multi(C.byref(st), devs, 0, 64, 64, 3, 32, 1, 1, 2, 1) == mi.BAD_ARGS
+    neg = (C.c_int32 * 2)(0, -1)
+    assert L.llcomp_mi_stream_create_multi(C.byref(st), neg, 2, 64, 64, 3, 32, 1, 1, 2, 1) == mi.BAD_ARGS
+    assert L.llcomp_mi_last_device_error(None, None, None) == 0
+    assert "device" in str(mi.LlcompError(mi.DEVICE_FAILED))
 
 
 def test_fnv_helper_matches_the_checker_and_continues_over_pieces(mi, orc):

@@ -1,4 +1,7 @@
-// llcomp_stream [frames] [width] [height] [tile_w] [tile_h] [depth] [encodes_in_flight] [frames_per_job] [pipelines]
+// llcomp_stream [frames] [width] [height] [tile_w] [tile_h] [depth] [encodes_in_flight] [frames_per_job] [pipelines] [--devices a,b,...]
+//
+// --devices: every pipeline object is a dealer over these GPUs (llcomp_mi_stream_create_multi: one pipeline of `depth` slots per
+// device, jobs dealt round-robin, results in submission order) -- BASELINE config 5's "round-robin over the GPUs" from one process.
 //
 // BASELINE config 5 driven from C++ through the C ABI alone (include/llcomp_mi.h, llcomp_mi_stream_*): `frames` distinct
 // RGB8 noise frames stream host -> GPU -> host (SLICED container) -> GPU -> host with `depth` pipeline slots; every decoded
@@ -44,6 +47,7 @@ struct Check {  // a decoded frame waiting for its comparison; the slot is relea
 
 struct Config {
     uint32_t w, h, c, tw, th, depth, max_enc, fpj;
+    std::vector<int32_t> devices;  // empty: the current device
 };
 
 struct Outcome {
@@ -57,7 +61,11 @@ struct Outcome {
 // one pipeline: `n` jobs of cfg.fpj frames each, sources at src + raw * job
 void drive(const Config& cfg, const uint8_t* src, uint32_t n, size_t raw, double origin, Outcome& out) {
     llcomp_mi_stream* st = nullptr;
-    if (int rc = llcomp_mi_stream_create_ex(&st, -1, cfg.w, cfg.h, cfg.c, cfg.tw, cfg.th, 1, cfg.depth, cfg.fpj)) {
+    const int rc_create = cfg.devices.empty()
+                              ? llcomp_mi_stream_create_ex(&st, -1, cfg.w, cfg.h, cfg.c, cfg.tw, cfg.th, 1, cfg.depth, cfg.fpj)
+                              : llcomp_mi_stream_create_multi(&st, cfg.devices.data(), uint32_t(cfg.devices.size()), cfg.w, cfg.h, cfg.c, cfg.tw,
+                                                              cfg.th, 1, cfg.depth, cfg.fpj);
+    if (int rc = rc_create) {
         std::fprintf(stderr, "llcomp_mi_stream_create: %s\n", llcomp_mi_strerror(rc));
         out.fail = rc;
         return;
@@ -158,8 +166,22 @@ void drive(const Config& cfg, const uint8_t* src, uint32_t n, size_t raw, double
 }  // namespace
 
 int main(int argc, char** argv) {
-    const uint32_t frames_total = argc > 1 ? uint32_t(std::atoi(argv[1])) : 64;
     Config cfg;
+    for (int i = 1; i + 1 < argc; ++i)  // the one flag: taken out of argv, the rest stays positional
+        if (std::strcmp(argv[i], "--devices") == 0) {
+            for (const char* p = argv[i + 1]; *p;) {
+                char* e = nullptr;
+                const long v = std::strtol(p, &e, 10);
+                if (e == p || v < 0) return 1;
+                cfg.devices.push_back(int32_t(v));
+                p = *e == ',' ? e + 1 : e;
+                if (*e && *e != ',') return 1;
+            }
+            for (int j = i; j + 2 < argc; ++j) argv[j] = argv[j + 2];
+            argc -= 2;
+            break;
+        }
+    const uint32_t frames_total = argc > 1 ? uint32_t(std::atoi(argv[1])) : 64;
     cfg.w = argc > 2 ? uint32_t(std::atoi(argv[2])) : 3840;
     cfg.h = argc > 3 ? uint32_t(std::atoi(argv[3])) : 2160;
     cfg.c = 3;
@@ -211,7 +233,7 @@ int main(int argc, char** argv) {
         for (double t : o.done_at) counted += t > begin;
     const double steady = double(counted) * cfg.fpj * cfg.w * cfg.h / 1e6 / (end - begin);
     std::printf("{\"frames\": %u, \"frames_per_job\": %u, \"pipelines\": %u, \"width\": %u, \"height\": %u, \"tile\": \"%ux%u\", \"depth\": %u, "
-                "\"steady_mpix_s\": %.1f, \"compression_ratio\": %.4f, \"backpressure_hits\": %u, \"verified\": true}\n",
-                frames_total, cfg.fpj, pipelines, cfg.w, cfg.h, cfg.tw, cfg.th, cfg.depth, steady, double(raw) * jobs / double(container_bytes), busy);
+                "\"devices\": %u, \"steady_mpix_s\": %.1f, \"compression_ratio\": %.4f, \"backpressure_hits\": %u, \"verified\": true}\n",
+                frames_total, cfg.fpj, pipelines, cfg.w, cfg.h, cfg.tw, cfg.th, cfg.depth, uint32_t(cfg.devices.empty() ? 1 : cfg.devices.size()), steady, double(raw) * jobs / double(container_bytes), busy);
     return 0;
 }

@@ -1,4 +1,4 @@
-// llcompc <image> [--sliced TWxTH | --sliced auto] [--interleaved] [--legacy] [--small-model]
+// llcompc <image> [--sliced TWxTH | --sliced auto] [--interleaved] [--legacy] [--small-model] [--devices a,b,...]
 //
 // Compressor front end on libllcomp_mi.so with the observable behaviour of the reference tool
 // (/root/reference/llcompc.cpp:14-43): exactly one required positional argument, output written next to the input as
@@ -9,6 +9,8 @@
 // tool says so on stderr for images above one megapixel; --sliced TWxTH selects the parallel container (e.g. 480x1),
 // --sliced auto takes one-row slices of the width llcomp_mi_suggest_tile_w returns for ONE image per call (a lone 4K
 // frame: 80 pixels, 0.76 ms instead of 2.2 ms at 480), --legacy states the default explicitly and silences the note.
+// --devices 0,1,2,...: the image's tile rows are dealt over these GPUs inside this process (llcomp::Options::devices; sliced
+// containers only, byte-identical to the one-GPU container).
 #include <cstdio>
 #include <exception>
 #include <string>
@@ -29,6 +31,8 @@ bool parse_flags(int argc, char** argv, llcomp::Options& opt, bool& explicit_leg
             explicit_legacy = true;
         } else if (flag == "--small-model") {  // the bitstream of a reference built with LargeModel = false (llcomp.hpp:21)
             opt.small_model = true;
+        } else if (flag == "--devices" && i + 1 < argc) {
+            if (!cli::parse_device_list(argv[++i], opt.devices)) return false;
         } else if (flag == "--sliced" && i + 1 < argc) {
             unsigned tw = 0, th = 0;
             if (std::string(argv[i + 1]) == "auto") {  // width chosen once the image size is known (compress_file)
@@ -81,7 +85,7 @@ int main(int argc, char** argv) {
     llcomp::Options opt;
     bool explicit_legacy = false, auto_width = false;
     if (argc < 2 || !parse_flags(argc, argv, opt, explicit_legacy, auto_width)) {
-        std::fprintf(stderr, "Usage: %s <image_path> [--sliced TWxTH|auto] [--interleaved] [--legacy] [--small-model]\n", argc ? argv[0] : "llcompc");
+        std::fprintf(stderr, "Usage: %s <image_path> [--sliced TWxTH|auto] [--interleaved] [--legacy] [--small-model] [--devices a,b,...]\n", argc ? argv[0] : "llcompc");
         return cli::kFailed;
     }
     return compress_file(argv[1], opt, explicit_legacy, auto_width);

@@ -1,4 +1,4 @@
-// llcompd <file.llcomp> [--small-model]
+// llcompd <file.llcomp> [--small-model] [--devices a,b,...]
 //
 // Decompressor front end on libllcomp_mi.so with the observable behaviour of the reference tool
 // (/root/reference/llcompd.cpp:11-41): one positional argument, the picture is written as "<file>.png", exit status 1
@@ -6,7 +6,8 @@
 // exception, and -- faithfully -- still 0 when only writing the PNG failed (llcompd.cpp:29-31).  stb_image_write is not
 // available; tools/image_io.hpp writes the PNG (adaptive row filters, own deflate).  Reads both wire formats.  --small-model: the file is a
 // reference-format stream written by a reference built with `LargeModel = false` (llcomp.hpp:21) -- that header does not
-// record the variant (a sliced container does).
+// record the variant (a sliced container does).  --devices 0,1,...: a sliced container is decoded over these GPUs inside this
+// process (llcomp_mi_decode_devices).
 #include <cstdio>
 #include <exception>
 #include <string>
@@ -18,7 +19,7 @@
 
 namespace {
 
-int expand_file(const std::string& stream_path, bool legacy_small_model) {
+int expand_file(const std::string& stream_path, bool legacy_small_model, const std::vector<int>& devices) {
     std::vector<uint8_t> stream;
     if (!cli::slurp(stream_path, stream)) {
         std::fprintf(stderr, "Error opening input file: %s\n", stream_path.c_str());
@@ -26,7 +27,7 @@ int expand_file(const std::string& stream_path, bool legacy_small_model) {
     }
     llcomp::RawImage picture;
     try {
-        picture = llcomp::decompressImage(stream, -1, legacy_small_model);
+        picture = devices.empty() ? llcomp::decompressImage(stream, -1, legacy_small_model) : llcomp::decompressImage(stream, devices, legacy_small_model);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "Error decompressing image: %s\n", e.what());
         return cli::kFailed;
@@ -45,10 +46,18 @@ int expand_file(const std::string& stream_path, bool legacy_small_model) {
 
 int main(int argc, char** argv) {
     if (argc < 2) {
-        std::fprintf(stderr, "Usage: %s <image_path> [--small-model]\n", argc ? argv[0] : "llcompd");
+        std::fprintf(stderr, "Usage: %s <image_path> [--small-model] [--devices a,b,...]\n", argc ? argv[0] : "llcompd");
         return cli::kFailed;
     }
     bool small = false;
-    for (int i = 2; i < argc; ++i) small = small || std::string(argv[i]) == "--small-model";
-    return expand_file(argv[1], small);
+    std::vector<int> devices;
+    for (int i = 2; i < argc; ++i) {
+        const std::string flag = argv[i];
+        if (flag == "--small-model") small = true;
+        else if (flag == "--devices" && i + 1 < argc && !cli::parse_device_list(argv[++i], devices)) {
+            std::fprintf(stderr, "Usage: %s <image_path> [--small-model] [--devices a,b,...]\n", argv[0]);
+            return cli::kFailed;
+        }
+    }
+    return expand_file(argv[1], small, devices);
 }
