@@ -233,6 +233,28 @@ int llcomp_mi_device_range_sums(const void* d_vals, const void* d_start, const v
 /* The u32 status word written by encode/decode holds bit flags (1 overflow, 2 bad exponent, 4 truncated);
  * this maps it to an llcomp_mi_status. */
 uint32_t llcomp_mi_status_from_bits(uint32_t bits);
+/* Event counters of a codec object: what the rare and the adaptive paths of its kernels actually did, cumulative since creation (or
+ * the last reset).  The kernels add to them with one atomic per wavefront -- and only wavefronts that have something to report -- so
+ * they cost nothing measurable and are always on.  Tests use them to prove that a branch ran (parity passes either way); a caller can
+ * watch the bank cache's hit rate on its content.  get_counters waits for the codec's last call (its own event, not the device),
+ * writes the first n (<= LLCOMP_MI_CTR_COUNT) counters and clears all of them when reset != 0. */
+enum {
+    LLCOMP_MI_CTR_DEC_CACHED_WAVES = 0,    /* 2-D decoder (state tables in HBM): wavefronts that started with the bank cache in LDS */
+    LLCOMP_MI_CTR_DEC_BYPASSED_WAVES = 1,  /* ... of those, the ones that gave it up (fewer than one hit in eight over four rows) */
+    LLCOMP_MI_CTR_CACHE_LOOKUPS = 2,       /* state-bank look-ups in the cache (one per decoded sample while the cache is in use) */
+    LLCOMP_MI_CTR_CACHE_MISSES = 3,        /* ... that missed: a 64-byte line fill from the table in HBM */
+    LLCOMP_MI_CTR_CACHE_WRITEBACKS = 4,    /* victims written back to the table (one 32-byte sector each) */
+    LLCOMP_MI_CTR_DEC_REPLAYS = 5,         /* decoded samples that ran out of window bytes (or saw an invalid exponent) on the fast path
+                                              and went through rollback + checked replay (llcomp.hpp:219-247 is the checked form) */
+    LLCOMP_MI_CTR_ENC_CARRY_BACKS = 6,     /* encoder: carries into a held 0xFF byte that went on into bytes already stored to HBM
+                                              (the reference's outstanding_count run, llcomp.hpp:40-57, resolved eagerly) */
+    LLCOMP_MI_CTR_GENERATION_WRAPS = 7,    /* state tables cleared because the 8-bit generation tag ran out (every 255 calls) */
+    LLCOMP_MI_CTR_DEC_LAUNCHES_CACHED = 8, /* 2-D decode launches that ran with the bank cache */
+    LLCOMP_MI_CTR_DEC_LAUNCHES_PLAIN = 9,  /* ... and without it, because (nearly) every wavefront of the last cached launch had given
+                                              it up: the plain kernel holds no LDS for a cache nobody uses; re-probed every 16th call */
+    LLCOMP_MI_CTR_COUNT = 16
+};
+int llcomp_mi_codec_get_counters(llcomp_mi_codec* codec, uint64_t* out, uint32_t n, int reset);
 /* Per-kernel timing with hipEvents recorded on the caller's stream around each launch (bench.py's roofline leg).
  * get_profile drains the stream, adds up the milliseconds since the last call and resets:
  *   ms[0] state-table clear -- or, where the 2-D encoder replays its states ahead of the coder (slices of several rows and

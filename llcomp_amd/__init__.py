@@ -472,5 +472,15 @@ class Codec:
         _check(self._L.llcomp_mi_codec_get_profile(self._h, ms, C.byref(ne), C.byref(nd)))
         return dict(zip(self.PROFILE_SLOTS, list(ms))), ne.value, nd.value
 
+    COUNTERS = ("dec_cached_waves", "dec_bypassed_waves", "cache_lookups", "cache_misses", "cache_writebacks", "dec_replays", "enc_carry_backs",
+                "generation_wraps", "dec_launches_cached", "dec_launches_plain")
+
+    def counters(self, reset=False):
+        """{name: count} -- what the rare and adaptive paths of this codec's kernels did so far (llcomp_mi_codec_get_counters);
+        waits for the codec's last call"""
+        v = (C.c_uint64 * 16)()
+        _check(self._L.llcomp_mi_codec_get_counters(self._h, v, 16, int(bool(reset))))
+        return dict(zip(self.COUNTERS, list(v)))
+
     def status(self, bits):
         return self._L.llcomp_mi_status_from_bits(int(bits))

@@ -103,6 +103,7 @@ int next_state_generation(llcomp_mi_codec* k, hipStream_t s) {
     }
     if (k->state_generation == 0 || k->state_generation >= 255) {
         const Geometry& g = k->g;
+        if (k->state_generation >= 255) ++k->host_counters[kCtrGenerationWraps];
         HIP_TRY(hipMemsetAsync(k->d_states, 0, (uint64_t(lane_groups(g)) * kContexts << g.lane_shift) * 8, s));
         k->state_generation = 0;
     }
@@ -124,6 +125,47 @@ int ensure_snapshot_arrays(llcomp_mi_codec* k) {
     }
     k->allocated_bytes += el * 18;
     return LLCOMP_MI_OK;
+}
+
+// The 2-D decoder's bank cache, per LAUNCH (codec_internal.hpp).  A wavefront that finds fewer than one hit in eight gives the cache up
+// by itself, but it goes on holding its 18 KB of LDS to the end of the kernel: content that makes EVERY wavefront give up (a dithered
+// gradient) paid the occupancy cap and the helper kernels' waits for nothing (round 5: 5 296 -> 4 622 MPix/s at 48 frames x 3).  The
+// kernels count {wavefronts, wavefronts that gave up}; when (nearly) all of the last cached launch did, the codec's next kPlainRun
+// decode calls run the plain kernel, then one call probes with the cache again.  Nothing waits: a result that has not arrived yet
+// leaves things as they are.  Same bytes either way (the tables are per call).
+bool use_bank_cache(llcomp_mi_codec* k) {
+    if (bank_cache_log2(k->g) == 0) return false;
+    if (k->fb_pending && k->fb_event && hipEventQuery(k->fb_event) == hipSuccess) {
+        k->fb_pending = false;
+        const uint64_t waves = k->h_feedback[0] - k->fb_seen[0], gave_up = k->h_feedback[1] - k->fb_seen[1];
+        k->fb_seen[0] = k->h_feedback[0];
+        k->fb_seen[1] = k->h_feedback[1];
+        if (waves && gave_up * 16 >= waves * 15) k->plain_calls_left = llcomp_mi_codec::kPlainRun;
+    } else {
+        (void)hipGetLastError();
+    }
+    if (k->plain_calls_left) {
+        --k->plain_calls_left;
+        ++k->host_counters[kCtrDecLaunchesPlainByFeedback];
+        return false;
+    }
+    ++k->host_counters[kCtrDecLaunchesCached];
+    return true;
+}
+// ... behind a cached launch: {cached wavefronts, bypassed wavefronts} -> the pinned mailbox, and the event that says it has arrived
+void queue_feedback(llcomp_mi_codec* k, hipStream_t s) {
+    if (!k->h_feedback) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&k->h_feedback), 16, hipHostMallocDefault) != hipSuccess) { k->h_feedback = nullptr; (void)hipGetLastError(); return; }
+        k->h_feedback[0] = k->h_feedback[1] = 0;
+        if (hipEventCreateWithFlags(&k->fb_event, hipEventDisableTiming) != hipSuccess) { k->fb_event = nullptr; (void)hipGetLastError(); return; }
+    }
+    if (!k->fb_event || k->fb_pending) return;  // (the previous answer has not been looked at: its copy may still be in flight)
+    if (hipMemcpyAsync(k->h_feedback, k->d_counters + kCtrDecCachedWaves, 16, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipEventRecord(k->fb_event, s) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    k->fb_pending = true;
 }
 
 // the codec's completion event: recorded behind the last launch of a call, on the caller's stream
@@ -164,6 +206,13 @@ void codec_release(llcomp_mi_codec* k) {
     dev_free(k->d_snap_sorted, k->done);
     dev_free(k->d_snap_banks, k->done);
     dev_free(k->d_snap_res, k->done);
+    dev_free(k->d_counters, k->done);
+    if (k->fb_event) (void)hipEventDestroy(k->fb_event);  // (legal while pending: released when it completes)
+    if (k->h_feedback) {
+        // the mailbox copy may still be queued on the caller's stream: it must not land in freed memory
+        if (k->done && k->done->ev) (void)hipEventSynchronize(k->done->ev);
+        (void)hipHostFree(k->h_feedback);
+    }
     for (auto& sp : k->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     delete k;
 }
@@ -247,7 +296,9 @@ int llcomp_mi_codec_create_ex(llcomp_mi_codec** out, int32_t device, uint32_t fr
     const bool ok = dev_alloc(&k->d_sym_or_rec, b_sym) == hipSuccess && dev_alloc(&k->d_lane_order, b_lanes) == hipSuccess &&
                     dev_alloc(reinterpret_cast<void**>(&k->d_scratch), b_scratch) == hipSuccess &&
                     dev_alloc(reinterpret_cast<void**>(&k->d_group_off), b_off) == hipSuccess &&
-                    dev_alloc(reinterpret_cast<void**>(&k->d_total_tmp), 8) == hipSuccess;
+                    dev_alloc(reinterpret_cast<void**>(&k->d_total_tmp), 8) == hipSuccess &&
+                    dev_alloc(reinterpret_cast<void**>(&k->d_counters), kCtrCount * 8) == hipSuccess &&
+                    hipMemset(k->d_counters, 0, kCtrCount * 8) == hipSuccess;
     if (!ok) {
         llcomp_mi_codec_destroy(k);
         return LLCOMP_MI_NOMEM;
@@ -315,7 +366,7 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
         const bool snap = snapshot_mode(g);
         HIP_TRY(launch_encode_slices(g, snap ? k->d_snap_res : k->d_lane_order, snap ? static_cast<uint64_t*>(k->d_snap_banks) : k->d_states,
                                      k->state_generation, k->d_scratch, static_cast<uint32_t*>(d_slice_len),
-                                     k->d_group_off, static_cast<uint32_t*>(d_status), s));
+                                     k->d_group_off, static_cast<uint32_t*>(d_status), k->d_counters, s));
     }
     {
         Timed t(k, s, 3);
@@ -354,8 +405,10 @@ int llcomp_mi_codec_decode(llcomp_mi_codec* k, const void* d_payload, uint64_t p
     }
     {
         Timed t(k, s, 5);
+        const bool cache = use_bank_cache(k);
         HIP_TRY(launch_decode_slices(g, k->d_scratch, static_cast<const uint32_t*>(d_slice_len), k->d_states, k->state_generation,
-                                     static_cast<int16_t*>(k->d_lane_order), static_cast<uint32_t*>(d_status), s));
+                                     static_cast<int16_t*>(k->d_lane_order), static_cast<uint32_t*>(d_status), k->d_counters, cache, s));
+        if (cache) queue_feedback(k, s);
     }
     {
         Timed t(k, s, 6);
@@ -389,6 +442,25 @@ int llcomp_mi_device_range_sums(const void* d_vals, const void* d_start, const v
     if (!d_vals || !d_start || !d_count || !d_out) return LLCOMP_MI_BAD_ARGS;
     HIP_TRY(launch_range_sums(static_cast<const uint32_t*>(d_vals), static_cast<const uint64_t*>(d_start), static_cast<const uint64_t*>(d_count),
                               static_cast<uint64_t*>(d_out), n, cap, static_cast<hipStream_t>(stream)));
+    return LLCOMP_MI_OK;
+}
+
+int llcomp_mi_codec_get_counters(llcomp_mi_codec* k, uint64_t* out, uint32_t n, int reset) {
+    if (!k || !out || n > kCtrCount) return LLCOMP_MI_BAD_ARGS;
+    DeviceGuard guard(k->device);
+    if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
+    // the codec's last call has to be done before its counts mean anything: wait for ITS event (not for the device)
+    if (k->done && k->done->ev && hipEventSynchronize(k->done->ev) != hipSuccess) (void)hipGetLastError();
+    uint64_t dev[kCtrCount];
+    HIP_TRY(hipMemcpy(dev, k->d_counters, sizeof(dev), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i) out[i] = dev[i] + k->host_counters[i];
+    if (reset) {
+        HIP_TRY(hipMemset(k->d_counters, 0, sizeof(dev)));
+        for (auto& h : k->host_counters) h = 0;
+        k->fb_seen[0] = k->fb_seen[1] = 0;
+        k->fb_pending = false;  // (a mailbox copy still in flight would carry pre-reset values)
+        if (k->h_feedback) k->h_feedback[0] = k->h_feedback[1] = 0;
+    }
     return LLCOMP_MI_OK;
 }
 

@@ -34,6 +34,19 @@ struct llcomp_mi_codec {
     void* d_snap_res = nullptr;
     uint64_t workspace_bytes = 0;    // what the codec can hold at most
     uint64_t allocated_bytes = 0;    // what it holds right now (state tables / snapshot arrays come with the first call that needs them)
+    // Event counters (kernels.hpp kCtr*): kernel-side u64[kCtrCount] in HBM, host-side additions, and the feedback that takes the bank
+    // cache away from a codec whose 2-D decode wavefronts ALL gave it up: a cached launch is followed by a 16-byte copy of
+    // {cached wavefronts, bypassed wavefronts} into a pinned mailbox + an event; the next decode call looks at the event WITHOUT waiting
+    // (no result yet = no change) and runs the plain kernel -- no LDS held for a cache nobody uses, so the helper kernels beside it find
+    // room on the CUs -- for kPlainRun calls before it probes with the cache again.
+    unsigned long long* d_counters = nullptr;
+    uint64_t host_counters[llcomp_mi::kCtrCount] = {};
+    uint64_t* h_feedback = nullptr;    // pinned: [0] cached wavefronts, [1] bypassed wavefronts (cumulative), as of fb_event
+    hipEvent_t fb_event = nullptr;
+    bool fb_pending = false;           // a mailbox copy has been queued and not looked at yet
+    uint64_t fb_seen[2] = {0, 0};      // the mailbox's values at the last look
+    uint32_t plain_calls_left = 0;     // > 0: this many decode calls run without the bank cache
+    static constexpr uint32_t kPlainRun = 15;
     bool need_states = true;  // false when the states live in LDS (1-row slices; one slice per wavefront)
     uint32_t state_generation = 0;  // tag of the last call that used d_states (kernels.hpp); 0 = the table has not been cleared yet
     // optional per-kernel timing (hipEvents on the caller's stream)

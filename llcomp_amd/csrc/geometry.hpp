@@ -73,7 +73,8 @@ inline Tuning tuning_from_env() {
     return t;
 }
 
-inline int bank_cache_log2(const Geometry& g) { return (g.flags & kGeoBankCache) ? 5 : 0; }
+constexpr int kBankCacheLog2 = 5;  // entries per lane of the 2-D decoder's bank cache (slice_kernels.hip): ONE constant for flag, launcher, kernel
+inline int bank_cache_log2(const Geometry& g) { return (g.flags & kGeoBankCache) ? kBankCacheLog2 : 0; }
 
 // lane order: element k of slice `id` inside an array laid out [group][k][group width]
 LLMI_HD inline size_t lane_order_index(const Geometry& g, uint32_t id, uint32_t k) {

@@ -11,6 +11,23 @@ namespace llcomp_mi {
 // status word bits written by kernels (atomicOr); mapped to llcomp_mi_status by the host
 enum : uint32_t { kStOverflow = 1u, kStBadExponent = 2u, kStTruncated = 4u, kStInternal = 8u /* a kernel found its own assumptions violated */ };
 
+// Event counters of a codec object (u64[kCtrCount] in HBM, cumulative; llcomp_mi_codec_get_counters, include/llcomp_mi.h
+// LLCOMP_MI_CTR_*).  The kernels add to 0..6 with one atomic per wavefront and counter at their end -- and only wavefronts that have
+// something to report; 7..9 are kept by the host (codec.hip).
+enum : uint32_t {
+    kCtrDecCachedWaves = 0,    // wavefronts of the 2-D decoder that started with the bank cache
+    kCtrDecBypassedWaves = 1,  // ... of those, the ones that gave it up (fewer than one hit in eight)
+    kCtrCacheLookups = 2,      // bank look-ups in the cache (lane-samples)
+    kCtrCacheMisses = 3,       // ... that missed (line fill from the table in HBM)
+    kCtrCacheWritebacks = 4,   // victims written back to the table
+    kCtrDecReplays = 5,        // decoded samples that went through rollback + checked replay
+    kCtrEncCarryBacks = 6,     // encoder carries that went on into bytes already stored to HBM
+    kCtrGenerationWraps = 7,   // state tables cleared because the 8-bit generation ran out (host)
+    kCtrDecLaunchesCached = 8, // 2-D decode launches with the bank cache (host)
+    kCtrDecLaunchesPlainByFeedback = 9,  // ... and without it because the previous call's wavefronts all gave it up (host)
+    kCtrCount = 16,
+};
+
 // Stage A (encode side): pixels u8 [frames][h][w][c] -> per-sample symbols u32, low 16 bits folded context, high
 // 16 bits folded residual (llcomp.hpp:396-436).  Layout [frames][h][w][c] for interleaved slices, plane-major
 // [frames][c][h][w] for planar slices (device_common.hpp), so that a slice row is contiguous.
@@ -43,7 +60,8 @@ bool slices_need_state_tables(const Geometry& g);
 //               The caller clears the table once (generation 0 = cleared memory) and again before it reuses a generation.
 //   d_scratch : the slices' streams in stream lane order ; d_slice_len : u32[n_slices]
 hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* d_states, uint32_t generation, uint8_t* d_scratch,
-                                uint32_t* d_slice_len, uint64_t* d_group_off, uint32_t* d_status, hipStream_t stream);
+                                uint32_t* d_slice_len, uint64_t* d_group_off, uint32_t* d_status, unsigned long long* d_counters,
+                                hipStream_t stream);
 // Offsets of the slices in the packed payload: one exclusive prefix value per LANE GROUP, u64[lane_groups + 1] (the last
 // element and *d_total = sum of all lengths); pack / stage add the wave prefix of the group's own lengths.
 // launch_encode_slices leaves the group sums in d_group_off itself when encoder_writes_group_sums(g); otherwise (and
@@ -74,8 +92,10 @@ hipError_t launch_range_sums(const uint32_t* d_vals, const uint64_t* d_start, co
                              uint32_t cap, hipStream_t stream);
 // One lane per slice: range decoder + adaptive states + context model on reconstructed samples.
 // llcomp.hpp:91-127, 219-247, 486-530.  d_rec int16 in LANE ORDER.
-// d_units: the slices' streams in dword lane order (launch_stage_streams).
+// d_units: the slices' streams in dword lane order (launch_stage_streams).  d_counters: kCtr* (may be null).  bank_cache = false:
+// a geometry with kGeoBankCache runs the plain kernel this once (same bytes; the tables are per call, nothing carries over).
 hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_units, const uint32_t* d_slice_len,
-                                uint64_t* d_states, uint32_t generation, int16_t* d_rec, uint32_t* d_status, hipStream_t stream);
+                                uint64_t* d_states, uint32_t generation, int16_t* d_rec, uint32_t* d_status, unsigned long long* d_counters,
+                                bool bank_cache, hipStream_t stream);
 
 }  // namespace llcomp_mi

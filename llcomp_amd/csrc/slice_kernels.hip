@@ -222,6 +222,23 @@ __device__ __forceinline__ void fetch_rest(Entries& E, const uint32_t* bank, con
 // the entry of the successor that half-entry `nx` names: its LDS address sits in the upper half (load_table)
 __device__ __forceinline__ entry_t entry_at(const entry_t*, uint32_t nx) { return lds_entry(nx >> 16); }
 
+// Event counters (llcomp_mi_codec_get_counters; kernels.hpp kCtr*): a lane counts in a register, the wavefront adds the sum of its
+// active lanes with ONE atomic -- and only when some lane has something to report (replays and carry-backs are rare).  Convergent
+// v_readlane sum over the lanes that are active here, as for the group sums below.
+__device__ __forceinline__ void publish_count(unsigned long long* counters, uint32_t which, uint32_t mine) {
+    if (!counters) return;
+    unsigned long long live = __ballot(mine != 0);
+    if (live == 0) return;
+    unsigned long long sum = 0;
+    const unsigned long long all = __ballot(1);
+    while (live) {
+        const int lane = __builtin_ctzll(live);
+        sum += uint32_t(__builtin_amdgcn_readlane(mine, lane));
+        live &= live - 1;
+    }
+    if (threadIdx.x == uint32_t(__builtin_ctzll(all))) atomicAdd(counters + which, sum);
+}
+
 // ================================================ ENCODER ========================================================
 // Range encoder of one lane (llcomp.hpp:33-89).  Output bytes are staged in a per-lane 32-byte LDS area and leave for
 // HBM as aligned 16-byte stores.
@@ -250,6 +267,7 @@ struct RangeEnc {
     uint32_t ostep;   //     2-cycle add per flush instead of 64-bit address arithmetic (ostep = 16 << lane_shift, a vector value)
     int32_t cap;
     uint32_t shift;   // lane_shift
+    uint32_t carries; // event counter: carries that went on into bytes already stored to HBM (kCtrEncCarryBacks)
 };
 // Staging area: 32 bytes per lane, filled LINEARLY -- the renormalisation stores its byte at `wp` and adds one, no index
 // arithmetic (round 2 kept a ring and paid a v_and_or per renormalisation, which the wavefront executes for every bin
@@ -287,6 +305,7 @@ __device__ __forceinline__ void enc_carry_back(RangeEnc& e) {
             r = uint8_t(v + 1);
         } else if (k < e.cap) {
             uint8_t* g = unit_byte(e, uint32_t(k));
+            if (k == e.flushed - 1) ++e.carries;  // the carry leaves the staging area
             v = *g;
             *g = uint8_t(v + 1);
         } else {
@@ -462,6 +481,7 @@ constexpr uint32_t kRowsEncTabOff = 0, kRowsEncStageOff = 1024, kRowsEncBankOff 
 constexpr uint32_t kRowsEncLdsBytes = kRowsEncBankOff + 3 * 64 * 8;
 // rare: a carry that the block could not finish inside the staging area goes on into the bytes already stored to HBM
 [[maybe_unused]] __device__ __forceinline__ void enc_carry_back_flushed(RangeEnc& e) {
+    if (e.flushed > 0 && e.flushed - 1 < e.cap) ++e.carries;
     for (int32_t k = e.flushed - 1; k >= 0; --k) {
         if (k >= e.cap) break;  // beyond the scratch capacity: the slice is reported as overflowed anyway
         uint8_t* g = unit_byte(e, uint32_t(k));
@@ -484,7 +504,8 @@ template <int NCH, bool ROWS, typename SYM, bool LDSTAB = false, bool SNAP = fal
 __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const uint32_t lpw,
                                                       const SYM* __restrict__ sym, uint64_t* __restrict__ states,
                                                       uint8_t* __restrict__ scratch, uint32_t* __restrict__ slice_len,
-                                                      uint64_t* __restrict__ group_sum, uint32_t* status, const uint64_t gpat) {
+                                                      uint64_t* __restrict__ group_sum, uint32_t* status, const uint64_t gpat,
+                                                      unsigned long long* __restrict__ counters) {
     static_assert(!(SNAP && (ROWS || LDSTAB)), "one kernel family at a time");
     constexpr bool ASM = (ROWS || SNAP) && LLMI_ASM_ENC != 0;
     entry_t* tab;
@@ -529,6 +550,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     asm volatile("" : "+v"(e.ostep));
     e.cap = int32_t(g.slice_cap);
     e.shift = g.lane_shift;
+    e.carries = 0;
     const uint32_t n_row = r.sw * (NCH ? uint32_t(NCH) : g.nch);  // samples per slice row (NCH == 0: any channel count)
     // symbols in lane order: sample k of this slice is p0[k * GW]; the lanes of a group read one contiguous piece
     const SYM* p0 = sym + lane_order_index(g, id, 0);
@@ -744,6 +766,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
         n_bytes = e.cap;
     }
     slice_len[id] = uint32_t(n_bytes);
+    publish_count(counters, kCtrEncCarryBacks, e.carries);
     // When a wavefront holds exactly one lane group (the normal case) it leaves the group's byte count behind: the
     // global scan then runs over one value per group instead of one per slice.  The sum is formed with v_readlane over
     // the lanes that are active HERE (a convergent operation with a defined result per lane: no shared-memory hand-off
@@ -800,6 +823,7 @@ struct RangeDec {
     uint32_t step;          // 4 << lane_shift (a vector value: an add with a scalar operand costs twice as much)
     uint32_t ofs_end;       // offset of the first dword AFTER the stream; the stager guarantees it (and every byte past the
                             // end of the stream inside the last dword) reads zero, as llcomp.hpp:475-479 wants
+    uint32_t replays;       // event counter: samples that went through rollback + checked replay (kCtrDecReplays)
 };
 __device__ __forceinline__ bool window_low(const RangeDec& d) { return uint32_t(d.win >> 32) == 0; }  // <= 3 bytes
 // issues the load of dword k.  UNCONDITIONAL (index clamped to the zero dword behind the stream) so that its result
@@ -844,6 +868,7 @@ __device__ __forceinline__ void dec_open(RangeDec& d, const uint32_t* group, uin
     d.range = 0xFF00;  // llcomp.hpp:93-96: low = first two bytes
     d.low = ((first & 0xFF) << 8) | ((first >> 8) & 0xFF);
     d.win = (both >> 16) | (1ull << 48);  // six bytes left
+    d.replays = 0;
 }
 // CHECKED == false is the fast path: it never looks at the fill level of the window.  The kernel tops the window up to
 // >= 4 bytes before every sample and afterwards looks at it once: an empty window (the sentinel is gone) means the
@@ -1013,6 +1038,7 @@ __device__ __forceinline__ bool dec_sample(RangeDec& d, Bank& bank, const entry_
     // (hipcc's fast path signals a sample that ran out of window bytes by an empty window; the block signals it through `ok`)
     const bool ran_dry = (INLDS && LLMI_ASM_DEC != 0) ? false : d.win == 0;
     if (__builtin_expect(!ok || ran_dry || replay_always, 0)) {
+        ++d.replays;
         d.low = s_low; d.range = s_range; d.win = s_win;
         bank.w[0] = s_b0; bank.w[1] = s_b1;
         if constexpr (INLDS) {  // the fast path has already stored new states: put the old ones back
@@ -1033,15 +1059,16 @@ __device__ __forceinline__ bool dec_sample(RangeDec& d, Bank& bank, const entry_
 // sector write in HBM; a miss fills, and writes the victim back behind the sample.  Nothing is flushed at the end: the table is
 // per call (generation tags), whatever stays in LDS is not needed again.  32 entries = 18 KB per wavefront = eight wavefronts per
 // CU; 64 entries (four per CU) were measured slower whenever a launch has more than 1024 wavefronts and 1-3 % faster below
-// (profiles/r05_bank_cache_ab.txt).  0 = no cache.
-constexpr int kBankCacheLog2 = 5;
+// (profiles/r05_bank_cache_ab.txt).  0 = no cache.  The entry count is geometry.hpp's kBankCacheLog2 (one constant for the flag, the
+// launcher and the kernel).
 constexpr uint32_t bank_cache_lds_bytes(int log2_entries) { return log2_entries ? (64u * 9u) << log2_entries : 0u; }
 template <int NCH, bool ROWS, bool LDSTAB = false, int CACHE = 0>
 __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const uint32_t lpw_and_flags,
                                                       const uint8_t* __restrict__ units,
                                                       const uint32_t* __restrict__ slice_len,
                                                       uint64_t* __restrict__ states, int16_t* __restrict__ rec,
-                                                      uint32_t* status, const uint64_t gpat) {
+                                                      uint32_t* status, const uint64_t gpat,
+                                                      unsigned long long* __restrict__ counters) {
     __shared__ entry_t tab[128];  // (entries carry absolute LDS addresses, load_table: the hand-written loop needs no base)
     __shared__ uint32_t rowbank[ROWS ? kWideBankWords : 1];
     // quant11 / quant5 as byte tables over the clamped difference (llcomp.hpp:297-341 has them as tables too): five look-ups that
@@ -1054,10 +1081,15 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
         }
     }
     static_assert(CACHE == 0 || (!ROWS && !LDSTAB && NCH != 0), "the bank cache belongs to the 2-D kernels with tables in HBM");
+    // tags are bytes holding context >> CACHE, 0xFF = empty: no real tag may reach 0xFF
+    static_assert(CACHE == 0 || ((kContexts - 1) >> CACHE) < 0xFF, "bank cache: a context's tag would alias the empty marker");
+    // the wavefront's misses / look-ups since the last bypass check (CACHE): lanes add theirs, every lane reads the sums
+    __shared__ uint32_t wave_sums[CACHE != 0 ? 2 : 1];
     clear_lds_states<LDSTAB>();
     if constexpr (CACHE != 0) {  // every entry empty
         uint32_t* tg = reinterpret_cast<uint32_t*>(dyn_lds + (512u << CACHE));
         for (uint32_t i = threadIdx.x; i < (16u << CACHE); i += blockDim.x) tg[i] = 0xFFFFFFFFu;
+        if (threadIdx.x < 2) wave_sums[threadIdx.x] = 0;
     }
     load_table(tab);
     const uint32_t lpw = lpw_and_flags & 0xFF;
@@ -1143,6 +1175,7 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
         for (; x < r.sw; ++x) pixel();
         if (bad) atomicOr(status, kStBadExponent);
         asm volatile("global_store_short %0, %1, %2" : : "v"(held_ofs), "v"(held_val), "s"(gbase) : "memory");
+        publish_count(counters, kCtrDecReplays, d.replays);
     } else {
         // Neighbours of the row above rotate through registers (tl <- t <- tr); the two values the NEXT pixel needs
         // from memory (top-right, top-top) are loaded while the current one decodes.
@@ -1190,18 +1223,31 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
         uint64_t held_bank = 0;
         [[maybe_unused]] uint64_t wb_bank = 0;       // CACHE: the victim of this sample's miss, written back behind the decoding
         [[maybe_unused]] uint64_t* wb_ptr = nullptr;
-        // CACHE: wave-uniform.  Every four rows from row 8 on the wavefront looks at the hit rate of the last four; content whose
-        // contexts do not come back soon enough (a dithered gradient: 1600 contexts in a 64x64 slice, 4 % hits behind the first
-        // rows) pays for the cache path without saving a transaction -- the entries are written back once and the rest of the
-        // slices runs on the plain path.  (profiles/r05_bank_cache_ab.txt)
+        // CACHE: every four rows from row 8 on the wavefront looks at the hit rate of the last four; content whose contexts do not
+        // come back soon enough (a dithered gradient: 1600 contexts in a 64x64 slice, 4 % hits behind the first rows) pays for the
+        // cache path without saving a transaction -- the entries are written back once and the rest of the slices runs on the plain
+        // path (profiles/r05_bank_cache_ab.txt).  Every lane counts ITS misses and look-ups (the lanes of a ragged wavefront leave a
+        // row at different x, so a count kept "per wavefront" inside the sample loop is not one); at the check the lanes add them up
+        // in LDS and all read the same two sums: the decision is wave-uniform by construction.  The same per-lane totals feed the
+        // event counters at the end (kCtrCache*); the host takes the cache away from a codec whose wavefronts all give it up
+        // (codec.hip: the plain kernel holds no LDS for it).
         [[maybe_unused]] bool use_cache = CACHE != 0;
-        [[maybe_unused]] uint32_t n_miss = 0, n_seen = 0;
+        [[maybe_unused]] uint32_t my_miss = 0, my_lookups = 0, my_wb = 0, miss_mark = 0, look_mark = 0;
         LLMI_PARTS_DECL();
         LLMI_PARTS_START();
         for (uint32_t y = 0; y < r.sh; ++y) {
             if constexpr (CACHE != 0) {
                 const uint32_t yu = __builtin_amdgcn_readfirstlane(y);
-                if (use_cache && yu >= 4 && (yu & 3) == 0) {  // (the counters start over at row 4: the first rows hit more than the rest)
+                if (use_cache && yu >= 4 && (yu & 3) == 0) {  // (the counts start over at row 4: the first rows hit more than the rest)
+                    __hip_atomic_fetch_add(&wave_sums[0], my_miss - miss_mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&wave_sums[1], my_lookups - look_mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    miss_mark = my_miss;
+                    look_mark = my_lookups;
+                    // (one wavefront per block: its LDS operations execute in program order, the adds of all lanes before the loads)
+                    const uint32_t n_miss = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&wave_sums[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    const uint32_t n_seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&wave_sums[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    __hip_atomic_store(&wave_sums[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&wave_sums[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (yu >= 8 && n_miss * 8 > n_seen * 7) {  // fewer than 1 hit in 8 over the last four rows
                         const uint64_t* c_banks = reinterpret_cast<const uint64_t*>(dyn_lds) + threadIdx.x;
                         const uint8_t* c_tags = dyn_lds + (512u << CACHE) + threadIdx.x;
@@ -1213,8 +1259,8 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                         use_cache = false;
                         held_ctx = ~0u;
                     }
-                    n_miss = n_seen = 0;
                 }
+                if (use_cache) my_lookups += r.sw * NCH;  // (this row's; a lane that leaves on a bad exponent loses a row of them)
             }
             int16_t* row = p0 + ptrdiff_t(y) * up;
             int l[NCH], L[NCH], t[NCH], tl[NCH], tr[NCH], T[NCH];
@@ -1260,12 +1306,12 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
                         uint8_t* c_tag = dyn_lds + (512u << CACHE) + entry * 64 + threadIdx.x;
                         const uint32_t have = *c_tag;
                         held_bank = *c_bank;
-                        n_miss += uint32_t(__popcll(__builtin_amdgcn_ballot_w64(have != want)));
-                        n_seen += uint32_t(__popcll(__builtin_amdgcn_ballot_w64(true)));
                         if (have != want) {
+                            ++my_miss;
                             // (the victim leaves only behind this sample's decoding: a store issued here would sit in the
                             // queue in front of the fill, and the fill's data come back in order behind it)
                             if (have != 0xFFu) {
+                                ++my_wb;
                                 wb_bank = bank_tagged<false>(held_bank, gpat);
                                 wb_ptr = banks + (size_t((have << CACHE) | entry) << bsh);
                             }
@@ -1323,6 +1369,17 @@ __global__ __launch_bounds__(64) void k_decode_slices(const Geometry g, const ui
             }
         }
         LLMI_PARTS_FLUSH();
+        if constexpr (CACHE != 0) {  // event counters of the cached decoder: one atomic each per wavefront
+            publish_count(counters, kCtrCacheLookups, my_lookups);
+            publish_count(counters, kCtrCacheMisses, my_miss);
+            publish_count(counters, kCtrCacheWritebacks, my_wb);
+            const unsigned long long live = __ballot(1), gave_up = __ballot(!use_cache);
+            if (counters && threadIdx.x == uint32_t(__builtin_ctzll(live))) {
+                atomicAdd(counters + kCtrDecCachedWaves, 1ull);
+                if (gave_up) atomicAdd(counters + kCtrDecBypassedWaves, 1ull);
+            }
+        }
+        publish_count(counters, kCtrDecReplays, d.replays);
         }
     }
     LLMI_PROBE_STOP(1);
@@ -1391,19 +1448,20 @@ uint64_t state_generation_tag(uint32_t generation) {
 }
 
 hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* d_states, uint32_t generation, uint8_t* d_scratch,
-                                uint32_t* d_slice_len, uint64_t* d_group_off, uint32_t* d_status, hipStream_t stream) {
+                                uint32_t* d_slice_len, uint64_t* d_group_off, uint32_t* d_status, unsigned long long* d_counters,
+                                hipStream_t stream) {
     const uint64_t gpat = slices_need_state_tables(g) ? state_generation_tag(generation) : 0;
     const uint32_t lpw = g.lpw;
     const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
     uint64_t* const d_group_sum = encoder_writes_group_sums(g) ? d_group_off : nullptr;
     if (model_is_fused(g)) {  // planar 1-row slices: 16-bit symbols, always the ROWS kernel
         k_encode_slices<1, true, uint16_t><<<dim3(blocks), dim3(64), LLMI_ASM_ENC ? kRowsEncLdsBytes : 0, stream>>>(
-            g, lpw, static_cast<const uint16_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status, gpat);
+            g, lpw, static_cast<const uint16_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status, gpat, d_counters);
         return hipGetLastError();
     }
     if (g.flags & kGeoSnapshot) {  // d_sym: residuals, d_states: banks before each sample (launch_snapshot), both in piece layout
         k_encode_slices<0, false, uint32_t, false, true><<<dim3(blocks), dim3(64), LLMI_ASM_ENC ? kRowsEncLdsBytes : 0, stream>>>(
-            g, lpw, static_cast<const uint32_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status, 0);
+            g, lpw, static_cast<const uint32_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status, 0, d_counters);
         return hipGetLastError();
     }
     const bool lds = states_in_lds(g);
@@ -1414,22 +1472,25 @@ hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* 
             if (e != hipSuccess) return e;
         }
         kernel<<<dim3(blocks), dim3(64), T ? kLdsTableBytes : (R && LLMI_ASM_ENC ? kRowsEncLdsBytes : 0), stream>>>(
-            g, lpw, static_cast<const uint32_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status, gpat);
+            g, lpw, static_cast<const uint32_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status, gpat, d_counters);
     });
     return hipGetLastError();
 }
 
 hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_units, const uint32_t* d_slice_len,
-                                uint64_t* d_states, uint32_t generation, int16_t* d_rec, uint32_t* d_status, hipStream_t stream) {
+                                uint64_t* d_states, uint32_t generation, int16_t* d_rec, uint32_t* d_status, unsigned long long* d_counters,
+                                bool bank_cache, hipStream_t stream) {
     const uint64_t gpat = slices_need_state_tables(g) ? state_generation_tag(generation) : 0;
     const uint32_t lpw = g.lpw;
     const uint32_t blocks = (g.n_slices + lpw - 1) / lpw;
     const uint32_t arg = lpw | ((g.flags & kGeoForceReplay) ? 0x100u : 0u);  // tests: rollback + checked replay everywhere
     const bool lds = states_in_lds(g);
-    if (bank_cache_log2(g) == kBankCacheLog2) {  // 2-D slices, tables in HBM, 1..4 channels: per-lane bank cache in LDS
+    // 2-D slices, tables in HBM, 1..4 channels: per-lane bank cache in LDS -- unless the caller takes it away for this launch (codec.hip:
+    // a codec whose wavefronts all gave the cache up last time runs the plain kernel, which holds no LDS for it)
+    if (bank_cache_log2(g) == kBankCacheLog2 && bank_cache) {
 #define LLMI_DECODE_CACHED(NCHV)                                                                                          \
     k_decode_slices<NCHV, false, false, kBankCacheLog2><<<dim3(blocks), dim3(64), bank_cache_lds_bytes(kBankCacheLog2), stream>>>( \
-        g, arg, d_units, d_slice_len, d_states, d_rec, d_status, gpat)
+        g, arg, d_units, d_slice_len, d_states, d_rec, d_status, gpat, d_counters)
         switch (g.nch) {
             case 1: LLMI_DECODE_CACHED(1); break;
             case 2: LLMI_DECODE_CACHED(2); break;
@@ -1447,7 +1508,7 @@ hipError_t launch_decode_slices(const Geometry& g, const uint8_t* d_units, const
             if (e != hipSuccess) return e;
         }
         kernel<<<dim3(blocks), dim3(64), T ? kLdsTableBytes : 0, stream>>>(g, arg, d_units, d_slice_len, d_states,
-                                                                          d_rec, d_status, gpat);
+                                                                          d_rec, d_status, gpat, d_counters);
     });
     return hipGetLastError();
 }

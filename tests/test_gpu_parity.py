@@ -243,8 +243,8 @@ def test_empty_and_mismatched_inputs_are_rejected(mi):
 
 def test_opts_struct_of_another_abi_is_refused(mi, orc):
     """One struct layout per ABI version (llcomp_mi.h): llcomp_mi_opts is checked through struct_size and a caller built
-    against another header -- ABI 1 had no small_model field and passed 24 -- is refused instead of being half-read; the
-    binding checks llcomp_mi_abi_version() when it loads the library."""
+    against another header -- ABI 1 had no small_model field and passed 24, ABI 2 / 3 had no device list and passed 28 -- is refused
+    instead of being half-read; the binding checks llcomp_mi_abi_version() when it loads the library."""
     import ctypes as C
 
     from llcomp_amd import _lib
@@ -257,10 +257,10 @@ def test_opts_struct_of_another_abi_is_refused(mi, orc):
     L = _lib.load()
     assert L.llcomp_mi_abi_version() == _lib.ABI_VERSION
     out, n = _lib.u8p(), C.c_size_t()
-    for size in (24, 20, 32):
+    for size in (24, 20, 32, 28):
         o = Opts1(size, mi.FORMAT_SLICED, 16, 1, 1, -1, 0)
         assert L.llcomp_mi_encode(img.ctypes.data_as(_lib.u8p), 50, 20, 3, C.cast(C.byref(o), C.POINTER(_lib.Opts)), C.byref(out), C.byref(n)) == mi.BAD_ARGS
-    o = Opts1(C.sizeof(_lib.Opts), mi.FORMAT_SLICED, 16, 1, 1, -1, 0)
+    o = _lib.Opts(C.sizeof(_lib.Opts), mi.FORMAT_SLICED, 16, 1, 1, -1, 0, 0, None, 0, 0)
     assert L.llcomp_mi_encode(img.ctypes.data_as(_lib.u8p), 50, 20, 3, C.cast(C.byref(o), C.POINTER(_lib.Opts)), C.byref(out), C.byref(n)) == mi.OK
     try:
         assert C.string_at(out, n.value) == orc.compress_sliced(img, 16, 1, True)
