@@ -230,8 +230,10 @@ def measure(frames_np, tile_w, tile_h, planar, streams, steps, warmup, local_ran
     if barrier:
         barrier()
     dt = time.perf_counter() - t0
-    prof, n_enc, n_dec = {}, 0, 0
+    prof, n_enc, n_dec, counters = {}, 0, 0, {}
     for p in parts:
+        for k, v in p["codec"].counters().items():  # what the adaptive / rare paths did since the codec was made (llcomp_mi_codec_get_counters)
+            counters[k] = counters.get(k, 0) + v
         pr, ne, nd = p["codec"].get_profile()
         p["codec"].set_profiling(False)
         for k, v in pr.items():
@@ -262,7 +264,7 @@ def measure(frames_np, tile_w, tile_h, planar, streams, steps, warmup, local_ran
     torch.cuda.empty_cache()
     container_bytes = total + 24 * F + 4 * n_slices  # per-frame container headers + slice tables
     return dict(dt=dt, steps=steps, F=F, S=S, w=w, h=h, c=c, n_slices=n_slices, payload=total, container_bytes=container_bytes,
-                raw_bytes=int(frames_np.size), prof=prof, step_ms=step_ms, frame0_container=frame0_container, frame0_fnv=frame0_fnv, n_enc=n_enc, n_dec=n_dec, iso=iso, iso_enc=iso_enc, iso_dec=iso_dec,
+                raw_bytes=int(frames_np.size), prof=prof, counters=counters, step_ms=step_ms, frame0_container=frame0_container, frame0_fnv=frame0_fnv, n_enc=n_enc, n_dec=n_dec, iso=iso, iso_enc=iso_enc, iso_dec=iso_dec,
                 mpix=F * w * h * steps / dt / 1e6, ratio=frames_np.size / container_bytes)
 
 
@@ -277,6 +279,18 @@ def brief(m, **extra):
                   "ms_per_step_min_max": [round(ms[0], 3), round(ms[-1], 3)], "value_min_max": [round(pix / (ms[-1] * 1e-3), 1), round(pix / (ms[0] * 1e-3), 1)]})
     d.update(extra)
     return d
+
+
+def cache_counters(m):
+    """the 2-D decoder's bank cache over all calls of the leg (warm-up included), from the codec objects' event counters"""
+    c = m.get("counters") or {}
+    if not c.get("dec_launches_cached") and not c.get("dec_launches_plain"):
+        return {}
+    out = {"decode_launches_with_cache": c["dec_launches_cached"], "decode_launches_plain_by_feedback": c["dec_launches_plain"],
+           "wavefronts_that_gave_the_cache_up": round(c["dec_bypassed_waves"] / max(1, c["dec_cached_waves"]), 4)}
+    if c.get("cache_lookups"):
+        out["hit_rate_while_cached"] = round(1 - c["cache_misses"] / c["cache_lookups"], 4)
+    return {"bank_cache": out}
 
 
 def tile_sides(m):
@@ -998,7 +1012,7 @@ def main():
                     also[f"{content}_tiles64x64_{frames}frames"] = brief(
                         m2, workload=f"{frames} frames 4K {content}, 64x64 planar tiles, {streams} pipelines; encoder: state snapshot pass + sequential coder (no state "
                                      f"table), decoder: per-slice state tables in HBM (generation-tagged)",
-                        samples_per_s=round(samples / m2["dt"] / 1e9, 2), **tile_sides(m2), **extra,
+                        samples_per_s=round(samples / m2["dt"] / 1e9, 2), **tile_sides(m2), **cache_counters(m2), **extra,
                         note="the decoder is bound by random state-bank transactions (the next context needs the sample just decoded), cut by a per-lane bank "
                              "cache in LDS; the encoder knows every context in advance and streams its states")
 

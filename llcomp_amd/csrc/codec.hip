@@ -140,7 +140,7 @@ bool use_bank_cache(llcomp_mi_codec* k) {
         const uint64_t waves = k->h_feedback[0] - k->fb_seen[0], gave_up = k->h_feedback[1] - k->fb_seen[1];
         k->fb_seen[0] = k->h_feedback[0];
         k->fb_seen[1] = k->h_feedback[1];
-        if (waves && gave_up * 16 >= waves * 15) k->plain_calls_left = llcomp_mi_codec::kPlainRun;
+        if (k->feedback && waves && gave_up * 16 >= waves * 15) k->plain_calls_left = llcomp_mi_codec::kPlainRun;
     } else {
         (void)hipGetLastError();
     }
@@ -278,6 +278,7 @@ int llcomp_mi_codec_create_ex(llcomp_mi_codec** out, int32_t device, uint32_t fr
     if (!k) return LLCOMP_MI_NOMEM;
     k->g = g;
     k->device = dev;
+    k->feedback = !current_tuning().nofeedback;
     const uint64_t samples = uint64_t(frames) * w * h * c;
     k->need_states = slices_need_state_tables(g);
     // the fused row path (planar 1-row slices) has no image-order intermediate and 16-bit lane-order arrays in both directions

@@ -46,6 +46,7 @@ struct llcomp_mi_codec {
     bool fb_pending = false;           // a mailbox copy has been queued and not looked at yet
     uint64_t fb_seen[2] = {0, 0};      // the mailbox's values at the last look
     uint32_t plain_calls_left = 0;     // > 0: this many decode calls run without the bank cache
+    bool feedback = true;              // (LLCOMP_MI_NOFEEDBACK=1 when the codec was made: the cache stays on in every launch)
     static constexpr uint32_t kPlainRun = 15;
     bool need_states = true;  // false when the states live in LDS (1-row slices; one slice per wavefront)
     uint32_t state_generation = 0;  // tag of the last call that used d_states (kernels.hpp); 0 = the table has not been cleared yet

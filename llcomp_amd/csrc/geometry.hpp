@@ -53,6 +53,7 @@ struct Tuning {
     bool force_replay = false; // LLCOMP_MI_FORCE_REPLAY=1
     bool nosnap = false;       // LLCOMP_MI_NOSNAP=1: the 2-D encoder keeps its state tables in HBM (the path before round 4)
     bool nocache = false;      // LLCOMP_MI_NOCACHE=1: the 2-D decoder fetches and writes every state bank in HBM (the path before round 5)
+    bool nofeedback = false;   // LLCOMP_MI_NOFEEDBACK=1: the bank cache stays on in every launch, whatever the last one's wavefronts did with it (A/B)
 };
 inline Tuning tuning_from_env() {
     Tuning t;
@@ -70,6 +71,7 @@ inline Tuning tuning_from_env() {
     t.force_replay = flag("LLCOMP_MI_FORCE_REPLAY");
     t.nosnap = flag("LLCOMP_MI_NOSNAP");
     t.nocache = flag("LLCOMP_MI_NOCACHE");
+    t.nofeedback = flag("LLCOMP_MI_NOFEEDBACK");
     return t;
 }
 
