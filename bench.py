@@ -23,8 +23,17 @@ scaling: a fixed batch of 8192x8192 RGB8 images, every image sharded over all ra
 is gathered on rank b % N), device concatenator -> complete containers spread over the ranks; decode mirrors it; the
 exchange is inside the timed region and container 0 is compared with the one-piece container.  Its one-GPU point is
 measured in the same run (rank 0 codes the same batch through a one-rank subgroup first): `one_gpu_value`,
-`scaling_vs_one_gpu`, `ranks_seen`.  `c5_replica_pcie` = config 5 in replica mode.  The secondary legs sit behind a
+`scaling_vs_one_gpu`, `ranks_seen`.  `c5_replica_pcie` = config 5 in replica mode.  `c4_inprocess_devices` = config 4 from ONE
+process through the C ABI's device list (llcomp_mi_opts.devices / llcomp_mi_decode_into_devices, host buffers in, host buffers out):
+rank 0 alone drives all N GPUs while the other ranks wait on the store (no collective, N PCIe links).  The secondary legs sit behind a
 watchdog: if one of them fails or hangs, the line still goes out with the headline and says which leg was lost.
+
+Key order of the line: the full-model figures (`full_model`, then `value_full_model`) are the LAST keys, behind `also` and the CPU
+legs, so that a record which keeps only the tail of the line still shows the real-model number.
+
+LLCOMP_BENCH_STANDIN=<module> (tests/test_bench_world8.py only): the named module -- it lives under tests/, nothing of it is in the
+product path -- replaces the GPU coders by CPU stand-ins and the backend by gloo, so that the N > 1 BOOKKEEPING of this file (rank
+layout, reductions, the legs' keys) can run at world size 8 where there is no GPU.  The numbers of such a run mean nothing.
 """
 import argparse
 import json
@@ -49,6 +58,25 @@ RMW_UBENCH = 24.06e9       # uniformly random dependent 8-byte read-modify-write
 TILE_HBM_SOURCE = "profiles/r05_tiles64_f16_{g3,nat}_pmc_summary.txt (KiB counters x 1024)"
 TILE_HBM_BYTES_PER_SAMPLE = {"g3": {"k_encode_slices": 12.9, "encode_all_kernels": 64.1, "k_decode_slices": 98.7, "decode_all_kernels": 108.9},
                              "nat": {"k_encode_slices": 10.7, "encode_all_kernels": 59.1, "k_decode_slices": 120.6, "decode_all_kernels": 128.4}}
+
+
+class Hooks:
+    """what the N > 1 branch calls; a stand-in module named by LLCOMP_BENCH_STANDIN (tests only) replaces the members"""
+    standin = None           # the module, when there is one
+    device = "cuda"          # where the reduction tensors live
+    backend = "nccl"
+    measure = None           # filled in below (the functions of this file)
+    c5_stream = None
+    band_factory = None      # sharding.ShardedCodec's local coder: None = the HIP codec object
+    one_piece = None         # (img, w, h, tile_w, tile_h) -> container bytes, for c4_run's check
+    inprocess = None         # c4_inprocess
+
+    @staticmethod
+    def sync():
+        if Hooks.device == "cuda":
+            import torch
+
+            torch.cuda.synchronize()
 
 
 def make_frames(content, frames, rank, w=W4K, h=H4K, c=C4K, distinct=None):
@@ -305,7 +333,7 @@ def tile_sides(m):
 def profile_numbers(F, tile_w, tile_h, planar, content, S, dom):
     """HBM-side bytes and VALU instructions per launch of kernel `dom` from the committed rocprofv3 PMC passes of THIS
     configuration (profiles/*_traffic.json); (None, None, None) when no committed profile matches."""
-    for name in ("r05_default_traffic.json", "r05_single_stream_traffic.json", "r04_default_traffic.json", "r04_single_stream_traffic.json", "r03_default_traffic.json", "r03_single_stream_traffic.json",
+    for name in ("r06_default_traffic.json", "r06_full_model_traffic.json", "r06_single_stream_traffic.json", "r05_default_traffic.json", "r05_single_stream_traffic.json", "r04_default_traffic.json", "r04_single_stream_traffic.json", "r03_default_traffic.json", "r03_single_stream_traffic.json",
                  "r02_default_traffic.json", "r02_single_stream_traffic.json", "r01_default_traffic.json", "r01_single_stream_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -458,22 +486,31 @@ def c5_stream(frames_np, tile_w, tile_h, planar, depth=6, frames_per_job=8, pipe
 
 
 def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank, check_one_piece=True, parts=0, group=None, height=None):
+    """(see below; device-agnostic where it matters: under LLCOMP_BENCH_STANDIN the tensors are CPU tensors and there are no HIP streams)"""
+    return _c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank, check_one_piece, parts, group, height)
+
+
+def _c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank, check_one_piece, parts, group, height):
     """BASELINE config 4: `images` noise images of size x size RGB8, each sharded over all ranks; encode (+ exchange of the
     bitstream) and decode (+ exchange back) per step.  The batch is coded as up to three part batches on as many HIP streams
     (a ShardedCodec each) so that the exchange of one part overlaps the coding of the others.  Returns the max-over-ranks wall time."""
     import torch
     import torch.distributed as dist
 
+    import contextlib
+
     import llcomp_amd as mi
     from llcomp_amd import sharding
 
-    dev = torch.device("cuda", local_rank)
+    cuda = Hooks.device == "cuda"
+    dev = torch.device("cuda", local_rank) if cuda else torch.device("cpu")
+    sync = Hooks.sync
     height = height or size  # (tools/attic/c4_overhead.py codes bands of the config-4 image: one rank's share at N > 1, on one GPU)
     # 3, 2 or 1 part batches (measured on one GPU: 2, 3 and 6 parts all take 82 ms per step), each spreading its containers evenly over the ranks
     halves = next(p for p in ((parts,) if parts else ()) + (3, 2, 1) if images % p == 0 and (images // p) % world == 0 or p == 1)
     per = images // halves
-    scs = [sharding.ShardedCodec(size, height, 3, tile_w, tile_h, True, images=per, device=dev, group=group) for _ in range(halves)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(halves)]
+    scs = [sharding.ShardedCodec(size, height, 3, tile_w, tile_h, True, images=per, device=dev, group=group, band_factory=Hooks.band_factory) for _ in range(halves)]
+    streams = [torch.cuda.Stream(device=dev) if cuda else None for _ in range(halves)]
     # uniform byte noise (torch Philox, seed 1234 + image): every rank draws the full image on its GPU and keeps its rows
     bands, first = [], None
     for k, sc in enumerate(scs):
@@ -489,7 +526,7 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
             del full
         bands.append(torch.cat([rows[j] for j in sc.frame_images], dim=0).contiguous())  # frames in the codec's order
         del rows
-    torch.cuda.synchronize()
+    sync()
 
     def step():
         """software pipeline over the parts: while the host waits for one part's sizes (the exchange needs them) the GPU
@@ -498,7 +535,7 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
         conts, outs = [None] * halves, [None] * halves
 
         def on(k, fn, *a, **kw):
-            with torch.cuda.stream(streams[k]):
+            with (torch.cuda.stream(streams[k]) if cuda else contextlib.nullcontext()):
                 return fn(*a, **kw)
 
         if os.environ.get("LLCOMP_BENCH_C4_ORDER", "one-ahead") == "deep":
@@ -524,18 +561,19 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
         # every part has drained its own stream by now (decode_finish reads its status); the device-wide wait costs
         # microseconds and keeps steps from interleaving in the runtime's queues (without it some runs of this leg took
         # twice as long per step, with identical kernels and allocator statistics)
-        torch.cuda.synchronize()
+        sync()
         return conts, outs
 
     conts, outs = step()
-    torch.cuda.synchronize()
+    sync()
     for k in range(halves):
         assert torch.equal(outs[k], bands[k]), "sharded round trip is not lossless"
     pb = torch.tensor([sum(int(c_.numel()) for cs in conts for c_ in cs.values())], dtype=torch.int64, device=dev)
     dist.all_reduce(pb, op=dist.ReduceOp.SUM, group=group)
     payload_bytes = int(pb.item())
     if first is not None:
-        one = mi.compress_image(first, size, height, 3, format=mi.FORMAT_SLICED, tile_w=tile_w, tile_h=tile_h, planar=True, device=local_rank)
+        one = Hooks.one_piece(first, size, height, tile_w, tile_h) if Hooks.one_piece else \
+            mi.compress_image(first, size, height, 3, format=mi.FORMAT_SLICED, tile_w=tile_w, tile_h=tile_h, planar=True, device=local_rank)
         assert bytes(conts[0][0].cpu().numpy()) == one, "sharded container differs from the one-piece container"
     # At least three more untimed passes, bound exactly like the timed ones (the results of pass i stay alive while pass
     # i + 1 runs): that is when torch's allocator takes its last segments from the driver.  With the results dropped at
@@ -543,20 +581,20 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     # step of four at 340 ms beside three at 80 ms.
     for _ in range(max(3, warmup - 1)):
         conts, outs = step()
-    torch.cuda.synchronize()
+    sync()
     # N = 1 only (an `also` leg there; at N > 1 this IS the timed headline and carries no instrumentation)
     codecs = [sc.band.codec for sc in scs if getattr(sc.band, "codec", None) is not None] if world == 1 else []
     for cd in codecs:  # hipEvent spans of the local coding kernels, so that a slow step can be told from a slow exchange
         cd.set_profiling(True)
         cd.get_profile()
     dist.barrier(group=group)
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     marks = []
     for _ in range(steps):
         conts, outs = step()
         marks.append(time.perf_counter())
-    torch.cuda.synchronize()
+    sync()
     dist.barrier(group=group)
     dt = time.perf_counter() - t0
     spans = {}
@@ -580,8 +618,96 @@ def c4_run(images, size, tile_w, tile_h, steps, warmup, local_rank, world, rank,
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     del scs, bands, outs, conts
-    torch.cuda.empty_cache()
+    if cuda:
+        torch.cuda.empty_cache()
     return float(t.item()), payload_bytes
+
+
+def c4_inprocess(devices, images=4, size=8192, tile_w=512, tile_h=1, steps=2, callers=2, compare_one_device=True):
+    """BASELINE config 4 from ONE process through the C ABI's device list (csrc/multidev.hip): every image goes host buffer ->
+    llcomp_mi_encode_into(opts.devices) -> container in host memory -> llcomp_mi_decode_into_devices -> host buffer.  Each device gets
+    only its tile rows over its own PCIe link and copies its payload / its rows straight to their place: no collective, no gather.
+    `callers` threads call concurrently (the C ABI is thread-safe; a second caller's copies overlap the first one's kernels), each
+    with its own pinned buffers.  PCIe inclusive by nature -- never part of `value`.  Image 0 is the golden vector's image
+    (std::mt19937(1234)): its container must be the one assembled from the REAL reference's per-slice streams
+    (tests/golden/c4_bench_slicing.json); the other images are rotations of it."""
+    import threading
+
+    import numpy as np
+
+    import llcomp_amd as mi
+    from llcomp_amd import synth
+
+    base = synth.gen_g3(size, size, 3)
+    raw = base.size
+    kw = dict(format=mi.FORMAT_SLICED, tile_w=tile_w, tile_h=tile_h, planar=True)
+    try:
+        gold = [v for v in json.load(open(os.path.join(ROOT, "tests", "golden", "c4_bench_slicing.json")))["vectors"]
+                if (v["gen"], v["w"], v["h"], v["tile_w"], v["tile_h"], v["planar"]) == ("g3", size, size, tile_w, tile_h, True)]
+    except OSError:
+        gold = []
+    callers = max(1, min(callers, images))
+    srcs = [mi.PinnedBuffer(raw) for _ in range(images)]          # every image's pixels, pinned (plain DMA per chunk of tile rows)
+    for b_, sb in enumerate(srcs):
+        sb.array[:] = np.roll(base, 11 * b_, axis=1).reshape(-1)
+    del base
+    outs = [(mi.PinnedBuffer(2 * raw), mi.PinnedBuffer(raw)) for _ in range(callers)]  # per caller: container, decoded pixels
+    bufs = [(x,) for x in srcs] + [tuple(o) for o in outs]
+
+    def run(devs, n_steps, check):
+        """every caller codes images t, t + callers, ... n_steps times; returns (seconds, container lengths)"""
+        errs, lens = [], {}
+
+        def work(t):
+            try:
+                cont, back = outs[t]
+                for _ in range(n_steps):
+                    for b in range(t, images, callers):
+                        src = srcs[b]
+                        n = mi.compress_image_into(src.array, size, size, 3, cont.array, devices=devs, **kw)
+                        lens[b] = n
+                        if check and b == 0 and gold:
+                            assert n == gold[0]["container_len"] and mi.fnv1a64(cont.array[:n]) == gold[0]["container_fnv1a64"], \
+                                "the device-list container of image 0 differs from the reference's"
+                        mi.decompress_image_into(cont.array[:n], back.array, devices=devs)
+                        if check:
+                            assert mi._same_bytes(back.array, src.array), "device-list round trip is not lossless"
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(t,)) for t in range(callers)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        if errs:
+            raise errs[0]
+        return time.perf_counter() - t0, lens
+
+    try:
+        run(devices, 1, True)            # untimed: lanes, code objects, first touch of the pinned buffers; golden pin + lossless check
+        dt, lens = run(devices, steps, False)
+        out = {"value": round(images * steps * size * size / dt / 1e6, 1), "unit": "MPix/s", "devices": list(devices), "distinct_gpus": len(set(devices)),
+               "images_per_step": images, "steps": steps, "concurrent_callers": callers, "ms_per_image_encode_plus_decode": round(dt / (images * steps) * callers * 1e3, 2),
+               "compression_ratio": round(images * raw / sum(lens.values()), 4), "golden_pin": bool(gold),
+               "workload": f"C4 {images} x {size}x{size} RGB8 std::mt19937 noise, {tile_w}x{tile_h} planar, host buffer -> llcomp_mi_encode_into(devices) -> "
+                           f"host container -> llcomp_mi_decode_into_devices -> host buffer; {callers} concurrent callers with pinned buffers; "
+                           "PCIe inclusive (every byte crosses the link twice per direction of the round trip)"}
+        if compare_one_device:
+            one = [devices[0]]
+            run(one, 1, False)
+            dt1, _ = run(one, steps, False)
+            out["one_device_value"] = round(images * steps * size * size / dt1 / 1e6, 1)
+            out["vs_one_device"] = round(dt1 / dt, 3)
+        if len(set(devices)) < 2:
+            out["note"] = "the list repeats one ordinal: two lanes on ONE GPU -- the path's overhead on one card, not a multi-GPU number"
+        return out
+    finally:
+        for tr in bufs:
+            for b in tr:
+                b.close()
+        mi.trim()
 
 
 def spawn_ranks(n):
@@ -778,9 +904,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra one-pipeline-at-a-time launches behind the timed region (profiler runs)")
     ap.add_argument("--no-also", action="store_true", help="only the headline workload (profiler runs, sweeps)")
-    ap.add_argument("--also-only", default="", help="comma-separated subset of the `also` legs: contents,tiles,latency,legacy,c5,c4,c2 (profiling)")
+    ap.add_argument("--also-only", default="", help="comma-separated subset of the `also` legs: full,contents,tiles,latency,legacy,c5,c4,inproc,c2 (profiling)")
     ap.add_argument("--c4-parts", type=int, default=0, help="part batches (ShardedCodec objects on their own HIP streams) of the config-4 step; 0 = three where the image count allows")
     ap.add_argument("--c4-images", type=int, default=24, help="8192x8192 images per step of the sharded (config 4) workload (fixed total: strong scaling)")
+    ap.add_argument("--c4-size", type=int, default=8192, help="side of the square config-4 images (8192 = BASELINE; smaller only for rehearsals)")
     ap.add_argument("--c4-tile-w", type=int, default=512)
     ap.add_argument("--c4-tile-h", type=int, default=1)
     ap.add_argument("--legs-timeout", type=float, default=300.0, help="N > 1: seconds the secondary legs (config 4, config 5) may take before the line goes out without them")
@@ -802,11 +929,21 @@ def main():
     local_rank = 0 if args.rehearse_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
-    if not torch.cuda.is_available() or mi.device_count() < 1:
+    Hooks.measure, Hooks.c5_stream, Hooks.inprocess = measure, c5_stream, c4_inprocess
+    if os.environ.get("LLCOMP_BENCH_STANDIN"):  # tests/test_bench_world8.py: CPU stand-ins for the coders, gloo for RCCL (docstring)
+        import importlib
+
+        Hooks.standin = importlib.import_module(os.environ["LLCOMP_BENCH_STANDIN"])
+        Hooks.standin.install(Hooks)
+        if world < 2:
+            raise SystemExit("LLCOMP_BENCH_STANDIN rehearses the N > 1 bookkeeping only")
+    elif not torch.cuda.is_available() or mi.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: llcomp_amd has no CPU path")
-    if local_rank >= torch.cuda.device_count():
-        raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
-    torch.cuda.set_device(local_rank)
+    if Hooks.device == "cuda":
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
+        torch.cuda.set_device(local_rank)
+    DEV = Hooks.device
     if world == 1:  # the sharded workload runs under torch.distributed at every N, so the N = 1 point is the same code
         import socket
 
@@ -816,13 +953,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
         sk.close()
     with quiet_stdout():
-        if args.rehearse_one_gpu:
+        if args.rehearse_one_gpu or Hooks.backend == "gloo":
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        warm = torch.zeros(1, device="cuda")
+        warm = torch.zeros(1, device=DEV)
         dist.all_reduce(warm)
-        torch.cuda.synchronize()
+        Hooks.sync()
     barrier = dist.barrier if world > 1 else None
 
     planar = not args.interleaved
@@ -830,10 +967,10 @@ def main():
 
     if world > 1:
         # ---- headline: BASELINE's metric on config 3, frames dealt to the ranks (same workload per GPU as at N = 1) ----
-        m = measure(make_frames(args.content, F, rank, distinct=min(F, 8)), args.tile_w, args.tile_h, planar, args.streams, args.steps, args.warmup,
-                    local_rank, barrier=barrier)
-        t = torch.tensor([m["dt"]], dtype=torch.float64, device="cuda")
-        every = torch.zeros(world, dtype=torch.float64, device="cuda")
+        m = Hooks.measure(make_frames(args.content, F, rank, distinct=min(F, 8)), args.tile_w, args.tile_h, planar, args.streams, args.steps, args.warmup,
+                          local_rank, barrier=barrier)
+        t = torch.tensor([m["dt"]], dtype=torch.float64, device=DEV)
+        every = torch.zeros(world, dtype=torch.float64, device=DEV)
         every[rank] = m["dt"]
         dist.all_reduce(every)  # every rank's own time for the same K steps (the line's value uses the slowest)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -853,9 +990,10 @@ def main():
         if dist.get_world_size() != args.gpus:  # (cannot happen behind the check above; a line from fewer ranks must not look green)
             raise SystemExit(4)
         dog = Watchdog(rank, res)
-        dog.arm(args.legs_timeout, "c4_sharded + c5_replica_pcie")
+        dog.arm(args.legs_timeout, "c4_sharded + c5_replica_pcie + c4_inprocess_devices")
+        empty_cache = torch.cuda.empty_cache if DEV == "cuda" else (lambda: None)
         # ---- BASELINE config 4: strong scaling of sharded 8192^2 images, gather + scatter inside the timed region -------
-        size, B = 8192, args.c4_images
+        size, B = args.c4_size, args.c4_images
         n4 = max(3, args.steps // 2)
         c4 = {}
         try:
@@ -865,17 +1003,17 @@ def main():
                 solo = dist.new_group(ranks=[0])
                 if rank == 0:
                     dist.all_reduce(warm, group=solo)
-                    torch.cuda.synchronize()
+                    Hooks.sync()
             one = None
             if rank == 0:  # the one-GPU point of the same batch, same code path, on a one-rank subgroup
                 dt1, pay1 = c4_run(B, size, args.c4_tile_w, args.c4_tile_h, n4, 3, local_rank, 1, 0, parts=args.c4_parts, group=solo)
                 mi.trim()
-                torch.cuda.empty_cache()
+                empty_cache()
                 one = B * size * size * n4 / dt1 / 1e6
             dist.barrier()
             dtn, payload = c4_run(B, size, args.c4_tile_w, args.c4_tile_h, n4, 3, local_rank, world, rank, parts=args.c4_parts)
             mi.trim()
-            torch.cuda.empty_cache()
+            empty_cache()
             if rank == 0:
                 raw = B * size * size * 3
                 vn = B * size * size * n4 / dtn / 1e6
@@ -884,7 +1022,7 @@ def main():
                       "ranks_seen": dist.get_world_size(), "images_per_step": B, "compression_ratio": round(raw / payload, 4),
                       "hbm_roofline_frac": round(2 * (raw + payload) * n4 / dtn / 1e9 / (HBM_PEAK_GBS * world), 6),
                       **getattr(c4_run, "last_detail", {}),
-                      "workload": f"C4 {B} x 8192x8192 RGB8 uniform noise per step (fixed total), every image sharded over {world} GPUs by interleaved chunks of "
+                      "workload": f"C4 {B} x {size}x{size} RGB8 uniform noise per step (fixed total), every image sharded over {world} GPUs by interleaved chunks of "
                                   f"tile rows; sliced container {args.c4_tile_w}x{args.c4_tile_h} tiles, per-channel planes; per step: local encode, slice-table "
                                   f"all_gather, variable-size all-to-all of the packed payloads over RCCL (image b is gathered on rank b % {world}), device "
                                   f"concatenator -> {B} complete containers spread over the ranks; then table all_gather, all-to-all back, local decode (decoded "
@@ -900,13 +1038,13 @@ def main():
         ok = 1.0
         try:
             dist.barrier()
-            c5 = c5_stream(make_frames(args.content, max(16, 64 // world), rank, distinct=8), args.tile_w, args.tile_h, planar)
+            c5 = Hooks.c5_stream(make_frames(args.content, max(16, 64 // world), rank, distinct=8), args.tile_w, args.tile_h, planar)
         except Exception as e:  # noqa: BLE001
             ok = 0.0
             print(f"bench: rank {rank}: config-5 replica leg failed: {e!r}", file=sys.stderr, flush=True)
-        v5 = torch.tensor([c5["value"], ok, float(c5["frames"])], dtype=torch.float64, device="cuda")
+        v5 = torch.tensor([c5["value"], ok, float(c5["frames"])], dtype=torch.float64, device=DEV)
         dist.all_reduce(v5, op=dist.ReduceOp.SUM)
-        t5 = torch.tensor([c5["seconds_first_submit_to_last_result"]], dtype=torch.float64, device="cuda")
+        t5 = torch.tensor([c5["seconds_first_submit_to_last_result"]], dtype=torch.float64, device=DEV)
         dist.all_reduce(t5, op=dist.ReduceOp.MAX)
         if rank == 0:
             whole = float(v5[2].item()) * W4K * H4K / 1e6 / float(t5.item()) if float(t5.item()) > 0 else 0.0
@@ -916,6 +1054,30 @@ def main():
                                       "frames_per_rank": 4 * max(16, 64 // world), "rank0": c5,
                                       "workload": f"C5: every rank streams its own {max(16, 64 // world)} 4K frames (four passes) host -> GPU -> host -> GPU -> host "
                                                   f"through llcomp_mi_stream_*, all {world} ranks at once; sum of the ranks' steady-state rates, PCIe inclusive"}
+        # ---- BASELINE config 4 from ONE process: rank 0 drives all N GPUs through the C ABI's device list (llcomp_mi_opts.devices) while
+        # the other ranks wait on the STORE (a collective would park a spinning RCCL kernel on the very GPUs rank 0 is about to use).
+        # Their GPUs are idle by now (lanes and torch's cache released); rank 0 opens a HIP context on each of them.
+        inproc = None
+        try:
+            mi.trim()
+            empty_cache()
+            dist.barrier()
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                try:
+                    inproc = Hooks.inprocess(list(range(world)), images=max(2, min(4, args.c4_images)), size=size, tile_w=args.c4_tile_w, tile_h=args.c4_tile_h)
+                    inproc["ranks_waiting"] = world - 1
+                except Exception as e:  # noqa: BLE001  (the leg is lost, the line is not)
+                    inproc = {"failed": f"{type(e).__name__}: {e}"[:300]}
+                    print(f"bench: in-process device-list leg failed: {e!r}", file=sys.stderr, flush=True)
+                store.set("llcomp_bench_inprocess_done", "1")
+            else:
+                store.wait(["llcomp_bench_inprocess_done"])
+            dist.barrier()
+        except Exception as e:  # noqa: BLE001
+            dog.bail("c4_inprocess_devices", f"rank {rank}: {type(e).__name__}: {e}")
+        if rank == 0:
+            res["c4_inprocess_devices"] = inproc
         if dog.finish() and rank == 0:
             print(json.dumps(res), flush=True)
         dist.destroy_process_group()
@@ -943,27 +1105,7 @@ def main():
             assert res["golden_pin"]["match"], "frame 0's container differs from the reference's (length or FNV-1a-64)"
     except OSError:
         pass
-    if not args.no_also and args.tile_h == 1:
-        # The headline's slicing (one-row slices) leaves llcomp's vertical context -- quant11 over three gradients, the two-row window, the
-        # median of left / top / gradient -- out of the timed region: with no row above, the context collapses to 605 * quant5(L - l).
-        # The same batch and pipelines through 64x64 planar tiles run the FULL model (and keep the reference's ratio): reported next to `value`.
-        mf = measure(frames_np, 64, 64, True, args.streams, max(12, args.steps), 2, local_rank, per_step=True)
-        bf = brief(mf)
-        res["value_full_model"] = bf["value"]
-        # the same contract figures for the full model's dominant kernel: algorithmic bytes of one direction per launch / its live duration
-        sides_f = tile_sides(mf)
-        kd, ke = sides_f["decode_ms_per_launch"]["k_decode_slices"], sides_f["encode_ms_per_launch"]["k_encode_slices"]
-        dom_f, dom_ms_f = ("k_decode_slices", kd) if kd >= ke else ("k_encode_slices", ke)
-        algo_f = (mf["raw_bytes"] + mf["container_bytes"]) // mf["S"]
-        roof_f = {"bound": "hbm", "limiter": "random state-bank transactions (decode) / one wavefront's dependent chain per slice (few frames in flight)",
-                  "kernel": dom_f, "achieved": round(algo_f / (dom_ms_f * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                  "frac": round(algo_f / (dom_ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": algo_f, "avg_launch_ms": round(dom_ms_f, 4)}
-        if args.content in TILE_HBM_BYTES_PER_SAMPLE:
-            roof_f["traffic"] = int(TILE_HBM_BYTES_PER_SAMPLE[args.content][dom_f] * mf["raw_bytes"] / mf["S"])
-            roof_f["traffic_source"] = TILE_HBM_SOURCE + " (bytes per sample of the 16-frame profile x this launch's samples)"
-        res["full_model"] = dict(bf, **sides_f, roofline=roof_f, workload=f"the headline's batch ({F} frames 4K {args.content}, {mf['S']} pipelines) in 64x64 planar tiles: "
-                                 f"{mf['n_slices'] // F} slices per frame, all five context terms and the median predictor live",
-                                 vs_value=round(bf["value"] / res["value"], 4))
+    full_box = {}
     if not args.no_also:
         also = {}
         sub = max(3, args.steps // 3)
@@ -971,6 +1113,36 @@ def main():
         only = set(x for x in args.also_only.split(",") if x)
         want = lambda leg: not only or leg in only  # noqa: E731
         legacy_box = {}
+
+        def leg_full():
+            # The headline's slicing (one-row slices) leaves llcomp's vertical context -- quant11 over three gradients, the two-row window, the
+            # median of left / top / gradient -- out of the timed region: with no row above, the context collapses to 605 * quant5(L - l).
+            # The same batch and pipelines through 64x64 planar tiles run the FULL model (and keep the reference's ratio): reported next to
+            # `value`, as the LAST keys of the line.
+            if args.tile_h != 1:
+                return
+            mf = measure(frames_np, 64, 64, True, args.streams, max(12, args.steps), 2, local_rank, per_step=True)
+            bf = brief(mf)
+            # the same contract figures for the full model's dominant kernel: algorithmic bytes of one direction per launch / its live duration
+            sides_f = tile_sides(mf)
+            kd, ke = sides_f["decode_ms_per_launch"]["k_decode_slices"], sides_f["encode_ms_per_launch"]["k_encode_slices"]
+            dom_f, dom_ms_f = ("k_decode_slices", kd) if kd >= ke else ("k_encode_slices", ke)
+            algo_f = (mf["raw_bytes"] + mf["container_bytes"]) // mf["S"]
+            roof_f = {"bound": "hbm", "limiter": "random state-bank transactions (decode) / one wavefront's dependent chain per slice (few frames in flight)",
+                      "kernel": dom_f, "achieved": round(algo_f / (dom_ms_f * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(algo_f / (dom_ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": algo_f, "avg_launch_ms": round(dom_ms_f, 4)}
+            # HBM-side bytes of that kernel per launch: the committed PMC passes of THIS configuration (frames, pipelines, 64x64 planar,
+            # content), looked up like the headline's (profiles/r06_full_model_traffic.json names the commit it was taken at)
+            traffic_f, _valu_f, source_f = profile_numbers(F, 64, 64, True, args.content, mf["S"], dom_f)
+            roof_f["traffic"], roof_f["traffic_source"] = traffic_f, source_f
+            full_box["full_model"] = dict(bf, **sides_f, **cache_counters(mf), roofline=roof_f,
+                                          workload=f"the headline's batch ({F} frames 4K {args.content}, {mf['S']} pipelines) in 64x64 planar tiles: "
+                                                   f"{mf['n_slices'] // F} slices per frame, all five context terms and the median predictor live",
+                                          vs_value=round(bf["value"] / res["value"], 4))
+            full_box["value_full_model"] = bf["value"]
+
+        def leg_inproc():  # BASELINE config 4 through the C ABI's device list, from this one process: {0,0} = two lanes on the one GPU
+            also["c4_inprocess_devices"] = c4_inprocess([local_rank, local_rank], images=4, tile_w=args.c4_tile_w, tile_h=args.c4_tile_h)
 
         def leg_c5():  # three repetitions: the pipeline's steady state is sensitive to how the copies of the jobs fall over each other (tools/attic/c5_repeat.py)
             link = dict(link0, measured="at the start of the process")
@@ -1005,7 +1177,8 @@ def main():
                     m2 = measure(fr, 64, 64, True, streams, max(12, sub), 2, local_rank, per_step=True)
                     samples = 2 * frames * W4K * H4K * C4K * m2["steps"]
                     extra = {}
-                    if content in TILE_HBM_BYTES_PER_SAMPLE:  # HBM-side traffic from the committed PMC passes of this configuration (one pipeline of 16 frames)
+                    if content in TILE_HBM_BYTES_PER_SAMPLE and frames == 16:  # HBM-side traffic from the committed PMC passes of 16 frames (one pipeline); the
+                        # 48-frame leg's traffic is NOT extrapolated from it -- its configuration at the headline's batch size has its own PMC passes (full_model)
                         t = TILE_HBM_BYTES_PER_SAMPLE[content]
                         gbs = (t["encode_all_kernels"] + t["decode_all_kernels"]) / 2 * samples / m2["dt"] / 1e9
                         extra = {"hbm_bytes_per_sample": t, "hbm_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 3), "hbm_source": TILE_HBM_SOURCE}
@@ -1046,7 +1219,7 @@ def main():
         # 4.8-5.2 GPix/s when its pinned buffers are allocated behind config 4's 150 GB; then BASELINE config 4 on one GPU =
         # the N = 1 point of the strong-scaling curve), before the allocate / free cycles of the others fragment HBM.  A secondary leg that fails is
         # reported as such; it never costs the headline line.
-        for name, fn in (("c5", leg_c5), ("c4", leg_c4), ("contents", leg_contents), ("tiles", leg_tiles), ("latency", leg_latency), ("c2", leg_c2), ("legacy", leg_legacy)):
+        for name, fn in (("c5", leg_c5), ("full", leg_full), ("c4", leg_c4), ("inproc", leg_inproc), ("contents", leg_contents), ("tiles", leg_tiles), ("latency", leg_latency), ("c2", leg_c2), ("legacy", leg_legacy)):
             if not want(name):
                 continue
             try:
@@ -1076,6 +1249,10 @@ def main():
 
         if not args.no_also and "legacy_streams_batched" in res.get("also", {}):
             res["also"]["legacy_streams_batched"]["cpu_reference"] = cpu_baseline(legacy_box["frame"], "256x256 RGB8 mid", 256, 256, False)
+    if not args.no_also:  # the real-model figures go LAST: a record that keeps the tail of the line keeps them
+        for k in ("full_model", "value_full_model"):
+            if k in full_box:
+                res[k] = full_box[k]
     print(json.dumps(res), flush=True)
     dist.destroy_process_group()
 

@@ -129,8 +129,10 @@ struct LaneCache {
     std::mutex mu;
     std::vector<Item> idle;
     uint64_t clock = 0;
-    static constexpr size_t kMaxIdle = 4;
-    static constexpr uint64_t kMaxIdleBytes = 12ull << 30;
+    // per device: a device list parks a lane on every GPU, concurrent callers one each (an 8192 x 8192 lane holds about 10 GB of the
+    // GPU's 288)
+    static constexpr size_t kMaxIdle = 6;
+    static constexpr uint64_t kMaxIdleBytes = 40ull << 30;
 
     HostLane* take(int dev, const Geometry& g, bool legacy) {
         std::lock_guard<std::mutex> lock(mu);
