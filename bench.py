@@ -1057,29 +1057,51 @@ def main():
         # ---- BASELINE config 4 from ONE process: rank 0 drives all N GPUs through the C ABI's device list (llcomp_mi_opts.devices) while
         # the other ranks wait on the STORE (a collective would park a spinning RCCL kernel on the very GPUs rank 0 is about to use).
         # Their GPUs are idle by now (lanes and torch's cache released); rank 0 opens a HIP context on each of them.
-        inproc = None
+        inproc, hung = None, False
         try:
+            import datetime
+            import threading
+
             mi.trim()
             empty_cache()
             dist.barrier()
             store = dist.distributed_c10d._get_default_store()
             if rank == 0:
-                try:
-                    inproc = Hooks.inprocess(list(range(world)), images=max(2, min(4, args.c4_images)), size=size, tile_w=args.c4_tile_w, tile_h=args.c4_tile_h)
-                    inproc["ranks_waiting"] = world - 1
-                except Exception as e:  # noqa: BLE001  (the leg is lost, the line is not)
-                    inproc = {"failed": f"{type(e).__name__}: {e}"[:300]}
-                    print(f"bench: in-process device-list leg failed: {e!r}", file=sys.stderr, flush=True)
-                store.set("llcomp_bench_inprocess_done", "1")
+                # on a thread with a deadline of its own: this leg is the newest code on the newest ground (one process on N GPUs
+                # that other processes hold contexts on) -- if it fails or hangs it costs ITS key, not the line and not the exit code
+                box = {}
+
+                def work():
+                    try:
+                        box["out"] = Hooks.inprocess(list(range(world)), images=max(2, min(4, args.c4_images)), size=size, tile_w=args.c4_tile_w, tile_h=args.c4_tile_h)
+                    except BaseException as e:  # noqa: BLE001
+                        box["err"] = f"{type(e).__name__}: {e}"[:300]
+
+                th = threading.Thread(target=work, daemon=True)
+                th.start()
+                th.join(min(150.0, max(30.0, args.legs_timeout / 2)))
+                if th.is_alive():
+                    inproc, hung = {"failed": "not finished after its own deadline; the line goes out without it"}, True
+                elif "err" in box:
+                    inproc = {"failed": box["err"]}
+                    print(f"bench: in-process device-list leg failed: {box['err']}", file=sys.stderr, flush=True)
+                else:
+                    inproc = dict(box["out"], ranks_waiting=world - 1)
+                store.set("llcomp_bench_inprocess_done", "hung" if hung else "ok")
             else:
-                store.wait(["llcomp_bench_inprocess_done"])
-            dist.barrier()
+                store.wait(["llcomp_bench_inprocess_done"], datetime.timedelta(seconds=args.legs_timeout))
+                hung = store.get("llcomp_bench_inprocess_done") == b"hung"  # (every rank skips the barrier then, and leaves the same way)
+            if not hung:
+                dist.barrier()
         except Exception as e:  # noqa: BLE001
             dog.bail("c4_inprocess_devices", f"rank {rank}: {type(e).__name__}: {e}")
         if rank == 0:
             res["c4_inprocess_devices"] = inproc
         if dog.finish() and rank == 0:
             print(json.dumps(res), flush=True)
+        if hung:  # a HIP call of the abandoned leg may never return: leave without waiting for its thread (the line is out, exit code 0)
+            sys.stdout.flush()
+            os._exit(0)
         dist.destroy_process_group()
         return
 

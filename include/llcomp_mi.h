@@ -204,6 +204,13 @@ uint32_t llcomp_mi_codec_kernel_family(const llcomp_mi_codec* codec);
  * arrays of the 2-D encoder (22 B per sample) are allocated by the first call that needs them, so an encode-only or decode-only
  * codec stays below this figure; that first call can return LLCOMP_MI_NOMEM. */
 uint64_t llcomp_mi_codec_workspace_bytes(const llcomp_mi_codec* codec);
+/* Allocates NOW what the first encode (LLCOMP_MI_PREPARE_ENCODE: the 2-D encoder's snapshot arrays, or its state tables) and / or
+ * the first decode (LLCOMP_MI_PREPARE_DECODE: the state tables of 2-D slices) would otherwise allocate inside the call -- for callers
+ * that need the first call to be like every other one (no hipMalloc behind work already queued on their stream, no NOMEM in the
+ * middle of a pipeline).  Idempotent; LLCOMP_MI_NOMEM when the device cannot give the memory. */
+#define LLCOMP_MI_PREPARE_ENCODE 1u
+#define LLCOMP_MI_PREPARE_DECODE 2u
+int llcomp_mi_codec_prepare(llcomp_mi_codec* codec, uint32_t what);
 /* Upper bound on the packed payload bytes the codec can emit for any input (13 B per sample + slack). */
 uint64_t llcomp_mi_codec_max_payload_bytes(const llcomp_mi_codec* codec);
 /* encode: d_px [frames][h][w][c] u8 -> d_payload (slice payloads packed back to back, slice order),

@@ -472,6 +472,10 @@ class Codec:
         _check(self._L.llcomp_mi_codec_get_profile(self._h, ms, C.byref(ne), C.byref(nd)))
         return dict(zip(self.PROFILE_SLOTS, list(ms))), ne.value, nd.value
 
+    def prepare(self, encode=True, decode=True):
+        """allocate now what the first encode / decode would allocate inside the call (llcomp_mi_codec_prepare)"""
+        _check(self._L.llcomp_mi_codec_prepare(self._h, (1 if encode else 0) | (2 if decode else 0)))
+
     COUNTERS = ("dec_cached_waves", "dec_bypassed_waves", "cache_lookups", "cache_misses", "cache_writebacks", "dec_replays", "enc_carry_backs",
                 "generation_wraps", "dec_launches_cached", "dec_launches_plain")
 

@@ -28,7 +28,7 @@ SYMBOLS = [
     "llcomp_mi_stream_poll", "llcomp_mi_stream_wait", "llcomp_mi_stream_release",
     "llcomp_mi_set_pool_limit", "llcomp_mi_pool_limit", "llcomp_mi_pool_idle_bytes", "llcomp_mi_fnv1a64", "llcomp_mi_suggest_tile_w", "llcomp_mi_decode_into_flags", "llcomp_mi_device_range_sums",
     "llcomp_mi_decode_devices", "llcomp_mi_decode_into_devices", "llcomp_mi_last_device_error", "llcomp_mi_plan_chunks",
-    "llcomp_mi_stream_create_multi", "llcomp_mi_stream_devices", "llcomp_mi_codec_get_counters",
+    "llcomp_mi_stream_create_multi", "llcomp_mi_stream_devices", "llcomp_mi_codec_get_counters", "llcomp_mi_codec_prepare",
 ]
 
 u8p = C.POINTER(C.c_uint8)
@@ -207,6 +207,8 @@ def load():
         L.llcomp_mi_stream_create_multi.argtypes = [C.POINTER(C.c_void_p), i32p, C.c_uint32] + [C.c_uint32] * 8
         L.llcomp_mi_stream_devices.restype = C.c_uint32
         L.llcomp_mi_stream_devices.argtypes = [C.c_void_p]
+        L.llcomp_mi_codec_prepare.restype = C.c_int
+        L.llcomp_mi_codec_prepare.argtypes = [C.c_void_p, C.c_uint32]
         L.llcomp_mi_codec_get_counters.restype = C.c_int
         L.llcomp_mi_codec_get_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_int]
     if "LLCOMP_MI_LIB" not in os.environ and L.llcomp_mi_abi_version() != ABI_VERSION:

@@ -90,17 +90,21 @@ struct Timed {
 
 // State tables in HBM are tagged with the generation of the call that wrote them instead of being cleared per call
 // (kernels.hpp): a real clear happens before the first call and whenever the 8-bit generation would repeat.
+int ensure_state_tables(llcomp_mi_codec* k) {
+    if (!k->need_states || k->d_states) return LLCOMP_MI_OK;
+    const Geometry& g = k->g;
+    if (dev_alloc(reinterpret_cast<void**>(&k->d_states), (uint64_t(lane_groups(g)) * kContexts << g.lane_shift) * 8) != hipSuccess) {
+        k->d_states = nullptr;
+        return LLCOMP_MI_NOMEM;
+    }
+    k->allocated_bytes += (uint64_t(lane_groups(g)) * kContexts << g.lane_shift) * 8;
+    k->state_generation = 0;
+    return LLCOMP_MI_OK;
+}
 int next_state_generation(llcomp_mi_codec* k, hipStream_t s) {
     if (!k->need_states) return LLCOMP_MI_OK;
-    if (!k->d_states) {  // first call that needs the tables (an encode-only codec with the snapshot pass never gets here)
-        const Geometry& g = k->g;
-        if (dev_alloc(reinterpret_cast<void**>(&k->d_states), (uint64_t(lane_groups(g)) * kContexts << g.lane_shift) * 8) != hipSuccess) {
-            k->d_states = nullptr;
-            return LLCOMP_MI_NOMEM;
-        }
-        k->allocated_bytes += (uint64_t(lane_groups(g)) * kContexts << g.lane_shift) * 8;
-        k->state_generation = 0;
-    }
+    // first call that needs the tables (an encode-only codec with the snapshot pass never gets here; llcomp_mi_codec_prepare allocates them ahead)
+    if (int rc = ensure_state_tables(k)) return rc;
     if (k->state_generation == 0 || k->state_generation >= 255) {
         const Geometry& g = k->g;
         if (k->state_generation >= 255) ++k->host_counters[kCtrGenerationWraps];
@@ -314,6 +318,22 @@ void llcomp_mi_codec_destroy(llcomp_mi_codec* k) {
     // the codec's last encode / decode, and are handed out again only after it.  Profiling events that were never read
     // are destroyed by codec_release (hipEventDestroy of a pending event is legal: it is released when it completes).
     llcomp_mi::codec_release(k);
+}
+
+int llcomp_mi_codec_prepare(llcomp_mi_codec* k, uint32_t what) {
+    if (!k || (what & ~(LLCOMP_MI_PREPARE_ENCODE | LLCOMP_MI_PREPARE_DECODE))) return LLCOMP_MI_BAD_ARGS;
+    DeviceGuard guard(k->device);
+    if (!guard.ok) return LLCOMP_MI_HIP_ERROR;
+    if (what & LLCOMP_MI_PREPARE_ENCODE) {
+        if (snapshot_mode(k->g)) {
+            if (int rc = ensure_snapshot_arrays(k)) return rc;
+        } else if (int rc = ensure_state_tables(k)) {
+            return rc;
+        }
+    }
+    if (what & LLCOMP_MI_PREPARE_DECODE)
+        if (int rc = ensure_state_tables(k)) return rc;
+    return LLCOMP_MI_OK;
 }
 
 uint32_t llcomp_mi_codec_slices(const llcomp_mi_codec* k) { return k ? k->g.n_slices : 0; }

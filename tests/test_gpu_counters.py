@@ -235,3 +235,23 @@ def test_generation_wraps_are_counted(mi, orc, set_hook):
     b.decode()
     assert b.codec.counters()["generation_wraps"] == 1
     b.close()
+
+
+def test_prepare_allocates_ahead_of_the_first_call(mi, orc, set_hook):
+    """llcomp_mi_codec_prepare: the state tables (decode) and the snapshot arrays (encode) exist before the first call asks for them;
+    idempotent; same bytes and pixels as without it"""
+    set_hook("LLCOMP_MI_LANE_SHIFT", "6")
+    img = make_image("nat", 256, 128, 3)
+    b = Batch(mi, img[None], 32, 32, True)
+    before = mi.pool_idle_bytes()
+    b.codec.prepare()
+    b.codec.prepare(encode=True, decode=False)
+    assert mi.pool_idle_bytes() <= before
+    b.encode()
+    b.decode()
+    want = orc.compress_sliced(img, 32, 32, True)
+    n = b.codec.n_slices
+    assert b.d_len.cpu().numpy().astype("<u4").tobytes() == want[24:24 + 4 * n] and b.d_pay[: b.total].cpu().numpy().tobytes() == want[24 + 4 * n:]
+    L = mi._lib.load()
+    assert L.llcomp_mi_codec_prepare(b.codec._h, 4) == mi.BAD_ARGS and L.llcomp_mi_codec_prepare(None, 1) == mi.BAD_ARGS
+    b.close()
