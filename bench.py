@@ -1073,7 +1073,9 @@ def main():
 
                 def work():
                     try:
-                        box["out"] = Hooks.inprocess(list(range(world)), images=max(2, min(4, args.c4_images)), size=size, tile_w=args.c4_tile_w, tile_h=args.c4_tile_h)
+                        # (a launcher that narrows every rank's view to its own GPU leaves rank 0 fewer ordinals than ranks: it then drives what it sees)
+                        seen = mi.device_count() if Hooks.device == "cuda" else world
+                        box["out"] = Hooks.inprocess(list(range(max(1, min(world, seen)))), images=max(2, min(4, args.c4_images)), size=size, tile_w=args.c4_tile_w, tile_h=args.c4_tile_h)
                     except BaseException as e:  # noqa: BLE001
                         box["err"] = f"{type(e).__name__}: {e}"[:300]
 
@@ -1143,8 +1145,14 @@ def main():
             # `value`, as the LAST keys of the line.
             if args.tile_h != 1:
                 return
-            mf = measure(frames_np, 64, 64, True, args.streams, max(12, args.steps), 2, local_rank, per_step=True)
+            # Timed like `value`: K steps queued back to back between two device synchronisations (the kernels of step i + 1 start while
+            # the tail of step i drains).  The second pass brackets every step with a synchronisation of its own and reports median and
+            # range: what one isolated step costs, and how far single steps fall from each other.
+            mf = measure(frames_np, 64, 64, True, args.streams, max(12, args.steps), 2, local_rank)
             bf = brief(mf)
+            ms_ = measure(frames_np, 64, 64, True, args.streams, max(12, args.steps), 2, local_rank, per_step=True)
+            bs = brief(ms_)
+            bf["steps_synchronised_one_by_one"] = {k: bs[k] for k in ("value", "value_is", "ms_per_step", "ms_per_step_min_max", "value_min_max")}
             # the same contract figures for the full model's dominant kernel: algorithmic bytes of one direction per launch / its live duration
             sides_f = tile_sides(mf)
             kd, ke = sides_f["decode_ms_per_launch"]["k_decode_slices"], sides_f["encode_ms_per_launch"]["k_encode_slices"]
