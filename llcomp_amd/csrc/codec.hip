@@ -119,15 +119,19 @@ int next_state_generation(llcomp_mi_codec* k, hipStream_t s) {
 int ensure_snapshot_arrays(llcomp_mi_codec* k) {
     if (k->d_snap_sorted) return LLCOMP_MI_OK;
     const uint64_t el = snapshot_elems(k->g);
+    const bool chunked = snapshot_chunked(k->g);
     if (dev_alloc(&k->d_snap_sorted, el * 8) != hipSuccess || dev_alloc(&k->d_snap_banks, el * 8) != hipSuccess ||
-        dev_alloc(&k->d_snap_res, el * 2) != hipSuccess) {
+        dev_alloc(&k->d_snap_res, el * 2) != hipSuccess ||
+        (chunked && (dev_alloc(&k->d_snap_ctx, el * 2) != hipSuccess || dev_alloc(&k->d_snap_io, el * 8) != hipSuccess))) {
         dev_free(k->d_snap_sorted);
         dev_free(k->d_snap_banks);
         dev_free(k->d_snap_res);
-        k->d_snap_sorted = k->d_snap_banks = k->d_snap_res = nullptr;
+        dev_free(k->d_snap_ctx);
+        dev_free(k->d_snap_io);
+        k->d_snap_sorted = k->d_snap_banks = k->d_snap_res = k->d_snap_ctx = k->d_snap_io = nullptr;
         return LLCOMP_MI_NOMEM;
     }
-    k->allocated_bytes += el * 18;
+    k->allocated_bytes += el * (chunked ? 28 : 18);
     return LLCOMP_MI_OK;
 }
 
@@ -210,6 +214,8 @@ void codec_release(llcomp_mi_codec* k) {
     dev_free(k->d_snap_sorted, k->done);
     dev_free(k->d_snap_banks, k->done);
     dev_free(k->d_snap_res, k->done);
+    dev_free(k->d_snap_ctx, k->done);
+    dev_free(k->d_snap_io, k->done);
     dev_free(k->d_counters, k->done);
     if (k->fb_event) (void)hipEventDestroy(k->fb_event);  // (legal while pending: released when it completes)
     if (k->h_feedback) {
@@ -297,7 +303,7 @@ int llcomp_mi_codec_create_ex(llcomp_mi_codec** out, int32_t device, uint32_t fr
     // What the codec can hold at most.  The state tables (decode, and encode without the snapshot pass) and the snapshot arrays
     // (encode) are allocated by the first call that needs them: a codec that only ever encodes, or only ever decodes, 64x64 tiles
     // holds 8.8 GB resp. 6.2 GB less per 16 frames of 4K than this figure.
-    k->workspace_bytes = b_sym + b_lanes + b_states + b_scratch + b_off + 8 + snap_el * 18;
+    k->workspace_bytes = b_sym + b_lanes + b_states + b_scratch + b_off + 8 + snap_el * (snapshot_chunked(g) ? 28 : 18);
     const bool ok = dev_alloc(&k->d_sym_or_rec, b_sym) == hipSuccess && dev_alloc(&k->d_lane_order, b_lanes) == hipSuccess &&
                     dev_alloc(reinterpret_cast<void**>(&k->d_scratch), b_scratch) == hipSuccess &&
                     dev_alloc(reinterpret_cast<void**>(&k->d_group_off), b_off) == hipSuccess &&
@@ -327,9 +333,9 @@ int llcomp_mi_codec_prepare(llcomp_mi_codec* k, uint32_t what) {
     if (what & LLCOMP_MI_PREPARE_ENCODE) {
         if (snapshot_mode(k->g)) {
             if (int rc = ensure_snapshot_arrays(k)) return rc;
-        } else if (int rc = ensure_state_tables(k)) {
-            return rc;
         }
+        if (!snapshot_mode(k->g) || snapshot_chunked(k->g))
+            if (int rc = ensure_state_tables(k)) return rc;
     }
     if (what & LLCOMP_MI_PREPARE_DECODE)
         if (int rc = ensure_state_tables(k)) return rc;
@@ -361,7 +367,9 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
     const Geometry& g = k->g;
     DoneGuard done_guard{k, s};
     HIP_TRY(hipMemsetAsync(d_status, 0, 4, s));
-    if (!snapshot_mode(g)) {  // (the snapshot encoder never touches the state tables: they are the decoder's alone)
+    // (the snapshot encoder of slices up to 4096 samples never touches the state tables: they are the decoder's alone; above that
+    // the pass carries a context's states from chunk to chunk through them, under a generation of its own)
+    if (!snapshot_mode(g) || snapshot_chunked(g)) {
         Timed t(k, s, 0);
         if (int rc = next_state_generation(k, s)) return rc;
     }
@@ -380,7 +388,8 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
         if (int rc = ensure_snapshot_arrays(k)) return rc;
         Timed t(k, s, 0);    // (profile slot 0: the pass takes the place of the state tables whose clear the slot times otherwise)
         HIP_TRY(launch_snapshot(g, static_cast<const uint32_t*>(k->d_sym_or_rec), k->d_lane_order, k->d_snap_sorted,
-                                k->d_snap_banks, k->d_snap_res, s));
+                                k->d_snap_banks, k->d_snap_res, k->d_snap_ctx, k->d_snap_io, k->d_states,
+                                snapshot_chunked(g) ? state_generation_tag(k->state_generation) : 0, s));
     }
     {
         Timed t(k, s, 2);

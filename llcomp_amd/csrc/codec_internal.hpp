@@ -32,6 +32,8 @@ struct llcomp_mi_codec {
     void* d_snap_sorted = nullptr;   // snapshot pass of the 2-D encoder (snapshot.hpp): banks in context-sorted order,
     void* d_snap_banks = nullptr;    // banks in stream order, residuals in stream order; null unless snapshot_mode(g)
     void* d_snap_res = nullptr;
+    void* d_snap_ctx = nullptr;      // ... slices above 4096 samples (snapshot_chunked): the context of every sorted position (u16) and the
+    void* d_snap_io = nullptr;       // states every context run of a chunk starts from (u64), both scratch of the pass
     uint64_t workspace_bytes = 0;    // what the codec can hold at most
     uint64_t allocated_bytes = 0;    // what it holds right now (state tables / snapshot arrays come with the first call that needs them)
     // Event counters (kernels.hpp kCtr*): kernel-side u64[kCtrCount] in HBM, host-side additions, and the feedback that takes the bank

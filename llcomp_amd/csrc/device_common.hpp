@@ -51,6 +51,17 @@ __device__ __forceinline__ int context_hash_lut(const Hood& n, const int8_t* lut
 }
 __device__ __forceinline__ int predict(const Hood& n) { return median3(n.l, n.l + n.t - n.tl, n.t); }
 
+// ---- generation tags of the state tables in HBM (slice_kernels.hip: "State tables in HBM"; also the snapshot pass's carry) ----------
+constexpr uint64_t kTagBits = 0x8080808080808080ull;
+template <bool INLDS_TABLE>
+__device__ __forceinline__ uint64_t bank_fresh(uint64_t raw, uint64_t gpat) {  // what the table holds for THIS call
+    if constexpr (INLDS_TABLE) return raw;  // (a table in LDS is cleared by the kernel itself and carries no tags)
+    return (raw & kTagBits) == gpat ? (raw & ~kTagBits) : 0ull;
+}
+template <bool INLDS_TABLE>
+__device__ __forceinline__ uint64_t bank_tagged(uint64_t states, uint64_t gpat) { return INLDS_TABLE ? states : (states | gpat); }
+
+
 // ---- sample layouts in HBM -------------------------------------------------------------------------------
 // Per-sample work arrays (encode: u32 symbols, decode: int16 reconstructed samples) are laid out so that the
 // samples of one slice row are CONTIGUOUS:

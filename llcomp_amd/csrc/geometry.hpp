@@ -36,11 +36,14 @@ enum : uint32_t {
     kGeoLdsTable = 2u,     // one slice per wavefront: its 63 KB state table lives in LDS
     kGeoForceReplay = 4u,  // test hook: every decoded sample also goes through rollback + checked replay
     kGeoSmallModel = 8u,   // bitstream variant: the reference built with LargeModel = false (llcomp.hpp:21, 26-32, 427-429)
-    kGeoSnapshot = 16u,    // 2-D slices of at most kSnapMaxSamples samples: the ENCODER streams state snapshots (snapshot_kernels.hip)
-                           // instead of read-modify-writing a 63 KB table per slice in HBM; the decoder still needs that table
+    kGeoSnapshot = 16u,    // 2-D slices of at most kSnapMaxSamples * kSnapMaxChunks samples: the ENCODER streams state snapshots
+                           // (snapshot_kernels.hip) instead of read-modify-writing a 63 KB table per slice in HBM per SAMPLE; the decoder
+                           // still needs that table, and so does the pass itself between the chunks of a slice above 4096 samples
     kGeoBankCache = 32u,   // 2-D decoder with tables in HBM: per-lane write-back cache of 32 state banks in LDS (slice_kernels.hip)
 };
-constexpr uint32_t kSnapMaxSamples = 4096;  // a slice's samples are sorted by context inside one workgroup's LDS
+constexpr uint32_t kSnapMaxSamples = 4096;  // a slice's samples are sorted by context inside one workgroup's LDS, 4096 at a time ...
+constexpr uint32_t kSnapMaxChunks = 16;     // ... and a bigger slice goes through the pass in chunks of 4096 consecutive samples whose contexts'
+                                            // states are carried from chunk to chunk through the slice's table in HBM (snapshot_kernels.hip)
 
 // Test / tuning hooks.  They are read from the environment ONCE per process (codec.hip: current_tuning; a test that
 // changes them calls llcomp_mi_reload_tuning), they select the kernel family when a codec object is created, and none
@@ -73,6 +76,13 @@ inline Tuning tuning_from_env() {
     t.nocache = flag("LLCOMP_MI_NOCACHE");
     t.nofeedback = flag("LLCOMP_MI_NOFEEDBACK");
     return t;
+}
+
+// snapshot pass (2-D encoder): chunks of a slice, and its sample capacity in the piece-layout arrays (a multiple of 16; whole chunks
+// when there are several, so that chunk c starts at sample c * 4096 = piece boundaries of every array)
+LLMI_HD inline uint32_t snapshot_chunks(const Geometry& g) { return (g.slice_samples + kSnapMaxSamples - 1) / kSnapMaxSamples; }
+LLMI_HD inline uint32_t snapshot_cap(const Geometry& g) {
+    return g.slice_samples <= kSnapMaxSamples ? (g.slice_samples + 15u) & ~15u : snapshot_chunks(g) * kSnapMaxSamples;
 }
 
 constexpr int kBankCacheLog2 = 5;  // entries per lane of the 2-D decoder's bank cache (slice_kernels.hip): ONE constant for flag, launcher, kernel
@@ -153,7 +163,7 @@ inline bool make_geometry(Geometry& g, uint32_t frames, uint32_t w, uint32_t h, 
     g.flags = 0;
     if (g.tile_h == 1 && !tune.norows && g.nch <= 4) g.flags |= kGeoRows;  // (the register-resident row kernels exist for 1..4 channels)
     else if (g.lpw == 1 && !tune.noldstab) g.flags |= kGeoLdsTable;
-    else if (g.slice_samples <= kSnapMaxSamples && !tune.nosnap) g.flags |= kGeoSnapshot;
+    else if (g.slice_samples <= kSnapMaxSamples * kSnapMaxChunks && !tune.nosnap) g.flags |= kGeoSnapshot;
     // The decoder of the families with tables in HBM (1..4 channels per slice): bank cache in LDS.
     if (!(g.flags & (kGeoRows | kGeoLdsTable)) && g.nch <= 4 && !tune.nocache) g.flags |= kGeoBankCache;
     if (tune.force_replay) g.flags |= kGeoForceReplay;

@@ -62,6 +62,8 @@ bool slices_need_state_tables(const Geometry& g);
 hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* d_states, uint32_t generation, uint8_t* d_scratch,
                                 uint32_t* d_slice_len, uint64_t* d_group_off, uint32_t* d_status, unsigned long long* d_counters,
                                 hipStream_t stream);
+// generation (1..255) -> the tag bits of a bank: bit i of the generation in the top bit of state byte i
+uint64_t state_generation_tag(uint32_t generation);
 // Offsets of the slices in the packed payload: one exclusive prefix value per LANE GROUP, u64[lane_groups + 1] (the last
 // element and *d_total = sum of all lengths); pack / stage add the wave prefix of the group's own lengths.
 // launch_encode_slices leaves the group sums in d_group_off itself when encoder_writes_group_sums(g); otherwise (and

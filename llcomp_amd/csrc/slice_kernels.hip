@@ -181,15 +181,6 @@ __device__ __forceinline__ uint32_t successor(entry_t e, bool bit) { return bit 
 // 7 bits (128 states), so the eight spare top bits of a bank carry the GENERATION of the call that wrote it: a bank whose
 // tag is not this call's generation is stale and reads as eight zero states -- exactly what a cleared table holds.  The
 // host clears the table for real once per 255 calls (generation 0 = cleared memory, never a call's tag).
-constexpr uint64_t kTagBits = 0x8080808080808080ull;
-template <bool INLDS_TABLE>
-__device__ __forceinline__ uint64_t bank_fresh(uint64_t raw, uint64_t gpat) {  // what the table holds for THIS call
-    if constexpr (INLDS_TABLE) return raw;  // (a table in LDS is cleared by the kernel itself and carries no tags)
-    return (raw & kTagBits) == gpat ? (raw & ~kTagBits) : 0ull;
-}
-template <bool INLDS_TABLE>
-__device__ __forceinline__ uint64_t bank_tagged(uint64_t states, uint64_t gpat) { return INLDS_TABLE ? states : (states | gpat); }
-
 // The 8 entries of one context.  `all` = request slots 1..7 together with slot 0 (worth it when most residuals
 // are non-zero); otherwise they are requested after the zero flag turned out 0.
 struct Entries {
@@ -562,7 +553,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
     if constexpr (SNAP) {
         // One bank and one residual per sample, front to back.  The sample index is wave-uniform (lock-step), so the piece
         // address is a scalar base plus the lane's fixed offset.
-        const uint32_t cap = (g.slice_samples + 15u) & ~15u;  // snapshot_cap()
+        const uint32_t cap = snapshot_cap(g);
         const uint32_t grp = __builtin_amdgcn_readfirstlane(id >> g.lane_shift);
         const char* const gres = reinterpret_cast<const char*>(sym) + ((size_t(grp) * cap * 2) << g.lane_shift);
         const char* const gbank = reinterpret_cast<const char*>(states) + ((size_t(grp) * cap * 8) << g.lane_shift);

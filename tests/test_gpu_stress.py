@@ -236,6 +236,51 @@ def run_tiles_case(mi, orc, seed):
         mi.reload_tuning()
 
 
+def run_chunked_case(mi, orc, seed):
+    """Slices ABOVE 4096 samples: the snapshot pass in chunks of 4096 with the contexts' states carried through the slice's table
+    (round 6).  Random tile shapes between 4097 and 40000 samples, 1..4 channels, planar and interleaved, ragged images (slices with
+    fewer chunks than their neighbours), forced lane-group widths, contents from noise to saturated checkerboards; now and then the
+    table encoder instead (LLCOMP_MI_NOSNAP=1): same bytes."""
+    rng = np.random.default_rng(seed)
+    c = int(rng.integers(1, 5))
+    planar = bool(rng.integers(0, 2))
+    per = 1 if planar else c
+    target = int(rng.choice((4100, 5000, 8192, 8200, 12288, 16384, 20000, 40000))) // per  # pixels per tile
+    th = int(rng.integers(8, 160))
+    tw = max(1, min(target // th, 1400))
+    w, h = int(rng.integers(tw, 3 * tw + 40)), int(rng.integers(th, 4 * th + 9))
+    w, h = min(w, 1500), min(h, 900)
+    img = make(rng, w, h, c, int(rng.integers(0, 5)))
+    env = {"LLCOMP_MI_NOSNAP": "1"} if rng.random() < 0.15 else {}
+    env["LLCOMP_MI_LANE_SHIFT"] = str(int(rng.integers(2, 7)))  # (so few big slices would otherwise get one wavefront each and their table in LDS)
+    for k in HOOKS:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    mi.reload_tuning()
+    try:
+        want = orc.compress_sliced(img, tw, th, planar)
+        got = mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar)
+        assert got == want, f"chunked case {seed}: container differs ({w}x{h}x{c} tile {tw}x{th} planar={planar} env={env})"
+        assert np.array_equal(mi.decompress_image(got).pixels, img), f"chunked case {seed}: round trip"
+    finally:
+        for k in HOOKS:
+            os.environ.pop(k, None)
+        mi.reload_tuning()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", range(3))
+def test_tiles_chunked_snapshot_path(chunk):
+    """30 random cases per run on slices above 4096 samples, byte-exact against the oracle and lossless."""
+    import llcomp_amd as mi
+    import orc as orc_mod
+
+    assert mi.device_count() >= 1, "GPU tests need a HIP device"
+    orc = orc_mod.Orc()
+    for i in range(10):
+        run_chunked_case(mi, orc, 9000 + chunk * 10 + i)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("chunk", range(3))
 def test_tiles_snapshot_path(chunk):
