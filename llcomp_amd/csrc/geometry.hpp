@@ -42,8 +42,11 @@ enum : uint32_t {
     kGeoBankCache = 32u,   // 2-D decoder with tables in HBM: per-lane write-back cache of 32 state banks in LDS (slice_kernels.hip)
 };
 constexpr uint32_t kSnapMaxSamples = 4096;  // a slice's samples are sorted by context inside one workgroup's LDS, 4096 at a time ...
-constexpr uint32_t kSnapMaxChunks = 16;     // ... and a bigger slice goes through the pass in chunks of 4096 consecutive samples whose contexts'
-                                            // states are carried from chunk to chunk through the slice's table in HBM (snapshot_kernels.hip)
+constexpr uint32_t kSnapMaxChunks = 4;      // ... and a bigger slice (up to 16384 samples: 64x64 interleaved RGB, 128x128 planes) goes through the
+                                            // pass in chunks of 4096 consecutive samples whose contexts' states are carried from chunk to chunk
+                                            // through the slice's table in HBM (snapshot_kernels.hip).  Beyond that the table encoder stays:
+                                            // 256x256 planes (16 chunks, a few thousand slices per launch) are one wavefront's dependent chain
+                                            // whatever feeds it, and 48 more launches in front of it cost 9 % (profiles/r06_chunked_snapshot_ab.txt)
 
 // Test / tuning hooks.  They are read from the environment ONCE per process (codec.hip: current_tuning; a test that
 // changes them calls llcomp_mi_reload_tuning), they select the kernel family when a codec object is created, and none
