@@ -132,6 +132,19 @@ int ensure_snapshot_arrays(llcomp_mi_codec* k) {
         return LLCOMP_MI_NOMEM;
     }
     k->allocated_bytes += el * (chunked ? 28 : 18);
+    if (chunked) {  // the coder's parking records, the second stream and the events of the fork / join
+        if (dev_alloc(reinterpret_cast<void**>(&k->d_seg_state), uint64_t(k->g.n_slices) * 64) != hipSuccess) { k->d_seg_state = nullptr; return LLCOMP_MI_NOMEM; }
+        k->allocated_bytes += uint64_t(k->g.n_slices) * 64;
+        if (k->overlap) {
+            bool ok = hipStreamCreateWithFlags(&k->aux, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&k->ev_fork, hipEventDisableTiming) == hipSuccess;
+            for (uint32_t c = 0; ok && c < snapshot_chunks(k->g); ++c) ok = hipEventCreateWithFlags(&k->ev_chunk[c], hipEventDisableTiming) == hipSuccess;
+            if (!ok) {  // no second stream to be had: the pass runs on the caller's (slower at few frames in flight, same bytes)
+                (void)hipGetLastError();
+                k->overlap = false;
+            }
+        }
+    }
     return LLCOMP_MI_OK;
 }
 
@@ -216,6 +229,11 @@ void codec_release(llcomp_mi_codec* k) {
     dev_free(k->d_snap_res, k->done);
     dev_free(k->d_snap_ctx, k->done);
     dev_free(k->d_snap_io, k->done);
+    dev_free(k->d_seg_state, k->done);
+    // (the second stream's work of a call is joined into the caller's stream before the call's last kernels: behind k->done it is idle)
+    if (k->ev_fork) (void)hipEventDestroy(k->ev_fork);
+    for (auto& ev : k->ev_chunk) if (ev) (void)hipEventDestroy(ev);
+    if (k->aux) (void)hipStreamDestroy(k->aux);
     dev_free(k->d_counters, k->done);
     if (k->fb_event) (void)hipEventDestroy(k->fb_event);  // (legal while pending: released when it completes)
     if (k->h_feedback) {
@@ -289,6 +307,7 @@ int llcomp_mi_codec_create_ex(llcomp_mi_codec** out, int32_t device, uint32_t fr
     k->g = g;
     k->device = dev;
     k->feedback = !current_tuning().nofeedback;
+    k->overlap = current_tuning().overlap;
     const uint64_t samples = uint64_t(frames) * w * h * c;
     k->need_states = slices_need_state_tables(g);
     // the fused row path (planar 1-row slices) has no image-order intermediate and 16-bit lane-order arrays in both directions
@@ -384,12 +403,59 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
                                                  static_cast<uint32_t*>(k->d_lane_order), s));
         }
     }
+    if (snapshot_mode(g) && snapshot_chunked(g)) {
+        // Slices above 4096 samples: pass and coder chunk by chunk.  The pass of chunk c + 1 needs the WALK of chunk c (the contexts'
+        // states travel through the table), the coder of chunk c needs the pass of chunk c only.  Default: everything in order on the
+        // caller's stream.  LLCOMP_MI_OVERLAP=1: the pass runs ahead on the codec's own second stream and the coder follows on the
+        // caller's, each segment behind its chunk's event -- a launch of such slices is a few hundred wavefronts, one wavefront's
+        // dependent chain, and the pass's nine or twelve launches in front of it cost 8-11 % against the table encoder at few frames
+        // in flight; beside it they are hidden (one or two pipelines: +1..+27 %), but with three pipelines' six streams the step got
+        // 25 % SLOWER than in order (profiles/r06_chunked_snapshot_ab.txt), so it is a hook, not the default.
+        if (int rc = ensure_snapshot_arrays(k)) return rc;
+        const uint64_t gpat = state_generation_tag(k->state_generation);
+        const uint32_t chunks = snapshot_chunks(g);
+        hipStream_t ps = k->overlap ? k->aux : s;
+        if (k->overlap) {  // fork: the pass starts behind stage A
+            HIP_TRY(hipEventRecord(k->ev_fork, s));
+            HIP_TRY(hipStreamWaitEvent(k->aux, k->ev_fork, 0));
+        }
+        auto pass = [&](uint32_t c) -> int {
+            Timed t(k, ps, 0);
+            HIP_TRY(launch_snapshot_chunk(g, c, static_cast<const uint32_t*>(k->d_sym_or_rec), k->d_lane_order, k->d_snap_sorted, k->d_snap_banks,
+                                          k->d_snap_res, k->d_snap_ctx, k->d_snap_io, k->d_states, gpat, ps));
+            return LLCOMP_MI_OK;
+        };
+        auto coder = [&](uint32_t c) -> int {
+            Timed t(k, s, 2);
+            HIP_TRY(launch_encode_segment(g, k->d_snap_res, static_cast<uint64_t*>(k->d_snap_banks), k->d_scratch, static_cast<uint32_t*>(d_slice_len),
+                                          static_cast<uint32_t*>(d_status), k->d_counters, c * kSnapMaxSamples, k->d_seg_state, s));
+            return LLCOMP_MI_OK;
+        };
+        int rc = LLCOMP_MI_OK;
+        if (k->overlap) {
+            for (uint32_t c = 0; c < chunks && !rc; ++c) {
+                rc = pass(c);
+                if (!rc && hipEventRecord(k->ev_chunk[c], k->aux) != hipSuccess) rc = LLCOMP_MI_HIP_ERROR;
+            }
+            // join: every segment waits for its chunk -- also when something failed above: whatever was queued on the second stream
+            // has to be behind the caller's stream before this call returns its buffers to anybody
+            for (uint32_t c = 0; c < chunks; ++c) {
+                if (hipStreamWaitEvent(s, k->ev_chunk[c], 0) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(k->aux); }
+                if (!rc) rc = coder(c);
+            }
+        } else {
+            for (uint32_t c = 0; c < chunks && !rc; ++c) {
+                rc = pass(c);
+                if (!rc) rc = coder(c);
+            }
+        }
+        if (rc) return rc;
+    } else {
     if (snapshot_mode(g)) {  // states replayed ahead of the coder: it reads banks + residuals front to back, no table
         if (int rc = ensure_snapshot_arrays(k)) return rc;
         Timed t(k, s, 0);    // (profile slot 0: the pass takes the place of the state tables whose clear the slot times otherwise)
         HIP_TRY(launch_snapshot(g, static_cast<const uint32_t*>(k->d_sym_or_rec), k->d_lane_order, k->d_snap_sorted,
-                                k->d_snap_banks, k->d_snap_res, k->d_snap_ctx, k->d_snap_io, k->d_states,
-                                snapshot_chunked(g) ? state_generation_tag(k->state_generation) : 0, s));
+                                k->d_snap_banks, k->d_snap_res, s));
     }
     {
         Timed t(k, s, 2);
@@ -397,6 +463,7 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
         HIP_TRY(launch_encode_slices(g, snap ? k->d_snap_res : k->d_lane_order, snap ? static_cast<uint64_t*>(k->d_snap_banks) : k->d_states,
                                      k->state_generation, k->d_scratch, static_cast<uint32_t*>(d_slice_len),
                                      k->d_group_off, static_cast<uint32_t*>(d_status), k->d_counters, s));
+    }
     }
     {
         Timed t(k, s, 3);

@@ -64,6 +64,11 @@ hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* 
                                 hipStream_t stream);
 // generation (1..255) -> the tag bits of a bank: bit i of the generation in the top bit of state byte i
 uint64_t state_generation_tag(uint32_t generation);
+// The snapshot coder of slices above 4096 samples, one segment (4096 samples of every slice) per launch: d_res / d_banks as
+// launch_snapshot leaves them, d_seg_state = 64 bytes per slice in which a lane parks its coder between the segments.
+hipError_t launch_encode_segment(const Geometry& g, const void* d_res, uint64_t* d_banks, uint8_t* d_scratch, uint32_t* d_slice_len,
+                                 uint32_t* d_status, unsigned long long* d_counters, uint32_t seg_first, uint32_t* d_seg_state,
+                                 hipStream_t stream);
 // Offsets of the slices in the packed payload: one exclusive prefix value per LANE GROUP, u64[lane_groups + 1] (the last
 // element and *d_total = sum of all lengths); pack / stage add the wave prefix of the group's own lengths.
 // launch_encode_slices leaves the group sums in d_group_off itself when encoder_writes_group_sums(g); otherwise (and

@@ -491,13 +491,18 @@ __device__ __forceinline__ void clear_lds_states() {
 // SNAP: slices of several rows whose states were replayed ahead of the coder (snapshot_kernels.hip): `sym` is then the array of
 // folded residuals (i16) and `states` the array of state banks as they stand BEFORE each sample (u64), both in stream order
 // and in the piece layout [lane group][piece][lane][32 bytes] -- the kernel reads them front to back and touches no table.
-template <int NCH, bool ROWS, typename SYM, bool LDSTAB = false, bool SNAP = false>
+// SEG (SNAP only; slices above 4096 samples, whose snapshot pass runs chunk after chunk): the launch codes samples [seg_first,
+// seg_first + 4096) of every slice and parks the lane's coder -- low, range, the staged bytes, the count of flushed ones -- in a
+// 64-byte record per slice (`seg_state`) for the launch that codes the next segment, so that the coding of chunk c runs while the
+// pass prepares chunk c + 1 on another stream (codec.hip).  The last segment of a slice finishes its stream as ever.
+template <int NCH, bool ROWS, typename SYM, bool LDSTAB = false, bool SNAP = false, bool SEG = false>
 __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const uint32_t lpw,
                                                       const SYM* __restrict__ sym, uint64_t* __restrict__ states,
                                                       uint8_t* __restrict__ scratch, uint32_t* __restrict__ slice_len,
                                                       uint64_t* __restrict__ group_sum, uint32_t* status, const uint64_t gpat,
-                                                      unsigned long long* __restrict__ counters) {
-    static_assert(!(SNAP && (ROWS || LDSTAB)), "one kernel family at a time");
+                                                      unsigned long long* __restrict__ counters, const uint32_t seg_first = 0,
+                                                      uint32_t* __restrict__ seg_state = nullptr) {
+    static_assert(!(SNAP && (ROWS || LDSTAB)) && (SNAP || !SEG), "one kernel family at a time");
     constexpr bool ASM = (ROWS || SNAP) && LLMI_ASM_ENC != 0;
     entry_t* tab;
     uint8_t* stage;
@@ -568,6 +573,22 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
             i = min(i, cap - 1);
             return *reinterpret_cast<const uint2*>(gbank + size_t(i >> 3) * (2 * row) + ((i & 7u) << 3) + 2 * lofs);  // 64-byte pieces
         };
+        uint32_t i = 0, end = total;
+        [[maybe_unused]] uint32_t* const rec = SEG ? seg_state + size_t(id) * 16 : nullptr;  // this slice's parked coder (64 bytes)
+        if constexpr (SEG) {
+            if (seg_first >= total) return;  // this slice ended in an earlier segment (its length is written)
+            i = seg_first;
+            end = min(total, seg_first + kSnapMaxSamples);
+            if (seg_first) {  // take the coder up where the previous segment's launch left it
+                const uint4 a = *reinterpret_cast<const uint4*>(rec), b = *reinterpret_cast<const uint4*>(rec + 4);
+                const uint4 s0 = *reinterpret_cast<const uint4*>(rec + 8), s1 = *reinterpret_cast<const uint4*>(rec + 12);
+                e.low = a.x; e.range = a.y; e.wp = e.base + a.z; e.flushed = int32_t(a.w);
+                e.carries = b.x; hot = b.y != 0;
+                e.oofs += (uint32_t(e.flushed) >> 4) * e.ostep;
+                uint32_t* const st = reinterpret_cast<uint32_t*>(e.area);
+                st[0] = s0.x; st[1] = s0.y; st[2] = s0.z; st[3] = s0.w; st[4] = s1.x; st[5] = s1.y; st[6] = s1.z; st[7] = s1.w;
+            }
+        }
 #if LLMI_ASM_ENC
         // the hand-written sample in its snapshot form (enc_sample_asm.inc, LL_SNAP): the bank arrives in two registers and no
         // state is written back anywhere
@@ -592,12 +613,11 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
         // in well under a microsecond, an HBM round trip under load takes two: bank and residual are requested FOUR samples
         // ahead, through four register slots that the 4x unrolled bulk loop rotates statically.  The bulk runs under a scalar
         // counter when all slices of the wavefront are equally long; what is left takes the loop with the per-lane test.
-        const uint32_t total0 = __builtin_amdgcn_readfirstlane(total);
-        const bool same = __builtin_amdgcn_ballot_w64(total != total0) == 0;
-        const uint32_t n_bulk = same ? total0 & ~3u : 0;
-        int r0 = load_res(0), r1 = load_res(1), r2 = load_res(2), r3 = load_res(3);
-        uint2 b0 = load_bank(0), b1 = load_bank(1), b2 = load_bank(2), b3 = load_bank(3);
-        uint32_t i = 0;
+        const uint32_t todo = end - i, todo0 = __builtin_amdgcn_readfirstlane(todo);
+        const bool same = __builtin_amdgcn_ballot_w64(todo != todo0) == 0;
+        const uint32_t n_bulk = i + (same ? todo0 & ~3u : 0);  // (i is wave-uniform: 0, or the segment's first sample)
+        int r0 = load_res(i), r1 = load_res(i + 1), r2 = load_res(i + 2), r3 = load_res(i + 3);
+        uint2 b0 = load_bank(i), b1 = load_bank(i + 1), b2 = load_bank(i + 2), b3 = load_bank(i + 3);
 #define LLMI_SNAP_SAMPLE(R, B, AHEAD)                          \
         {                                                          \
             const int rc = int(consume_here(uint32_t(R)));        \
@@ -614,7 +634,7 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
             LLMI_SNAP_SAMPLE(r2, b2, 6)
             LLMI_SNAP_SAMPLE(r3, b3, 7)
         }
-        for (; i < total; ++i) {  // (slot 0 always holds sample i here: the slots move down by one)
+        for (; i < end; ++i) {  // (slot 0 always holds sample i here: the slots move down by one)
             LLMI_SNAP_SAMPLE(r0, b0, 4)
             {
                 const int tr = r0;
@@ -628,6 +648,16 @@ __global__ __launch_bounds__(64) void k_encode_slices(const Geometry g, const ui
         e.low = uint32_t(low_range);
         e.range = uint32_t(low_range >> 32);
 #endif
+        if constexpr (SEG) {
+            if (end < total) {  // the slice goes on: park the coder for the next segment's launch
+                const uint32_t* const st = reinterpret_cast<const uint32_t*>(e.area);
+                *reinterpret_cast<uint4*>(rec) = make_uint4(e.low, e.range, e.wp - e.base, uint32_t(e.flushed));
+                *reinterpret_cast<uint4*>(rec + 4) = make_uint4(e.carries, hot ? 1u : 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(rec + 8) = make_uint4(st[0], st[1], st[2], st[3]);
+                *reinterpret_cast<uint4*>(rec + 12) = make_uint4(st[4], st[5], st[6], st[7]);
+                return;
+            }
+        }
     } else if constexpr (ROWS) {
         // contexts 0 / 605 / 1210 only: their state bytes sit in LDS, [context][lane] (a read + a write per sample
         // instead of selecting among / writing back to three register pairs: twelve v_cndmask)
@@ -1429,7 +1459,21 @@ hipError_t allow_big_lds(K kernel) {  // more than the default 64 KB of LDS per 
                                int(kLdsTableBytes));
 }
 
-bool encoder_writes_group_sums(const Geometry& g) { return g.lpw == (1u << g.lane_shift); }
+// (not when the coder runs in segments -- slices above 4096 samples through the snapshot pass: a lane whose slice ended in an earlier
+// segment is not there when the last one adds up)
+static bool coder_in_segments(const Geometry& g) { return (g.flags & kGeoSnapshot) != 0 && snapshot_chunks(g) > 1; }
+bool encoder_writes_group_sums(const Geometry& g) { return g.lpw == (1u << g.lane_shift) && !coder_in_segments(g); }
+
+// One segment (4096 samples of every slice) of the snapshot coder: launch_snapshot has prepared banks and residuals of that chunk.
+hipError_t launch_encode_segment(const Geometry& g, const void* d_res, uint64_t* d_banks, uint8_t* d_scratch, uint32_t* d_slice_len,
+                                 uint32_t* d_status, unsigned long long* d_counters, uint32_t seg_first, uint32_t* d_seg_state,
+                                 hipStream_t stream) {
+    if (!coder_in_segments(g) || !d_seg_state) return hipErrorInvalidValue;
+    const uint32_t blocks = (g.n_slices + g.lpw - 1) / g.lpw;
+    k_encode_slices<0, false, uint32_t, false, true, true><<<dim3(blocks), dim3(64), LLMI_ASM_ENC ? kRowsEncLdsBytes : 0, stream>>>(
+        g, g.lpw, static_cast<const uint32_t*>(d_res), d_banks, d_scratch, d_slice_len, nullptr, d_status, 0, d_counters, seg_first, d_seg_state);
+    return hipGetLastError();
+}
 
 // generation (1..255) -> the tag bits of a bank: bit i of the generation in the top bit of state byte i; 0 for tables in LDS
 uint64_t state_generation_tag(uint32_t generation) {
@@ -1463,7 +1507,7 @@ hipError_t launch_encode_slices(const Geometry& g, const void* d_sym, uint64_t* 
             if (e != hipSuccess) return e;
         }
         kernel<<<dim3(blocks), dim3(64), T ? kLdsTableBytes : (R && LLMI_ASM_ENC ? kRowsEncLdsBytes : 0), stream>>>(
-            g, lpw, static_cast<const uint32_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status, gpat, d_counters);
+            g, lpw, static_cast<const uint32_t*>(d_sym), d_states, d_scratch, d_slice_len, d_group_sum, d_status, gpat, d_counters, 0u, nullptr);
     });
     return hipGetLastError();
 }

@@ -484,33 +484,40 @@ bool snapshot_chunked(const Geometry& g) { return snapshot_mode(g) && snapshot_c
 uint64_t snapshot_elems(const Geometry& g) { return (uint64_t(lane_groups(g)) * snapshot_cap(g)) << g.lane_shift; }
 
 hipError_t launch_snapshot(const Geometry& g, const uint32_t* d_sym, void* d_entries, void* d_sorted, void* d_banks, void* d_residuals,
-                           void* d_ctx16, void* d_io, uint64_t* d_states, uint64_t gpat, hipStream_t stream) {
+                           hipStream_t stream) {
+    if (snapshot_chunked(g)) return hipErrorInvalidValue;  // (chunk after chunk: launch_snapshot_chunk)
     const uint32_t cap = snapshot_cap(g);
     const uint32_t groups = lane_groups(g);
     const uint32_t blocks = (((groups + 7u) >> 3) << 3) << g.lane_shift;  // whole rounds of eight lane groups (one per XCD)
     const uint32_t waves = (g.n_slices + g.lpw - 1) / g.lpw;
     const dim3 walk_grid((waves + kWalkThreads / 64 - 1) / (kWalkThreads / 64));
     uint8_t* const entries = static_cast<uint8_t*>(d_entries);
-    if (!snapshot_chunked(g)) {
-        if (cap <= 4 * kSortThreads) k_snap_sort<4><<<dim3(blocks), dim3(kSortThreads), 0, stream>>>(g, cap, d_sym, entries, 0, nullptr, nullptr, nullptr, 0);
-        else if (cap <= 8 * kSortThreads) k_snap_sort<8><<<dim3(blocks), dim3(kSortThreads), 0, stream>>>(g, cap, d_sym, entries, 0, nullptr, nullptr, nullptr, 0);
-        else k_snap_sort<16><<<dim3(blocks), dim3(kSortThreads), 0, stream>>>(g, cap, d_sym, entries, 0, nullptr, nullptr, nullptr, 0);
-        k_snap_walk<false><<<walk_grid, dim3(kWalkThreads), 0, stream>>>(g, g.lpw, cap, entries, static_cast<uint8_t*>(d_sorted), 0, nullptr, nullptr, nullptr, 0);
-        k_snap_unperm<<<dim3(blocks), dim3(kUnpermThreads), 0, stream>>>(g, cap, entries, static_cast<const uint8_t*>(d_sorted),
-                                                                         static_cast<uint8_t*>(d_banks), static_cast<uint8_t*>(d_residuals), 0);
-        return hipGetLastError();
-    }
-    // slices above 4096 samples: chunk after chunk, in stream order (chunk c + 1 sorts -- and fetches its runs' starting states --
-    // behind chunk c's walk, which left them in the table)
-    if (!d_ctx16 || !d_io || !d_states) return hipErrorInvalidValue;
-    for (uint32_t c = 0; c < snapshot_chunks(g); ++c) {
-        k_snap_sort<16, true><<<dim3(blocks), dim3(kSortThreads), 0, stream>>>(g, cap, d_sym, entries, c, static_cast<uint8_t*>(d_ctx16),
-                                                                               static_cast<uint8_t*>(d_io), d_states, gpat);
-        k_snap_walk<true><<<walk_grid, dim3(kWalkThreads), 0, stream>>>(g, g.lpw, cap, entries, static_cast<uint8_t*>(d_sorted), c,
-                                                                        static_cast<const uint8_t*>(d_ctx16), static_cast<const uint8_t*>(d_io), d_states, gpat);
-        k_snap_unperm<<<dim3(blocks), dim3(kUnpermThreads), 0, stream>>>(g, cap, entries, static_cast<const uint8_t*>(d_sorted),
-                                                                         static_cast<uint8_t*>(d_banks), static_cast<uint8_t*>(d_residuals), c * kSnapMaxSamples);
-    }
+    if (cap <= 4 * kSortThreads) k_snap_sort<4><<<dim3(blocks), dim3(kSortThreads), 0, stream>>>(g, cap, d_sym, entries, 0, nullptr, nullptr, nullptr, 0);
+    else if (cap <= 8 * kSortThreads) k_snap_sort<8><<<dim3(blocks), dim3(kSortThreads), 0, stream>>>(g, cap, d_sym, entries, 0, nullptr, nullptr, nullptr, 0);
+    else k_snap_sort<16><<<dim3(blocks), dim3(kSortThreads), 0, stream>>>(g, cap, d_sym, entries, 0, nullptr, nullptr, nullptr, 0);
+    k_snap_walk<false><<<walk_grid, dim3(kWalkThreads), 0, stream>>>(g, g.lpw, cap, entries, static_cast<uint8_t*>(d_sorted), 0, nullptr, nullptr, nullptr, 0);
+    k_snap_unperm<<<dim3(blocks), dim3(kUnpermThreads), 0, stream>>>(g, cap, entries, static_cast<const uint8_t*>(d_sorted),
+                                                                     static_cast<uint8_t*>(d_banks), static_cast<uint8_t*>(d_residuals), 0);
+    return hipGetLastError();
+}
+
+// Slices above 4096 samples: chunk c of every slice.  The chunks go in stream order (chunk c + 1 sorts -- and fetches its runs'
+// starting states -- behind chunk c's walk, which left them in the table); the coder of chunk c needs nothing of chunk c + 1.
+hipError_t launch_snapshot_chunk(const Geometry& g, uint32_t c, const uint32_t* d_sym, void* d_entries, void* d_sorted, void* d_banks,
+                                 void* d_residuals, void* d_ctx16, void* d_io, uint64_t* d_states, uint64_t gpat, hipStream_t stream) {
+    if (!snapshot_chunked(g) || c >= snapshot_chunks(g) || !d_ctx16 || !d_io || !d_states) return hipErrorInvalidValue;
+    const uint32_t cap = snapshot_cap(g);
+    const uint32_t groups = lane_groups(g);
+    const uint32_t blocks = (((groups + 7u) >> 3) << 3) << g.lane_shift;
+    const uint32_t waves = (g.n_slices + g.lpw - 1) / g.lpw;
+    const dim3 walk_grid((waves + kWalkThreads / 64 - 1) / (kWalkThreads / 64));
+    uint8_t* const entries = static_cast<uint8_t*>(d_entries);
+    k_snap_sort<16, true><<<dim3(blocks), dim3(kSortThreads), 0, stream>>>(g, cap, d_sym, entries, c, static_cast<uint8_t*>(d_ctx16),
+                                                                           static_cast<uint8_t*>(d_io), d_states, gpat);
+    k_snap_walk<true><<<walk_grid, dim3(kWalkThreads), 0, stream>>>(g, g.lpw, cap, entries, static_cast<uint8_t*>(d_sorted), c,
+                                                                    static_cast<const uint8_t*>(d_ctx16), static_cast<const uint8_t*>(d_io), d_states, gpat);
+    k_snap_unperm<<<dim3(blocks), dim3(kUnpermThreads), 0, stream>>>(g, cap, entries, static_cast<const uint8_t*>(d_sorted),
+                                                                     static_cast<uint8_t*>(d_banks), static_cast<uint8_t*>(d_residuals), c * kSnapMaxSamples);
     return hipGetLastError();
 }
 

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 import pytest  # noqa: E402
 
-HOOKS = ("LLCOMP_MI_LANE_SHIFT", "LLCOMP_MI_NOROWS", "LLCOMP_MI_NOLDSTAB", "LLCOMP_MI_FORCE_REPLAY", "LLCOMP_MI_NOSNAP", "LLCOMP_MI_NOCACHE")
+HOOKS = ("LLCOMP_MI_LANE_SHIFT", "LLCOMP_MI_NOROWS", "LLCOMP_MI_NOLDSTAB", "LLCOMP_MI_FORCE_REPLAY", "LLCOMP_MI_NOSNAP", "LLCOMP_MI_NOCACHE", "LLCOMP_MI_OVERLAP")
 
 
 def make(rng, w, h, c, kind):
@@ -252,6 +252,8 @@ def run_chunked_case(mi, orc, seed):
     w, h = min(w, 1500), min(h, 900)
     img = make(rng, w, h, c, int(rng.integers(0, 5)))
     env = {"LLCOMP_MI_NOSNAP": "1"} if rng.random() < 0.15 else {}
+    if rng.random() < 0.3:
+        env["LLCOMP_MI_OVERLAP"] = "1"
     env["LLCOMP_MI_LANE_SHIFT"] = str(int(rng.integers(2, 7)))  # (so few big slices would otherwise get one wavefront each and their table in LDS)
     for k in HOOKS:
         os.environ.pop(k, None)
