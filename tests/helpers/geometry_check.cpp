@@ -17,6 +17,9 @@ int main() {
     show("tiles_4k_64x64", 16, 3840, 2160, 3, 64, 64, 1);
     show("tiles_4k_32x32_interleaved", 16, 3840, 2160, 3, 32, 32, 0);
     show("tiles_4k_128x128", 16, 3840, 2160, 3, 128, 128, 1);
+    show("tiles_4k_64x64_interleaved", 16, 3840, 2160, 3, 64, 64, 0);
+    show("tiles_4k_256x256", 16, 3840, 2160, 3, 256, 256, 1);
+    show("tiles_4k_128x129", 16, 3840, 2160, 3, 128, 129, 1);
     show("one_frame_256x256", 1, 3840, 2160, 3, 256, 256, 1);
     show("legacy_bulk_512", 512, 256, 256, 3, 256, 256, 0);
     show("lone_legacy", 1, 1920, 1080, 3, 0, 0, 0);

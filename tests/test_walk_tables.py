@@ -19,16 +19,17 @@ def test_walk_tables_equal_the_state_machine_over_the_binarisation(tmp_path):
 
 def test_geometry_selects_the_kernel_family(tmp_path):
     """llcomp_amd/csrc/geometry.hpp (host + device header): one-row slices keep three contexts on chip (kGeoRows = 1), a lone slice
-    per wavefront keeps its table in LDS (kGeoLdsTable = 2; also chosen for up to 512 big slices), 2-D slices of at most 4096
-    samples that share a wavefront get the snapshot encoder (kGeoSnapshot = 16) unless the tuning hook forbids it, bigger 2-D
-    slices keep tables in HBM both ways; every family with tables in HBM and at most four channels per slice decodes through the
+    per wavefront keeps its table in LDS (kGeoLdsTable = 2; also chosen for up to 512 big slices), 2-D slices of at most 16384
+    samples (four chunks of 4096: 128x128 planes, 64x64 interleaved RGB) that share a wavefront get the snapshot encoder
+    (kGeoSnapshot = 16) unless the tuning hook forbids it, bigger 2-D slices (256x256 planes, 128x129) keep tables in HBM both ways; every family with tables in HBM and at most four channels per slice decodes through the
     bank cache in LDS (kGeoBankCache = 32) unless LLCOMP_MI_NOCACHE forbids it."""
     exe = str(tmp_path / "geometry_check")
     subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "llcomp_amd", "csrc"), "-o", exe,
                            os.path.join(ROOT, "tests", "helpers", "geometry_check.cpp")])
     rows = {ln.split()[0]: [int(x) for x in ln.split()[1:]] for ln in subprocess.check_output([exe], text=True).splitlines()}
     flags = {k: v[0] for k, v in rows.items()}
-    assert flags == {"rows_4k_480x1": 1, "tiles_4k_64x64": 48, "tiles_4k_32x32_interleaved": 48, "tiles_4k_128x128": 32,
+    assert flags == {"rows_4k_480x1": 1, "tiles_4k_64x64": 48, "tiles_4k_32x32_interleaved": 48, "tiles_4k_128x128": 48,
+                     "tiles_4k_64x64_interleaved": 48, "tiles_4k_256x256": 32, "tiles_4k_128x129": 32,
                      "one_frame_256x256": 2, "legacy_bulk_512": 2, "lone_legacy": 2, "tiles_4k_64x64_nosnap": 32,
                      "rows_forced_general": 48, "nine_channels_one_row": 2, "tiles_4k_64x64_nocache": 16, "nine_channels_tiles": 16}
     assert rows["tiles_4k_64x64"][1:] == [6, 64, 97920, 4096]      # lane_shift, slices per wavefront, slices, samples per slice
