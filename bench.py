@@ -1075,7 +1075,9 @@ def main():
                     try:
                         # (a launcher that narrows every rank's view to its own GPU leaves rank 0 fewer ordinals than ranks: it then drives what it sees)
                         seen = mi.device_count() if Hooks.device == "cuda" else world
-                        box["out"] = Hooks.inprocess(list(range(max(1, min(world, seen)))), images=max(2, min(4, args.c4_images)), size=size, tile_w=args.c4_tile_w, tile_h=args.c4_tile_h)
+                        # (the one-GPU rehearsal repeats its one ordinal, so that the list path -- a lane and a thread per part -- runs beside the waiting ranks)
+                        devs = [local_rank] * min(world, 3) if args.rehearse_one_gpu else list(range(max(1, min(world, seen))))
+                        box["out"] = Hooks.inprocess(devs, images=max(2, min(4, args.c4_images)), size=size, tile_w=args.c4_tile_w, tile_h=args.c4_tile_h)
                     except BaseException as e:  # noqa: BLE001
                         box["err"] = f"{type(e).__name__}: {e}"[:300]
 

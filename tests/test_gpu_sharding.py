@@ -182,3 +182,7 @@ def test_bench_line_from_four_ranks_rehearsed_on_one_gpu():
     assert c4.get("ranks_seen") == 4 and c4["value"] > 0 and c4["scaling"] == "strong" and c4["images_per_step"] == 4, c4
     c5 = d["c5_replica_pcie"]
     assert c5["ranks_ok"] == 4 and c5["value"] > 0, c5
+    # the device-list leg: rank 0 alone through llcomp_mi_opts.devices (here {0,0,0}: three lanes on the one GPU) while three ranks wait on the store
+    ip = d["c4_inprocess_devices"]
+    assert "failed" not in ip and ip["value"] > 0 and ip["devices"] == [0, 0, 0] and ip["ranks_waiting"] == 3 and ip["golden_pin"], ip
+    assert list(d)[-1] == "c4_inprocess_devices"
