@@ -115,6 +115,28 @@ int next_state_generation(llcomp_mi_codec* k, hipStream_t s) {
     return LLCOMP_MI_OK;
 }
 
+// LLCOMP_MI_OVERLAP=2: one second stream per device for the snapshot passes of ALL codec objects (created once, never destroyed)
+hipStream_t shared_second_stream(int device) {
+    static std::mutex mu;
+    static hipStream_t streams[64] = {};
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!streams[device]) {
+        // the highest priority: priority streams sit on hardware queues of their own.  An ordinary stream can land on the queue the
+        // caller's stream uses (the NULL stream of a one-pipeline caller did: no overlap at all, 2 419 instead of 2 731 MPix/s at 16
+        // frames of 128x128 planes, 3 844 instead of 4 410 at 32; profiles/r06_chunked_snapshot_ab.txt)
+        int least = 0, greatest = 0;
+        const bool prio = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+        const hipError_t rc = prio ? hipStreamCreateWithPriority(&streams[device], hipStreamNonBlocking, greatest)
+                                   : hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking);
+        if (rc != hipSuccess) {
+            (void)hipGetLastError();
+            streams[device] = nullptr;
+        }
+    }
+    return streams[device];
+}
+
 // the snapshot pass's arrays (2-D encoder): allocated by the first encode -- a decode-only codec never pays for them
 int ensure_snapshot_arrays(llcomp_mi_codec* k) {
     if (k->d_snap_sorted) return LLCOMP_MI_OK;
@@ -136,7 +158,8 @@ int ensure_snapshot_arrays(llcomp_mi_codec* k) {
         if (dev_alloc(reinterpret_cast<void**>(&k->d_seg_state), uint64_t(k->g.n_slices) * 64) != hipSuccess) { k->d_seg_state = nullptr; return LLCOMP_MI_NOMEM; }
         k->allocated_bytes += uint64_t(k->g.n_slices) * 64;
         if (k->overlap) {
-            bool ok = hipStreamCreateWithFlags(&k->aux, hipStreamNonBlocking) == hipSuccess &&
+            bool ok = (k->aux_shared ? (k->aux = shared_second_stream(k->device)) != nullptr
+                                     : hipStreamCreateWithFlags(&k->aux, hipStreamNonBlocking) == hipSuccess) &&
                       hipEventCreateWithFlags(&k->ev_fork, hipEventDisableTiming) == hipSuccess;
             for (uint32_t c = 0; ok && c < snapshot_chunks(k->g); ++c) ok = hipEventCreateWithFlags(&k->ev_chunk[c], hipEventDisableTiming) == hipSuccess;
             if (!ok) {  // no second stream to be had: the pass runs on the caller's (slower at few frames in flight, same bytes)
@@ -233,7 +256,7 @@ void codec_release(llcomp_mi_codec* k) {
     // (the second stream's work of a call is joined into the caller's stream before the call's last kernels: behind k->done it is idle)
     if (k->ev_fork) (void)hipEventDestroy(k->ev_fork);
     for (auto& ev : k->ev_chunk) if (ev) (void)hipEventDestroy(ev);
-    if (k->aux) (void)hipStreamDestroy(k->aux);
+    if (k->aux && !k->aux_shared) (void)hipStreamDestroy(k->aux);
     dev_free(k->d_counters, k->done);
     if (k->fb_event) (void)hipEventDestroy(k->fb_event);  // (legal while pending: released when it completes)
     if (k->h_feedback) {
@@ -307,7 +330,8 @@ int llcomp_mi_codec_create_ex(llcomp_mi_codec** out, int32_t device, uint32_t fr
     k->g = g;
     k->device = dev;
     k->feedback = !current_tuning().nofeedback;
-    k->overlap = current_tuning().overlap;
+    k->overlap = current_tuning().overlap != 0;
+    k->aux_shared = current_tuning().overlap == 2;
     const uint64_t samples = uint64_t(frames) * w * h * c;
     k->need_states = slices_need_state_tables(g);
     // the fused row path (planar 1-row slices) has no image-order intermediate and 16-bit lane-order arrays in both directions
@@ -405,12 +429,13 @@ int llcomp_mi_codec_encode(llcomp_mi_codec* k, const void* d_px, void* d_payload
     }
     if (snapshot_mode(g) && snapshot_chunked(g)) {
         // Slices above 4096 samples: pass and coder chunk by chunk.  The pass of chunk c + 1 needs the WALK of chunk c (the contexts'
-        // states travel through the table), the coder of chunk c needs the pass of chunk c only.  Default: everything in order on the
-        // caller's stream.  LLCOMP_MI_OVERLAP=1: the pass runs ahead on the codec's own second stream and the coder follows on the
-        // caller's, each segment behind its chunk's event -- a launch of such slices is a few hundred wavefronts, one wavefront's
-        // dependent chain, and the pass's nine or twelve launches in front of it cost 8-11 % against the table encoder at few frames
-        // in flight; beside it they are hidden (one or two pipelines: +1..+27 %), but with three pipelines' six streams the step got
-        // 25 % SLOWER than in order (profiles/r06_chunked_snapshot_ab.txt), so it is a hook, not the default.
+        // states travel through the table), the coder of chunk c needs the pass of chunk c only: so the pass runs AHEAD on a second
+        // stream and the coder follows on the caller's, each segment behind its chunk's event (fork / join: the caller's stream still
+        // orders everything).  A launch of such slices is a few hundred wavefronts -- one wavefront's dependent chain -- and the
+        // pass's nine or twelve launches in FRONT of it cost 8-11 % against the table encoder at few frames in flight; beside it they
+        // are hidden.  The second stream is ONE PER DEVICE, shared by all codec objects (the passes are throughput kernels: they may
+        // queue behind each other): a second stream per codec left the GPU idle as soon as three pipelines made six streams (25 %
+        // below in-order; more hardware queues change nothing) -- profiles/r06_chunked_snapshot_ab.txt.  LLCOMP_MI_OVERLAP=0: in order.
         if (int rc = ensure_snapshot_arrays(k)) return rc;
         const uint64_t gpat = state_generation_tag(k->state_generation);
         const uint32_t chunks = snapshot_chunks(g);

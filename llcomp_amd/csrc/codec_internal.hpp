@@ -35,12 +35,13 @@ struct llcomp_mi_codec {
     void* d_snap_ctx = nullptr;      // ... slices above 4096 samples (snapshot_chunked): the context of every sorted position (u16) and the
     void* d_snap_io = nullptr;       // states every context run of a chunk starts from (u64), both scratch of the pass
     // ... their coder runs in segments of 4096 samples (a lane parks its coder in 64 bytes per slice in between), each behind ITS chunk
-    // of the pass only; with LLCOMP_MI_OVERLAP=1 the pass works ahead of the coder on the codec's own second stream (fork / join with
-    // events, so the caller's stream still orders everything)
+    // of the pass only: the pass works ahead of the coder on a second stream (one per device, shared by all codecs; fork / join with
+    // events, so the caller's stream still orders everything; LLCOMP_MI_OVERLAP=0: in order, =1: a second stream of the codec's own)
     uint32_t* d_seg_state = nullptr;
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_chunk[llcomp_mi::kSnapMaxChunks] = {};
-    bool overlap = false;            // (LLCOMP_MI_OVERLAP=1 when the codec was made; default: everything in order on the caller's stream)
+    bool overlap = true;             // (LLCOMP_MI_OVERLAP when the codec was made)
+    bool aux_shared = true;          // (`aux` is the device's shared second stream, not this codec's to destroy)
     uint64_t workspace_bytes = 0;    // what the codec can hold at most
     uint64_t allocated_bytes = 0;    // what it holds right now (state tables / snapshot arrays come with the first call that needs them)
     // Event counters (kernels.hpp kCtr*): kernel-side u64[kCtrCount] in HBM, host-side additions, and the feedback that takes the bank

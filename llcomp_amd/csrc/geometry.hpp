@@ -59,9 +59,10 @@ struct Tuning {
     bool force_replay = false; // LLCOMP_MI_FORCE_REPLAY=1
     bool nosnap = false;       // LLCOMP_MI_NOSNAP=1: the 2-D encoder keeps its state tables in HBM (the path before round 4)
     bool nocache = false;      // LLCOMP_MI_NOCACHE=1: the 2-D decoder fetches and writes every state bank in HBM (the path before round 5)
-    bool overlap = false;      // LLCOMP_MI_OVERLAP=1: slices above 4096 samples: the snapshot pass of chunk c + 1 runs beside the coding of chunk c on a second
-                               // stream of the codec's own instead of behind it on the caller's (helps one or two pipelines at few frames in flight,
-                               // hurts three: profiles/r06_chunked_snapshot_ab.txt; off by default)
+    int overlap = 2;           // LLCOMP_MI_OVERLAP: slices above 4096 samples -- 2 (default): the snapshot pass of chunk c + 1 runs beside the coding of
+                               // chunk c on ONE second stream per device, shared by all codec objects; 1: on a second stream of the codec's own
+                               // (fine for one or two pipelines, 25 % below in-order with three: too many queues); 0: in order on the caller's
+                               // stream (profiles/r06_chunked_snapshot_ab.txt)
     bool nofeedback = false;   // LLCOMP_MI_NOFEEDBACK=1: the bank cache stays on in every launch, whatever the last one's wavefronts did with it (A/B)
 };
 inline Tuning tuning_from_env() {
@@ -81,7 +82,7 @@ inline Tuning tuning_from_env() {
     t.nosnap = flag("LLCOMP_MI_NOSNAP");
     t.nocache = flag("LLCOMP_MI_NOCACHE");
     t.nofeedback = flag("LLCOMP_MI_NOFEEDBACK");
-    t.overlap = flag("LLCOMP_MI_OVERLAP");
+    t.overlap = num("LLCOMP_MI_OVERLAP", 0, 2, 2);
     return t;
 }
 

@@ -643,10 +643,10 @@ def test_2d_encoder_snapshot_pass_or_state_tables_same_bytes(mi, orc, set_hook):
                 orc.set_small_model(False)
             # (images this small have so few slices that each would get a wavefront of its own and its table in LDS -- neither 2-D
             # encoder: the lane-group width is forced; the last round runs the geometry as the library picks it)
-            # (OVERLAP: slices above 4096 samples -- the pass of chunk c + 1 beside the coding of chunk c on the codec's second stream
-            # instead of behind it on the caller's)
-            for nosnap, shift, noov in (("0", "6", "0"), ("1", "6", "0"), ("0", "3", "0"), ("0", None, "0"), ("0", "6", "1")):
-                if noov == "1" and tw * th * (1 if planar else c) <= 4096:
+            # (OVERLAP: slices above 4096 samples -- the pass of chunk c + 1 beside the coding of chunk c on the device's shared second
+            # stream (2, the default), on one of the codec's own (1), or behind it on the caller's (0))
+            for nosnap, shift, noov in (("0", "6", None), ("1", "6", None), ("0", "3", None), ("0", None, None), ("0", "6", "0"), ("0", "6", "1")):
+                if noov is not None and tw * th * (1 if planar else c) <= 4096:
                     continue
                 set_hook("LLCOMP_MI_NOSNAP", nosnap)
                 set_hook("LLCOMP_MI_OVERLAP", noov)
@@ -654,7 +654,7 @@ def test_2d_encoder_snapshot_pass_or_state_tables_same_bytes(mi, orc, set_hook):
                 s = mi.compress_image(img, w, h, c, format=mi.FORMAT_SLICED, tile_w=tw, tile_h=th, planar=planar, small_model=small)
                 assert s == want, (w, h, c, tw, th, planar, small, nosnap, shift, noov)
                 assert np.array_equal(mi.decompress_image(s, small_model=small).pixels, img)
-    set_hook("LLCOMP_MI_OVERLAP", "0")
+    set_hook("LLCOMP_MI_OVERLAP", None)
     set_hook("LLCOMP_MI_LANE_SHIFT", "6")
     for nosnap in ("0", "1"):
         set_hook("LLCOMP_MI_NOSNAP", nosnap)

@@ -252,8 +252,8 @@ def run_chunked_case(mi, orc, seed):
     w, h = min(w, 1500), min(h, 900)
     img = make(rng, w, h, c, int(rng.integers(0, 5)))
     env = {"LLCOMP_MI_NOSNAP": "1"} if rng.random() < 0.15 else {}
-    if rng.random() < 0.3:
-        env["LLCOMP_MI_OVERLAP"] = "1"
+    if rng.random() < 0.4:
+        env["LLCOMP_MI_OVERLAP"] = str(int(rng.integers(0, 2)))  # (default 2: the device's shared second stream)
     env["LLCOMP_MI_LANE_SHIFT"] = str(int(rng.integers(2, 7)))  # (so few big slices would otherwise get one wavefront each and their table in LDS)
     for k in HOOKS:
         os.environ.pop(k, None)
