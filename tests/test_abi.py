@@ -43,6 +43,24 @@ def test_struct_layouts_match_header(mi):
     assert C.sizeof(_lib.StreamResult) == 40
 
 
+def test_header_is_plain_c_and_the_cpp_mirror_compiles(tmp_path):
+    """include/llcomp_mi.h is what a cgo / JNI / ctypes binding reads: it must compile as C99 (no C++ in the signatures), with the opts
+    struct at the size the bindings assume; include/llcomp_mi.hpp (the reference's own signatures on top, llcomp.hpp:358, 454-461) as
+    C++17 with the device list in its options"""
+    import subprocess
+
+    c = tmp_path / "h.c"
+    c.write_text('#include "llcomp_mi.h"\nint main(void) { llcomp_mi_opts o = {0}; o.struct_size = sizeof o; (void)o; '
+                 'return sizeof(llcomp_mi_opts) == 48 && sizeof(llcomp_mi_info) == 56 && sizeof(llcomp_mi_stream_result) == 40 ? 0 : 1; }\n')
+    exe = tmp_path / "h"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    assert subprocess.call([str(exe)]) == 0
+    cpp = tmp_path / "h.cpp"
+    cpp.write_text('#include "llcomp_mi.hpp"\nint main() { llcomp::Options o; o.sliced = true; o.devices = {0, 1}; o.chunks_per_device = 2; '
+                   'llcomp::RawImage r{}; (void)r; return o.devices.size() == 2 ? 0 : 1; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(cpp)])
+
+
 def test_no_cpu_fallback(mi):
     import torch
 
