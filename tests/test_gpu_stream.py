@@ -231,3 +231,63 @@ def test_cpp_stream_driver(mi):
         out = json.loads(r.stdout.strip().splitlines()[-1])
         assert out["verified"] is True and out["frames"] == int(args[0]) and out["frames_per_job"] == int(args[7])
         assert 0.5 < out["compression_ratio"] < 0.85  # xorshift noise
+
+
+def test_chunked_snapshot_pass_against_the_real_reference_and_at_4k(mi, orc, monkeypatch):
+    """Slices above 4096 samples (round 6: the snapshot pass in chunks of 4096, the coder in segments, the pass one chunk ahead on the
+    device's second stream).  (1) 1080p in 128x128 planes with the lane-group width forced to 64 -- so that its 405 slices share
+    wavefronts instead of getting one each with the table in LDS -- against the golden container made from the REAL reference's
+    per-slice streams; (2) at BASELINE's full 4K size, two frames per call through a device-resident codec object: 64x64 tiles with
+    the channels interleaved (12288 samples: three chunks) and 128x128 planes (four), every frame's table and payload against the
+    oracle's container, decoded back bit-exact; the same with the pass in order (LLCOMP_MI_OVERLAP=0)."""
+    import torch
+
+    v = golden("mid", 1920, 128, 128, True)
+    img = make_image("mid", 1920, 1080, 3)
+    monkeypatch.setenv("LLCOMP_MI_LANE_SHIFT", "6")
+    mi.reload_tuning()
+    try:
+        k = mi.Codec(1, 1920, 1080, 3, 128, 128, True)
+        assert k.family["snapshot"] and not k.family["lds_table"], k.family
+        k.close()
+        s = mi.compress_image(img, 1920, 1080, 3, format=mi.FORMAT_SLICED, tile_w=128, tile_h=128, planar=True)
+        assert len(s) == v["container_len"] and fnv_hex(orc, s) == v["container_fnv1a64"], "chunked snapshot container differs from the real reference's"
+        assert np.array_equal(mi.decompress_image(s).pixels, img)
+    finally:
+        monkeypatch.delenv("LLCOMP_MI_LANE_SHIFT")
+        mi.reload_tuning()
+    frames = np.stack([make_image("nat", 3840, 2160, 3), make_image("g3@77", 3840, 2160, 3)])
+    st = torch.cuda.current_stream().cuda_stream
+    d_px = torch.from_numpy(frames).cuda()
+    for tw, th, planar in ((64, 64, False), (128, 128, True)):
+        want = [orc.compress_sliced(frames[f], tw, th, planar) for f in range(2)]
+        for overlap in (None, "0"):
+            if overlap is not None:
+                monkeypatch.setenv("LLCOMP_MI_OVERLAP", overlap)
+            mi.reload_tuning()
+            codec = mi.Codec(2, 3840, 2160, 3, tw, th, planar)
+            assert codec.family["snapshot"] and not codec.family["lds_table"], codec.family
+            cap = min(codec.max_payload_bytes, 2 * frames.size + 64 * codec.n_slices + 4096)
+            d_pay = torch.empty(cap, dtype=torch.uint8, device="cuda")
+            d_len = torch.empty(codec.n_slices, dtype=torch.int32, device="cuda")
+            d_tot = torch.zeros(1, dtype=torch.int64, device="cuda")
+            d_st = torch.zeros(1, dtype=torch.int32, device="cuda")
+            for _ in range(2):  # twice on one object: the carry table's generation moves on, the parked coders are overwritten
+                codec.encode(d_px.data_ptr(), d_pay.data_ptr(), cap, d_len.data_ptr(), d_tot.data_ptr(), d_st.data_ptr(), st)
+            torch.cuda.synchronize()
+            assert int(d_st.item()) == 0
+            total, spf = int(d_tot.item()), codec.n_slices // 2
+            lens = d_len.cpu().numpy().astype(np.int64)
+            pay = d_pay[:total].cpu().numpy().tobytes()
+            offs = np.concatenate([[0], np.cumsum(lens)])
+            for f in range(2):
+                assert lens[f * spf:(f + 1) * spf].astype("<u4").tobytes() == want[f][24:24 + 4 * spf], (tw, th, f, overlap)
+                assert pay[offs[f * spf]:offs[(f + 1) * spf]] == want[f][24 + 4 * spf:], (tw, th, f, overlap)
+            d_out = torch.zeros_like(d_px)
+            codec.decode(d_pay.data_ptr(), total, d_len.data_ptr(), d_out.data_ptr(), d_st.data_ptr(), st)
+            torch.cuda.synchronize()
+            assert int(d_st.item()) == 0 and torch.equal(d_out, d_px)
+            codec.close()
+            if overlap is not None:
+                monkeypatch.delenv("LLCOMP_MI_OVERLAP")
+                mi.reload_tuning()
