@@ -421,7 +421,7 @@ def link_rate(n=256 << 20, reps=6, streams=None):
     return out
 
 
-def c5_stream(frames_np, tile_w, tile_h, planar, depth=6, frames_per_job=8, pipelines=2, encodes_in_flight=2, passes=4, pin=True, verify=True, link=None):
+def c5_stream(frames_np, tile_w, tile_h, planar, depth=6, frames_per_job=8, pipelines=2, encodes_in_flight=2, passes=4, pin=True, verify=True, link=None, devices=None):
     """BASELINE config 5, PCIe inclusive: the frames stream host -> GPU -> host (container) -> GPU -> host through the
     product's pipeline (llcomp_mi_stream_*, jobs of `frames_per_job` frames), `passes` times over the batch; every frame verified
     bit-exact.  `pipelines` stream objects, each driven by its own thread over its own share of the frames: one pipeline
@@ -440,7 +440,9 @@ def c5_stream(frames_np, tile_w, tile_h, planar, depth=6, frames_per_job=8, pipe
     pinned = mi.PinnedBuffer(F * h * w * c)
     pinned.array[:] = frames_np[:F].reshape(-1)
     views = [pinned.array[i * h * w * c:(i + 1) * h * w * c].reshape(h, w, c) for i in range(F)]
-    sts = [mi.Stream(w, h, c, tile_w, tile_h, planar, depth=depth, frames_per_job=frames_per_job) for _ in range(pipelines)]
+    # devices: every pipeline object is a dealer over that device list (llcomp_mi_stream_create_multi: one pipeline of `depth` slots per
+    # device behind one object, jobs dealt round-robin, results in submission order)
+    sts = [mi.Stream(w, h, c, tile_w, tile_h, planar, depth=depth, frames_per_job=frames_per_job, devices=devices) for _ in range(pipelines)]
     res, errs = [None] * pipelines, []
     origin = time.perf_counter()
 
@@ -1185,6 +1187,13 @@ def main():
             leg["spread"] = round((runs[-1]["value"] - runs[0]["value"]) / runs[-1]["value"], 3)
             leg["note"] = "median of three repetitions in this process; " + leg["note"]
             also["c5_stream_pcie"] = leg
+            # the same frames through ONE pipeline object that deals its jobs over a device list ({0,0}: two pipelines of six slots on
+            # the one GPU behind one object -- the same twelve slots as above --, ONE driving thread) -- config 5's "round-robin over
+            # the GPUs" from one process
+            dl = c5_stream(frames_np, args.tile_w, args.tile_h, planar, depth=6, pipelines=1, encodes_in_flight=4, passes=4, link=link, devices=[local_rank, local_rank])
+            dl["devices"] = [local_rank, local_rank]
+            dl["note"] = "one llcomp_mi_stream_create_multi object over {0,0}, one driving thread; " + dl["note"]
+            also["c5_stream_device_list"] = dl
 
         def leg_c4():
             n4 = max(4, sub // 2)

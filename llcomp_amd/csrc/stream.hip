@@ -24,8 +24,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <deque>
+#include <thread>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -420,10 +422,19 @@ int llcomp_mi_stream_wait(llcomp_mi_stream* s, llcomp_mi_stream_result* r) {
             if (s->order.empty()) return LLCOMP_MI_BAD_ARGS;
             i = s->order.front();  // (single consumer: the oldest job cannot change while this thread waits for it)
         }
-        // the other devices' size mailboxes keep arriving while this thread blocks on the oldest job's pipeline: let them queue their
-        // container copies first (a pipeline pumps itself only when somebody enters it)
-        for (uint32_t j = 0; j < s->subs.size(); ++j)
-            if (j != i) (void)llcomp_mi_stream_poll(s->subs[j]);
+        // HIP has no "wait for any of these events", and a pipeline queues the container copy of a job only when somebody enters it
+        // (pump): blocking on the oldest job's pipeline alone would leave the size mailboxes of the OTHER devices' younger jobs
+        // unanswered for as long as the oldest job takes (measured: 4.9 instead of 6.3 GPix/s through {0,0}).  So the dealer looks at
+        // every pipeline's events in turn, 50 us apart, until the oldest job is ready; the blocking wait below then returns at once.
+        for (;;) {
+            int oldest_ready = LLCOMP_MI_BUSY;
+            for (uint32_t j = 0; j < s->subs.size(); ++j) {
+                const int q = llcomp_mi_stream_poll(s->subs[j]);
+                if (j == i) oldest_ready = q;
+            }
+            if (oldest_ready != LLCOMP_MI_BUSY) break;
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
         if (int rc = llcomp_mi_stream_wait(s->subs[i], r)) return rc;
         r->slot |= i << 8;
         std::lock_guard<std::mutex> lock(s->mu);
