@@ -138,7 +138,8 @@ void* llcomp_mi_host_alloc(size_t bytes); /* pinned host memory, NULL on failure
 void llcomp_mi_host_free(void* p);
 const char* llcomp_mi_strerror(int status);
 int llcomp_mi_abi_version(void);
-/* Test / tuning hooks (LLCOMP_MI_LPW, _LANE_SHIFT, _NOROWS, _NOLDSTAB, _FORCE_REPLAY; none changes an output byte) are
+/* Test / tuning hooks (LLCOMP_MI_LPW, _LANE_SHIFT, _NOROWS, _NOLDSTAB, _NOSNAP, _NOCACHE, _NOFEEDBACK, _OVERLAP, _FORCE_REPLAY; none
+ * changes an output byte) are
  * read from the environment once per process; a test that changes them calls this to have them read again. */
 void llcomp_mi_reload_tuning(void);
 /* Number of usable HIP devices (0 when there is none; never fails). */
