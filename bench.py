@@ -993,6 +993,7 @@ def main():
             raise SystemExit(4)
         dog = Watchdog(rank, res)
         dog.arm(args.legs_timeout, "c4_sharded + c5_replica_pcie + c4_inprocess_devices")
+        t_legs = time.perf_counter()
         empty_cache = torch.cuda.empty_cache if DEV == "cuda" else (lambda: None)
         # ---- BASELINE config 4: strong scaling of sharded 8192^2 images, gather + scatter inside the timed region -------
         size, B = args.c4_size, args.c4_images
@@ -1083,9 +1084,14 @@ def main():
                     except BaseException as e:  # noqa: BLE001
                         box["err"] = f"{type(e).__name__}: {e}"[:300]
 
+                # (its deadline also stays clear of the watchdog's: what is left of --legs-timeout minus 30 s)
+                budget = min(150.0, args.legs_timeout - (time.perf_counter() - t_legs) - 30.0)
                 th = threading.Thread(target=work, daemon=True)
-                th.start()
-                th.join(min(150.0, max(30.0, args.legs_timeout / 2)))
+                if budget >= 20.0:
+                    th.start()
+                    th.join(budget)
+                else:
+                    box["err"] = "skipped: the legs before it left less than 50 s of --legs-timeout"
                 if th.is_alive():
                     inproc, hung = {"failed": "not finished after its own deadline; the line goes out without it"}, True
                 elif "err" in box:
