@@ -131,10 +131,11 @@ void for_each_part(std::vector<Part>& parts, Fn fn) {
 
 bool is_data_verdict(int rc) { return rc == LLCOMP_MI_BAD_EXPONENT || rc == LLCOMP_MI_TRUNCATED || rc == LLCOMP_MI_OUTPUT_OVERFLOW; }
 
-// the first failing part in list order decides
+// the first failing part in list order decides.  Verdicts about the data come back as themselves, and so does "this machine has no
+// HIP device at all" (there is no list member to blame); everything else is the failure of ONE device of the list.
 int verdict(const std::vector<Part>& parts) {
     for (const Part& p : parts)
-        if (p.rc) return is_data_verdict(p.rc) ? p.rc : device_failed(p.device, p.index, p.rc);
+        if (p.rc) return (is_data_verdict(p.rc) || p.rc == LLCOMP_MI_NO_DEVICE) ? p.rc : device_failed(p.device, p.index, p.rc);
     return LLCOMP_MI_OK;
 }
 

@@ -232,7 +232,7 @@ int llcomp_mi_stream_create_multi(llcomp_mi_stream** out, const int32_t* devices
         llcomp_mi_stream* sub = nullptr;
         if (int rc = llcomp_mi_stream_create_ex(&sub, devices[i], w, h, c, tile_w, tile_h, planar, depth, frames_per_job)) {
             llcomp_mi_stream_destroy(s);
-            return device_failed(devices[i], i, rc);
+            return rc == LLCOMP_MI_NO_DEVICE ? rc : device_failed(devices[i], i, rc);  // (no HIP device at all: nobody of the list to blame)
         }
         s->subs.push_back(sub);
     }

@@ -75,6 +75,17 @@ def test_no_cpu_fallback(mi):
     assert e.value.status == mi.NO_DEVICE
     with pytest.raises(mi.LlcompError):
         mi.Codec(1, 64, 64, 3)
+    # ... and a device list changes nothing about that: no device at all is NO_DEVICE, not the failure of one list member
+    with pytest.raises(mi.LlcompError) as e:
+        mi.compress_image(np.zeros(64 * 64 * 3, np.uint8), 64, 64, 3, format=mi.FORMAT_SLICED, tile_w=16, tile_h=16, planar=True, devices=[0, 0])
+    assert e.value.status == mi.NO_DEVICE and mi.last_device_error() is None
+    good = bytes([0x9C, 1, 3, 1]) + b"".join(int(v).to_bytes(4, "little") for v in (8, 8, 8, 4, 6)) + (4).to_bytes(4, "little") * 6 + bytes(24)
+    with pytest.raises(mi.LlcompError) as e:
+        mi.decompress_image(good, devices=[0, 0])
+    assert e.value.status == mi.NO_DEVICE
+    with pytest.raises(mi.LlcompError) as e:
+        mi.Stream(64, 64, 3, 32, 1, True, depth=2, devices=[0, 0])
+    assert e.value.status == mi.NO_DEVICE
 
 
 def test_bench_touches_the_oracle_only_in_its_cpu_baseline_leg():
