@@ -57,7 +57,8 @@ typedef enum llcomp_mi_status {
     LLCOMP_MI_BUSY = 10,           /* streaming pipeline: every slot is occupied / the oldest job is still in flight */
     LLCOMP_MI_DEVICE_FAILED = 11   /* a call over a device list: one of the devices failed (HIP error, out of memory, no such device) and
                                       nothing was published; llcomp_mi_last_device_error tells which one and why.  Verdicts about the
-                                      DATA (BAD_EXPONENT, TRUNCATED, OUTPUT_OVERFLOW) come back as themselves from any device. */
+                                      DATA (BAD_EXPONENT, TRUNCATED, OUTPUT_OVERFLOW) come back as themselves from any device, and so
+                                      does NO_DEVICE (a machine without any HIP device: no member of the list to blame). */
 } llcomp_mi_status;
 
 typedef enum llcomp_mi_format { LLCOMP_MI_FORMAT_LEGACY = 0, LLCOMP_MI_FORMAT_SLICED = 1 } llcomp_mi_format;
