@@ -192,7 +192,8 @@ int llcomp_mi_codec_create(llcomp_mi_codec** codec, int32_t device, uint32_t fra
 int llcomp_mi_codec_create_ex(llcomp_mi_codec** codec, int32_t device, uint32_t frames, uint32_t w, uint32_t h,
                               uint32_t c, uint32_t tile_w, uint32_t tile_h, uint32_t planar, uint32_t flags);
 /* Does not wait for the device: the workspace is parked behind an event recorded on the stream of the codec's LAST encode /
- * decode (whether that call succeeded or not) and is handed out again only after it.  That stream should outlive the work
+ * decode (whether that call succeeded or not) and is handed out again only after it.  (One exception, microseconds in practice: a
+ * codec destroyed right behind a 2-D decode waits for that call's 16-byte feedback copy, whose pinned mailbox it is about to free.)  That stream should outlive the work
  * queued on it; if it is destroyed earlier (legal HIP: hipStreamDestroy drains it in the background) the library notices the
  * dead event when the blocks are taken out again and drains the whole device instead. */
 void llcomp_mi_codec_destroy(llcomp_mi_codec* codec);

@@ -258,12 +258,14 @@ void codec_release(llcomp_mi_codec* k) {
     for (auto& ev : k->ev_chunk) if (ev) (void)hipEventDestroy(ev);
     if (k->aux && !k->aux_shared) (void)hipStreamDestroy(k->aux);
     dev_free(k->d_counters, k->done);
-    if (k->fb_event) (void)hipEventDestroy(k->fb_event);  // (legal while pending: released when it completes)
     if (k->h_feedback) {
-        // the mailbox copy may still be queued on the caller's stream: it must not land in freed memory
-        if (k->done && k->done->ev) (void)hipEventSynchronize(k->done->ev);
+        // the 16-byte feedback copy of the last cached decode may still be queued on the caller's stream: it must not land in freed
+        // memory.  Its own event says when it has arrived (usually long ago); only a codec destroyed right behind such a call waits.
+        if (k->fb_pending && k->fb_event && hipEventQuery(k->fb_event) == hipErrorNotReady) (void)hipEventSynchronize(k->fb_event);
+        (void)hipGetLastError();
         (void)hipHostFree(k->h_feedback);
     }
+    if (k->fb_event) (void)hipEventDestroy(k->fb_event);
     for (auto& sp : k->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     delete k;
 }
