@@ -411,8 +411,10 @@ uint64_t llcomp_mi_pool_limit(void) { return dev_limit(); }
 uint64_t llcomp_mi_pool_idle_bytes(void) { return dev_idle_bytes(); }
 
 void* llcomp_mi_host_alloc(size_t bytes) {
+    // portable: a buffer from here is handed to EVERY device of a device list (multidev.hip: each GPU copies its rows / its payload
+    // straight out of / into the caller's buffer), not only to the device that was current when it was allocated
     void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) return nullptr;
     return p;
 }
 

@@ -203,7 +203,8 @@ int llcomp_mi_stream_create_ex(llcomp_mi_stream** out, int32_t device, uint32_t 
         sl.part_off.assign(s->fpj, 0);
         sl.part_len.assign(s->fpj, 0);
         s->out_cap = std::max<uint64_t>(s->raw * s->fpj, uint64_t(LLCOMP_MI_SLICED_HEADER_BYTES) * s->fpj + 4ull * s->spf * s->fpj + sl.lane->payload_cap);
-        if (hipHostMalloc(reinterpret_cast<void**>(&sl.h_out), s->out_cap, hipHostMallocDefault) != hipSuccess) rc = LLCOMP_MI_NOMEM;
+        // (portable: behind a device list an encode result of THIS device's pipeline is handed to the decode job of another's)
+        if (hipHostMalloc(reinterpret_cast<void**>(&sl.h_out), s->out_cap, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) rc = LLCOMP_MI_NOMEM;
         else if (hipEventCreateWithFlags(&sl.e1, hipEventDisableTiming) != hipSuccess ||
                  hipEventCreateWithFlags(&sl.e2, hipEventDisableTiming) != hipSuccess)
             rc = LLCOMP_MI_HIP_ERROR;
