@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Soak of round 6's new paths with seeds the committed tests do not use: slices above 4096 samples (chunked snapshot pass), 2-D tiles,
-and device lists against the one-device container.  python tools/attic/soak_r06.py [n]   (GPU box; prints one line per failure)"""
+and device lists against the one-device container.  Not a test (pytest does not collect it; it uses the checker, so it lives under
+tests/):  python tests/soak_r06.py [n]   (GPU box; prints one line per failure).  Round 6: 2000 rounds x 3, no failure."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import orc as orc_mod
