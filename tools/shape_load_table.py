@@ -38,9 +38,12 @@ for d in sys.argv[1:]:
             if m:
                 dur[m.group(1) + (m.group(2) or "")] = (float(row["AverageNs"]) / 1e6, int(row["Calls"]))
     tot = 0.0
+    # a kernel that is dispatched several times per encode / decode call (the chunked snapshot pass: once per chunk) counts that often
+    base_calls = max([v[1] for k_, v in dur.items() if k_.startswith("k_model_fwd")] or [1])
     for k in sorted(fetch, key=lambda k_: -(2 * fetch[k_] + write.get(k_, 0))):
-        by = (2 * fetch[k] + write.get(k, 0.0)) * 1024
-        tot += by
         ms = dur.get(k, (float("nan"), 0))
-        print(f"   {k:<52s} {ms[0]:8.3f} ms/launch under trace ({ms[1]:3d} calls)   {by / 1e9:7.2f} GB/launch = {by / samples:6.1f} B/sample")
+        times = max(1, round(ms[1] / base_calls)) if ms[1] and k.startswith("k_") and not k.startswith("k_scan_groups") else 1
+        by = (2 * fetch[k] + write.get(k, 0.0)) * 1024 * times
+        tot += by
+        print(f"   {k:<62s} {ms[0]:8.3f} ms/dispatch under trace ({ms[1]:3d} dispatches, {times} per call)   {by / 1e9:7.2f} GB/call = {by / samples:6.1f} B/sample")
     print(f"   all kernels of one encode + one decode launch: {tot / 1e9:.1f} GB = {tot / samples:.1f} B/sample\n")
